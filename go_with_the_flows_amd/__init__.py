@@ -1,0 +1,8 @@
+"""go_with_the_flows_amd -- MI355X-native discrete point-flow decoder (gfx950 HIP behind the reference's nn.Module API)."""
+from .layers import SharedDot, Swish
+from .flows import CondRealNVPFlow3D, CondRealNVPFlow3DTriple, WARP_PATTERNS
+from .decoders import LocalCondRNVPDecoder
+from ._lib import GwtfError
+
+__all__ = ['SharedDot', 'Swish', 'CondRealNVPFlow3D', 'CondRealNVPFlow3DTriple', 'LocalCondRNVPDecoder',
+           'WARP_PATTERNS', 'GwtfError']

@@ -1,0 +1,137 @@
+"""ctypes binding of libgwtf_hip.so (C ABI: include/gwtf.h).
+
+The product path has no fallback: if the shared library is missing or a call fails this module
+raises.  Calls are enqueued on torch's current HIP stream for the tensor's device.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgwtf_hip.so')
+ABI_VERSION = 1
+
+MODE_DIRECT, MODE_INVERSE = 0, 1
+_MODES = {'direct': MODE_DIRECT, 'inverse': MODE_INVERSE}
+
+_c_fp = ctypes.c_void_p
+_SIGNATURES = {
+    'gwtf_abi_version': (ctypes.c_int, []),
+    'gwtf_error_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'gwtf_padded_width': (ctypes.c_int, [ctypes.c_int]),
+    'gwtf_raw_coupling_floats': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    'gwtf_packed_w_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
+    'gwtf_packed_film_coupling_floats': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
+    'gwtf_film_out_floats': (ctypes.c_size_t, [ctypes.c_int]),
+    'gwtf_pack_weights': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_film_forward': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
+    'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+class GwtfError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises GwtfError when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GwtfError(f'{LIB_PATH} not found: build it with `make -C go_with_the_flows_amd/csrc` '
+                            '(or `python -c "import __graft_entry__ as g; g.build()"`). There is no fallback path.')
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype, fn.argtypes = res, args
+        if handle.gwtf_abi_version() != ABI_VERSION:
+            raise GwtfError(f'libgwtf_hip.so ABI {handle.gwtf_abi_version()} != expected {ABI_VERSION}; rebuild')
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise GwtfError(f'libgwtf_hip call failed ({code}): {lib().gwtf_error_string(code).decode()}')
+
+
+def _ptr(t, name):
+    """Device pointer of a tensor after the input checks the reference's native ops apply
+    (is-device + contiguous: lib/metrics/pytorch_structural_losses/src/structural_loss.cpp:10-12)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise GwtfError(f'{name} must live on a HIP device (got {t.device}); there is no CPU path')
+    if not t.is_contiguous():
+        raise GwtfError(f'{name} must be contiguous')
+    if t.dtype != torch.float32:
+        raise GwtfError(f'{name} must be float32 (got {t.dtype})')
+    return t.data_ptr()
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def padded_width(f):
+    return lib().gwtf_padded_width(f)
+
+
+def pack_weights(raw, C, f, G, training):
+    L = lib()
+    pw = torch.empty(C * L.gwtf_packed_w_coupling_floats(f), device=raw.device, dtype=torch.float32)
+    pf = torch.empty(C * L.gwtf_packed_film_coupling_floats(f, G), device=raw.device, dtype=torch.float32)
+    if raw.numel() != C * L.gwtf_raw_coupling_floats(f, G):
+        raise GwtfError(f'raw arena has {raw.numel()} floats, expected {C * L.gwtf_raw_coupling_floats(f, G)}')
+    with torch.cuda.device(raw.device):
+        check(L.gwtf_pack_weights(_ptr(raw, 'raw'), _ptr(pw, 'packed_w'), _ptr(pf, 'packed_film'), C, f, G,
+                                  int(bool(training)), _stream(raw)))
+    return pw, pf
+
+
+def film_forward(g, packed_film, C, f, eps, training, want_stats=False):
+    L = lib()
+    B, G = g.shape
+    out = torch.empty(B, C, L.gwtf_film_out_floats(f), device=g.device, dtype=torch.float32)
+    stats = torch.empty(C, 2, 2, 2, f, device=g.device, dtype=torch.float32) if (training and want_stats) else None
+    with torch.cuda.device(g.device):
+        check(L.gwtf_film_forward(_ptr(g, 'g'), _ptr(packed_film, 'packed_film'), _ptr(out, 'film_out'),
+                                  _ptr(stats, 'bn_stats'), B, G, C, f, float(eps), int(bool(training)), _stream(g)))
+    return (out, stats) if want_stats else out
+
+
+def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists):
+    L = lib()
+    B, three, N = p.shape
+    if three != 3:
+        raise GwtfError(f'p must be (B,3,N), got {tuple(p.shape)}')
+    if film.shape[0] != B or film.shape[1] != C:
+        raise GwtfError(f'film is {tuple(film.shape)}, expected ({B},{C},...)')
+    out = torch.empty_like(p)
+    logdet = torch.empty_like(p)
+    lists = torch.empty(3, C, B, 3, N, device=p.device, dtype=torch.float32) if want_lists else None
+    lp = [lists[i].data_ptr() for i in range(3)] if want_lists else [None, None, None]
+    with torch.cuda.device(p.device):
+        check(L.gwtf_stack_forward(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                   _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], B, N, C, f, pattern0, float(eps),
+                                   _MODES[mode], _stream(p)))
+    return out, logdet, lists
+
+
+def mixture_nll(z, logdet, mu0, lv0, logits, want_point_lse=False):
+    L = lib()
+    K, B, _, N = z.shape
+    nll = torch.empty(B, device=z.device, dtype=torch.float32)
+    plse = torch.empty(B, N, device=z.device, dtype=torch.float32) if want_point_lse else None
+    with torch.cuda.device(z.device):
+        check(L.gwtf_mixture_nll(_ptr(z, 'z'), _ptr(logdet, 'logdet'), _ptr(mu0, 'mu0'), _ptr(lv0, 'lv0'),
+                                 _ptr(logits, 'logits'), _ptr(plse, 'point_lse'), _ptr(nll, 'nll_shape'), K, B, N,
+                                 _stream(z)))
+    return (nll, plse) if want_point_lse else nll

@@ -1,0 +1,18 @@
+// gwtf_api.hip -- size queries, version and error text of the C ABI (include/gwtf.h).
+#include <hip/hip_runtime.h>
+#include "gwtf_layout.h"
+#include "../../include/gwtf.h"
+
+extern "C" int gwtf_abi_version(void) { return GWTF_ABI_VERSION; }
+
+extern "C" const char* gwtf_error_string(int code) {
+  if (code == 0) return "success";
+  if (code == GWTF_E_BADARG) return "gwtf: bad argument (null pointer, non-positive size, f > 64, bad mode/pattern, or B too large for train-mode FiLM)";
+  return hipGetErrorString((hipError_t)code);
+}
+
+extern "C" int gwtf_padded_width(int f) { return (f + 15) / 16 * 16; }
+extern "C" size_t gwtf_raw_coupling_floats(int f, int G) { return GwtfRaw(f, G).coupling_size(); }
+extern "C" size_t gwtf_packed_w_coupling_floats(int f) { return GwtfPackW(gwtf_padded_width(f)).coupling_size(); }
+extern "C" size_t gwtf_packed_film_coupling_floats(int f, int G) { return GwtfPackF(gwtf_padded_width(f), G).coupling_size(); }
+extern "C" size_t gwtf_film_out_floats(int f) { return gwtf_film_out_size(gwtf_padded_width(f)); }

@@ -1,0 +1,99 @@
+// Buffer layouts shared by the packer, the FiLM kernel and the fused stack kernel.
+// Everything is fp32.  "f" is the natural feature width (reference f_n_features),
+// "FP" is f rounded up to a multiple of 16 (one MFMA 16x16x4 row block), G the latent width.
+//
+// RAW ARENA (input of gwtf_pack_weights): C coupling records in direct order, each made of
+// two branch records, branch 0 = logvar, branch 1 = mu.  A branch record is the reference's
+// parameters and BatchNorm buffers (lib/networks/flows.py:25-50 / 60-85) flattened row-major in
+// this order (k = kept coordinates padded to 2 columns with zeros, w = warped padded to 2 rows):
+//   sd0.weight[f][2] | sd0_bn.{weight,bias,running_mean,running_var}[f] | sd1.weight[f][f] |
+//   sd1_bn.{running_mean,running_var}[f] |
+//   film_w0.weight[f][G] | film_w0_bn.{weight,bias,running_mean,running_var}[f] | film_w1.weight[f][f] | film_w1.bias[f] |
+//   film_b0.weight[f][G] | film_b0_bn.{...}[f] | film_b1.weight[f][f] | film_b1.bias[f] |
+//   sd2.weight[2][f] | sd2.bias[2]
+#pragma once
+#include <stddef.h>
+
+#ifdef __HIPCC__
+#define GWTF_HD __host__ __device__ inline
+#else
+#define GWTF_HD static inline
+#endif
+
+#define GWTF_BN_EPS 1e-5f
+#define GWTF_MAX_FP 64
+
+struct GwtfRaw {  // offsets inside one branch record
+  int f, G;
+  GWTF_HD GwtfRaw(int f_, int G_) : f(f_), G(G_) {}
+  GWTF_HD size_t sd0_w() const { return 0; }
+  GWTF_HD size_t bn0() const { return (size_t)2 * f; }              // gamma, beta, rm, rv
+  GWTF_HD size_t sd1_w() const { return (size_t)6 * f; }
+  GWTF_HD size_t bn1() const { return (size_t)6 * f + (size_t)f * f; }  // rm, rv
+  GWTF_HD size_t film_size() const { return (size_t)f * G + 5 * (size_t)f + (size_t)f * f; }
+  GWTF_HD size_t film(int which) const { return (size_t)8 * f + (size_t)f * f + which * film_size(); }
+  GWTF_HD size_t film_l0(int which) const { return film(which); }
+  GWTF_HD size_t film_bn(int which) const { return film(which) + (size_t)f * G; }
+  GWTF_HD size_t film_l1(int which) const { return film_bn(which) + 4 * (size_t)f; }
+  GWTF_HD size_t film_l1b(int which) const { return film_l1(which) + (size_t)f * f; }
+  GWTF_HD size_t sd2_w() const { return film(2); }
+  GWTF_HD size_t sd2_b() const { return sd2_w() + 2 * (size_t)f; }
+  GWTF_HD size_t branch_size() const { return sd2_b() + 2; }
+  GWTF_HD size_t coupling_size() const { return 2 * branch_size(); }
+};
+
+// PACKED STACK WEIGHTS (read by the fused kernel through LDS), per coupling:
+//   Aimg[branch][kk][lane][MBS]  : sd1 weight with sd1_bn's 1/sqrt(var+eps) folded into its rows, in
+//                                  MFMA-A fragment order: value W[16*m + (lane&15)][4*kk + (lane>>4)]
+//   sd0[branch][FP] float4       : {w0[j][0]*s, w0[j][1]*s, beta - mean*s, 0},  s = gamma/sqrt(var+eps)
+struct GwtfPackW {
+  int FP;
+  GWTF_HD GwtfPackW(int FP_) : FP(FP_) {}
+  GWTF_HD int MB() const { return FP / 16; }
+  GWTF_HD int MBS() const { return MB() == 3 ? 4 : MB(); }  // per-lane stride: keep ds_read 16-B aligned
+  GWTF_HD int KK() const { return FP / 4; }
+  GWTF_HD size_t aimg_size() const { return (size_t)KK() * 64 * MBS(); }
+  GWTF_HD size_t aimg(int branch) const { return branch * aimg_size(); }
+  GWTF_HD size_t sd0(int branch) const { return 2 * aimg_size() + (size_t)branch * 4 * FP; }
+  GWTF_HD size_t coupling_size() const { return 2 * aimg_size() + 8 * (size_t)FP; }
+};
+
+// PACKED FILM WEIGHTS (read by gwtf_film_forward), per coupling, per branch:
+//   for which in {w,b}: L0T[G][FP] | S[FP] | T[FP] | L1T[FP][FP] | L1B[FP]
+//   C1[FP] (sd1_bn shift: -mean/sqrt(var+eps)) | W2[2][FP] | B2[4] (sd2 bias, 2 used)
+// eval: S = gamma/sqrt(var+eps), T = beta - mean*S (running statistics)
+// train: S = gamma, T = beta (batch statistics are taken inside the FiLM kernel)
+struct GwtfPackF {
+  int FP, G;
+  GWTF_HD GwtfPackF(int FP_, int G_) : FP(FP_), G(G_) {}
+  GWTF_HD size_t mlp_size() const { return (size_t)G * FP + 3 * (size_t)FP + (size_t)FP * FP; }
+  GWTF_HD size_t l0t(int which) const { return which * mlp_size(); }
+  GWTF_HD size_t s(int which) const { return l0t(which) + (size_t)G * FP; }
+  GWTF_HD size_t t(int which) const { return s(which) + FP; }
+  GWTF_HD size_t l1t(int which) const { return t(which) + FP; }
+  GWTF_HD size_t l1b(int which) const { return l1t(which) + (size_t)FP * FP; }
+  GWTF_HD size_t c1() const { return 2 * mlp_size(); }
+  GWTF_HD size_t w2() const { return c1() + FP; }
+  GWTF_HD size_t b2() const { return w2() + 2 * (size_t)FP; }
+  GWTF_HD size_t branch_size() const { return b2() + 4; }
+  GWTF_HD size_t coupling_size() const { return 2 * branch_size(); }
+};
+
+// FILM OUTPUT (written by gwtf_film_forward, read by the fused kernel through LDS), per (shape b, coupling c):
+//   epi[branch][FP] float4 : {a, a*C1 + b, W2[0][j], W2[1][j]} with a = eps + exp(cond_w(g)), b = cond_b(g)
+//   bias float4            : {b2_logvar[0], b2_logvar[1], b2_mu[0], b2_mu[1]}
+GWTF_HD size_t gwtf_film_out_size(int FP) { return 8 * (size_t)FP + 4; }
+
+// warp pattern of coupling c in direct order (reference flows.py:129-148, decoders.py:49-52):
+// index (pattern0 + c) % 6 -> 0:[0] 1:[1] 2:[2] 3:[0,1] 4:[0,2] 5:[1,2]
+GWTF_HD void gwtf_pattern_dims(int pat, int* k0, int* k1, int* w0, int* w1) {
+  // kept dims (k1 = -1 when only... two kept -> both valid), warped dims (w1 = -1 when one warped)
+  switch (pat) {
+    case 0: *w0 = 0; *w1 = -1; *k0 = 1; *k1 = 2; break;
+    case 1: *w0 = 1; *w1 = -1; *k0 = 0; *k1 = 2; break;
+    case 2: *w0 = 2; *w1 = -1; *k0 = 0; *k1 = 1; break;
+    case 3: *w0 = 0; *w1 = 1; *k0 = 2; *k1 = -1; break;
+    case 4: *w0 = 0; *w1 = 2; *k0 = 1; *k1 = -1; break;
+    default: *w0 = 1; *w1 = 2; *k0 = 0; *k1 = -1; break;
+  }
+}

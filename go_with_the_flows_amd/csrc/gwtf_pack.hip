@@ -1,0 +1,116 @@
+// gwtf_pack.hip -- weight packer: raw arena -> (MFMA-fragment-ordered stack weights, FiLM weights).
+// One thread per OUTPUT element, grid-stride; pure gather + BatchNorm folding, HBM/L2 bound and tiny
+// (a few hundred KB).  Layouts: gwtf_layout.h.  Arithmetic being folded: reference
+// lib/networks/flows.py:25-31 (sd0 -> BN -> ReLU -> sd1 -> BN(affine=False)) in eval mode.
+#include <hip/hip_runtime.h>
+#include "gwtf_layout.h"
+#include "../../include/gwtf.h"
+
+namespace {
+
+__device__ __forceinline__ float inv_std(float var) { return 1.0f / sqrtf(var + GWTF_BN_EPS); }
+
+// packed stack weights
+__global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__ out, int C, int f, int G, int FP) {
+  const GwtfRaw R(f, G);
+  const GwtfPackW P(FP);
+  const size_t per = P.coupling_size();
+  const size_t total = per * (size_t)C;
+  const int MBS = P.MBS();
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx / per);
+    size_t o = idx - (size_t)c * per;
+    float v = 0.f;
+    if (o < 2 * P.aimg_size()) {
+      const int br = (int)(o / P.aimg_size());
+      o -= (size_t)br * P.aimg_size();
+      const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
+      const int m = (int)(o % MBS);
+      const int lane = (int)((o / MBS) % 64);
+      const int kk = (int)(o / ((size_t)MBS * 64));
+      const int j = 16 * m + (lane & 15);   // output feature (row of sd1.weight)
+      const int i = 4 * kk + (lane >> 4);   // input feature
+      if (m < P.MB() && j < f && i < f) v = rb[R.sd1_w() + (size_t)j * f + i] * inv_std(rb[R.bn1() + f + j]);
+    } else {
+      o -= 2 * P.aimg_size();
+      const int br = (int)(o / (4 * (size_t)FP));
+      o -= (size_t)br * 4 * FP;
+      const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
+      const int j = (int)(o / 4), e = (int)(o % 4);
+      if (j < f) {
+        const float* bn = rb + R.bn0();
+        const float s = bn[j] * inv_std(bn[3 * f + j]);
+        if (e < 2) v = rb[R.sd0_w() + 2 * j + e] * s;
+        else if (e == 2) v = bn[f + j] - bn[2 * f + j] * s;
+      }
+    }
+    out[idx] = v;
+  }
+}
+
+// packed FiLM weights
+__global__ void pack_film_kernel(const float* __restrict__ raw, float* __restrict__ out, int C, int f, int G, int FP,
+                                 int training) {
+  const GwtfRaw R(f, G);
+  const GwtfPackF P(FP, G);
+  const size_t perb = P.branch_size();
+  const size_t total = perb * 2 * (size_t)C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cb = (int)(idx / perb);  // coupling*2 + branch
+    size_t o = idx - (size_t)cb * perb;
+    const float* rb = raw + (size_t)cb * R.branch_size();  // coupling_size == 2*branch_size
+    float v = 0.f;
+    if (o < P.c1()) {
+      const int which = (int)(o / P.mlp_size());
+      o -= (size_t)which * P.mlp_size();
+      const float* bn = rb + R.film_bn(which);
+      if (o < (size_t)G * FP) {  // L0T[i][j] = L0[j][i]
+        const int i = (int)(o / FP), j = (int)(o % FP);
+        if (j < f) v = rb[R.film_l0(which) + (size_t)j * G + i];
+      } else if ((o -= (size_t)G * FP) < (size_t)FP) {  // S
+        const int j = (int)o;
+        if (j < f) v = training ? bn[j] : bn[j] * inv_std(bn[3 * f + j]);
+      } else if ((o -= FP) < (size_t)FP) {  // T
+        const int j = (int)o;
+        if (j < f) v = training ? bn[f + j] : bn[f + j] - bn[2 * f + j] * (bn[j] * inv_std(bn[3 * f + j]));
+      } else if ((o -= FP) < (size_t)FP * FP) {  // L1T[i][j] = L1[j][i]
+        const int i = (int)(o / FP), j = (int)(o % FP);
+        if (i < f && j < f) v = rb[R.film_l1(which) + (size_t)j * f + i];
+      } else {  // L1B
+        const int j = (int)(o - (size_t)FP * FP);
+        if (j < f) v = rb[R.film_l1b(which) + j];
+      }
+    } else if ((o -= P.c1()) < (size_t)FP) {  // C1 = -mean/sqrt(var+eps) of sd1_bn
+      const int j = (int)o;
+      if (j < f) v = -rb[R.bn1() + j] * inv_std(rb[R.bn1() + f + j]);
+    } else if ((o -= FP) < 2 * (size_t)FP) {  // W2[w][j]
+      const int w = (int)(o / FP), j = (int)(o % FP);
+      if (j < f) v = rb[R.sd2_w() + (size_t)w * f + j];
+    } else {  // B2
+      const int e = (int)(o - 2 * (size_t)FP);
+      if (e < 2) v = rb[R.sd2_b() + e];
+    }
+    out[idx] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film, int C, int f, int G,
+                                 int training, void* stream) {
+  if (C <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_w || !packed_film) return GWTF_E_BADARG;
+  const int FP = gwtf_padded_width(f);
+  hipStream_t st = (hipStream_t)stream;
+  const int threads = 256;
+  {
+    const size_t total = GwtfPackW(FP).coupling_size() * (size_t)C;
+    const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
+    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_w, C, f, G, FP);
+  }
+  {
+    const size_t total = GwtfPackF(FP, G).coupling_size() * (size_t)C;
+    const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
+    hipLaunchKernelGGL(pack_film_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,300 @@
+// gwtf_stack.hip -- the fused coupling-stack kernel (forward / inverse + log-det), gfx950.
+//
+// One launch applies all C elementary couplings (reference lib/networks/flows.py:95-117, stacked by
+// flows.py:150-160 and decoders.py:61-79) to every point and accumulates sum(logvars)
+// (losses.py:14,115).  Coordinates and log-det stay in registers for the whole stack; HBM traffic is
+// 12 B/pt in, 24 B/pt out (+36 B/pt per coupling only when the reference's per-layer lists are asked for).
+//
+// Work decomposition
+//   workgroup = 4 waves, one shape b, 4*16*NB consecutive points; wave = 16*NB points.
+//   The f x f per-point contraction (sd1) runs on v_mfma_f32_16x16x4_f32 with features on M and points on N:
+//     A[i][k] = W1'[16m+i][4kk+k]   (sd1 weight, sd1_bn scale folded; fragment-ordered image in LDS)
+//     B[k][j] = h0[4kk+k][point j]  (sd0 + sd0_bn + ReLU, computed in the lane that owns (k,j) -- 3 VALU ops)
+//     D[16m + 4q + r][point j]      (q = lane>>4, r = accumulator register)
+//   so FiLM + ReLU + the f->w contraction (sd2) happen in-lane on the accumulators, followed by a
+//   transpose-reduce over the four lane quarters that leaves quarter q with the totals of point block q.
+//   Each lane then owns ONE point for the transcendental tail (softsign, exp, sqrt, affine) and the
+//   log-det accumulation; new coordinates are re-broadcast to the quarters with ds_bpermute.
+//   Per coupling the packed weights (2*FP^2 + 8*FP floats) and this shape's FiLM vectors are copied
+//   global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double buffer while the previous coupling
+//   computes; one barrier per coupling.
+#include <hip/hip_runtime.h>
+#include "gwtf_layout.h"
+#include "../../include/gwtf.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int MB>
+struct Cfg {
+  static constexpr int FP = 16 * MB;
+  static constexpr int KK = FP / 4;
+  static constexpr int MBS = MB == 3 ? 4 : MB;
+  static constexpr int AIMG = KK * 64 * MBS;           // floats, one branch
+  static constexpr int PW = 2 * AIMG + 8 * FP;         // packed weights per coupling
+  static constexpr int FS = 8 * FP + 4;                // FiLM output per (shape, coupling)
+  static constexpr int LAYER = PW + FS;                // one LDS buffer, multiple of 4 floats
+  static constexpr int LAYER_PAD = (LAYER + 255) / 256 * 256;  // whole 1-KiB DMA pieces
+};
+
+__device__ __forceinline__ float sel3(float a, float b, float c, int d) { return d == 0 ? a : (d == 1 ? b : c); }
+
+template <int MB>
+__device__ __forceinline__ void load_afrag(const float* p, float (&a)[MB]);
+template <>
+__device__ __forceinline__ void load_afrag<1>(const float* p, float (&a)[1]) { a[0] = p[0]; }
+template <>
+__device__ __forceinline__ void load_afrag<2>(const float* p, float (&a)[2]) {
+  const float2 v = *reinterpret_cast<const float2*>(p);
+  a[0] = v.x; a[1] = v.y;
+}
+template <>
+__device__ __forceinline__ void load_afrag<3>(const float* p, float (&a)[3]) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  a[0] = v[0]; a[1] = v[1]; a[2] = v[2];
+}
+template <>
+__device__ __forceinline__ void load_afrag<4>(const float* p, float (&a)[4]) {
+  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+  a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+}
+
+// Sum the per-quarter partials o[nb] over the four 16-lane quarters so that the lane in quarter q ends
+// with the total of point block (q & (NB-1)).
+template <int NB>
+__device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
+  if constexpr (NB == 4) {
+    const bool hi = q >= 2, odd = q & 1;
+    const float s0 = hi ? o[0] : o[2], s1 = hi ? o[1] : o[3];
+    const float t0 = (hi ? o[2] : o[0]) + __shfl_xor(s0, 32);
+    const float t1 = (hi ? o[3] : o[1]) + __shfl_xor(s1, 32);
+    return (odd ? t1 : t0) + __shfl_xor(odd ? t0 : t1, 16);
+  } else if constexpr (NB == 2) {
+    const bool odd = q & 1;
+    const float t0 = o[0] + __shfl_xor(o[0], 32);
+    const float t1 = o[1] + __shfl_xor(o[1], 32);
+    return (odd ? t1 : t0) + __shfl_xor(odd ? t0 : t1, 16);
+  } else {
+    float t = o[0] + __shfl_xor(o[0], 32);
+    return t + __shfl_xor(t, 16);
+  }
+}
+
+template <int MB, int NB, int MODE, bool LISTS>
+__global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p, const float* __restrict__ pw,
+                                                    const float* __restrict__ film, float* __restrict__ out,
+                                                    float* __restrict__ logdet, float* __restrict__ ps,
+                                                    float* __restrict__ mus, float* __restrict__ lvs, int B, int N, int C,
+                                                    int pattern0, float eps, int tiles_per_shape) {
+  using K = Cfg<MB>;
+  constexpr int FP = K::FP, KK = K::KK, MBS = K::MBS;
+  __shared__ __align__(16) float lds[2][K::LAYER_PAD];
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int b = blockIdx.x / tiles_per_shape;
+  const int tile = blockIdx.x - b * tiles_per_shape;
+  const int n_wave0 = (tile * 4 + wave) * 16 * NB;
+  const int own_nb = q & (NB - 1);
+  const int n_own = n_wave0 + 16 * own_nb + i16;
+  const bool own_valid = n_own < N && q < NB;  // q >= NB holds duplicates of quarter q & (NB-1)
+  const bool own_inrange = n_own < N;
+
+  // global -> LDS staging of one coupling (LDS-DMA, 1 KiB per wave-instruction)
+  auto stage = [&](int buf, int c) {
+    const float* src_w = pw + (size_t)c * K::PW;
+    const float* src_f = film + ((size_t)b * C + c) * K::FS;
+    constexpr int PIECES = K::LAYER_PAD / 256;
+    for (int piece = wave; piece < PIECES; piece += 4) {
+      const int fo = piece * 256 + lane * 4;  // float offset inside the layer image
+      if (fo < K::LAYER) {
+        const float* src = fo < K::PW ? src_w + fo : src_f + (fo - K::PW);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
+      }
+    }
+  };
+
+  // this lane's own point (one per lane) and the per-quarter copies used to build the MFMA B operand
+  float xo[3], ld[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) xo[d] = own_inrange ? p[((size_t)b * 3 + d) * N + n_own] : 0.f;
+  float x[NB][3];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) x[nb][d] = __shfl(xo[d], 16 * nb + i16);
+
+  stage(0, MODE == GWTF_MODE_INVERSE ? C - 1 : 0);
+  const float s_keep = sqrtf(eps + 1.0f);  // scale applied to un-warped coordinates (reference quirk)
+
+  for (int step = 0; step < C; ++step) {
+    const int c = MODE == GWTF_MODE_INVERSE ? C - 1 - step : step;
+    const int buf = step & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (step + 1 < C) stage(buf ^ 1, MODE == GWTF_MODE_INVERSE ? c - 1 : c + 1);
+
+    const float* L = lds[buf];
+    int k0, k1, w0, w1;
+    gwtf_pattern_dims((pattern0 + c) % 6, &k0, &k1, &w0, &w1);
+    float xa[NB], xb[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
+      xb[nb] = k1 < 0 ? 0.f : sel3(x[nb][0], x[nb][1], x[nb][2], k1);
+    }
+
+    float res[2][2];  // [branch][warped slot] for this lane's own point
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+      f32x4 acc[MB][NB];
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* aimg = L + br * K::AIMG + lane * MBS;
+      const f32x4* sd0 = reinterpret_cast<const f32x4*>(L + 2 * K::AIMG + br * 4 * FP) + q;
+#pragma unroll 4
+      for (int kk = 0; kk < KK; ++kk) {
+        const f32x4 s0 = sd0[4 * kk];
+        float a[MB];
+        load_afrag<MB>(aimg + kk * 64 * MBS, a);
+        float h[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) h[nb] = fmaxf(fmaf(s0[0], xa[nb], fmaf(s0[1], xb[nb], s0[2])), 0.f);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], h[nb], acc[m][nb], 0, 0, 0);
+      }
+      // FiLM + ReLU + sd2 on the accumulators
+      const f32x4* epi = reinterpret_cast<const f32x4*>(L + K::PW + br * 4 * FP) + 4 * q;
+      float o0[NB], o1[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) o0[nb] = o1[nb] = 0.f;
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const f32x4 e = epi[16 * m + r];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float v = fmaxf(fmaf(e[0], acc[m][nb][r], e[1]), 0.f);
+            o0[nb] = fmaf(e[2], v, o0[nb]);
+            o1[nb] = fmaf(e[3], v, o1[nb]);
+          }
+        }
+      res[br][0] = quarter_reduce<NB>(o0, q);
+      res[br][1] = quarter_reduce<NB>(o1, q);
+    }
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 8 * FP);
+
+    // transcendental tail on this lane's own point
+    float lv_w[2], mu_w[2], sc_w[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float t = res[0][s] + bias[s];
+      lv_w[s] = t / (1.0f + fabsf(t));                 // softsign (flows.py:99)
+      mu_w[s] = res[1][s] + bias[2 + s];
+      sc_w[s] = sqrtf(eps + expf(lv_w[s]));            // flows.py:113,115
+    }
+    float mu_d[3], lv_d[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const bool is0 = d == w0, is1 = d == w1;
+      lv_d[d] = is0 ? lv_w[0] : (is1 ? lv_w[1] : 0.f);
+      mu_d[d] = is0 ? mu_w[0] : (is1 ? mu_w[1] : 0.f);
+      const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : s_keep);
+      if (MODE == GWTF_MODE_DIRECT)
+        xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
+      else
+        xo[d] = __fdiv_rn(__fsub_rn(xo[d], mu_d[d]), sc);
+      ld[d] += lv_d[d];
+    }
+    if (LISTS && own_valid) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const size_t o = (((size_t)c * B + b) * 3 + d) * N + n_own;
+        ps[o] = xo[d];
+        mus[o] = mu_d[d];
+        lvs[o] = lv_d[d];
+      }
+    }
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) x[nb][d] = __shfl(xo[d], 16 * nb + i16);
+  }
+
+  if (own_valid) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const size_t o = ((size_t)b * 3 + d) * N + n_own;
+      out[o] = xo[d];
+      logdet[o] = ld[d];
+    }
+  }
+}
+
+template <int MB, int NB>
+int launch(const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps, float* mus,
+           float* lvs, int B, int N, int C, int pattern0, float eps, int mode, hipStream_t st) {
+  const int pts_wg = 4 * 16 * NB;
+  const int tiles = (N + pts_wg - 1) / pts_wg;
+  const dim3 grid((unsigned)(B * tiles)), block(256);
+  const bool lists = ps != nullptr;
+#define GWTF_LAUNCH(MODE_, LISTS_)                                                                                      \
+  hipLaunchKernelGGL((stack_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, \
+                     B, N, C, pattern0, eps, tiles)
+  if (mode == GWTF_MODE_DIRECT) {
+    if (lists) GWTF_LAUNCH(GWTF_MODE_DIRECT, true); else GWTF_LAUNCH(GWTF_MODE_DIRECT, false);
+  } else {
+    if (lists) GWTF_LAUNCH(GWTF_MODE_INVERSE, true); else GWTF_LAUNCH(GWTF_MODE_INVERSE, false);
+  }
+#undef GWTF_LAUNCH
+  return (int)hipGetLastError();
+}
+
+template <int MB>
+int launch_nb(int nb, const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps,
+              float* mus, float* lvs, int B, int N, int C, int pattern0, float eps, int mode, hipStream_t st) {
+  switch (nb) {
+    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, st);
+    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, st);
+    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, st);
+  }
+}
+
+int g_force_nb = 0;  // test/tuning hook, see gwtf_debug_set_points_per_wave
+
+}  // namespace
+
+extern "C" void gwtf_debug_set_points_per_wave(int pts) { g_force_nb = pts / 16; }
+
+extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const float* film, float* out, float* logdet,
+                                  float* ps, float* mus, float* logvars, int B, int N, int C, int f, int pattern0,
+                                  float eps, int mode, void* stream) {
+  if (B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || !p || !packed_w || !film || !out || !logdet)
+    return GWTF_E_BADARG;
+  if (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) return GWTF_E_BADARG;
+  if (pattern0 < 0 || pattern0 > 5) return GWTF_E_BADARG;
+  const bool any = ps || mus || logvars, all = ps && mus && logvars;
+  if (any && !all) return GWTF_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  // points per wave: enough workgroups to give every SIMD two waves when the problem allows it
+  int nb = g_force_nb;
+  if (nb != 1 && nb != 2 && nb != 4) {
+    const long pts = (long)B * N;
+    nb = pts >= 4L * 2048 * 64 ? 4 : (pts >= 2L * 2048 * 32 ? 2 : 1);
+  }
+  switch (gwtf_padded_width(f) / 16) {
+    case 1: return launch_nb<1>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
+    case 2: return launch_nb<2>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
+    case 3: return launch_nb<3>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
+    case 4: return launch_nb<4>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
+    default: return GWTF_E_BADARG;
+  }
+}

@@ -1,0 +1,243 @@
+"""Conditional affine couplings of the discrete point flow, MI355X-native.
+
+Same constructor signatures, attribute names, ``state_dict`` keys and ``forward(p, g, mode)``
+contract as the reference's ``lib/networks/flows.py`` (``CondRealNVPFlow3D`` :10-117,
+``CondRealNVPFlow3DTriple`` :120-160).  The sub-modules below only HOLD parameters and
+BatchNorm buffers under the reference's names; they are never called.  All arithmetic runs in
+hand-written HIP kernels (``csrc/``) through the C ABI in ``include/gwtf.h``: one weight-pack
+launch (cached while parameters are unchanged), one FiLM launch, one fused stack launch.
+There is no torch/CPU fallback: tensors must live on a HIP device.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .layers import SharedDot, Swish
+
+# index -> warped coordinates; couplings of a decoder cycle through these (reference flows.py:129-148)
+WARP_PATTERNS = ((0,), (1,), (2,), (0, 1), (0, 2), (1, 2))
+
+
+def _film_head(X, which, f, G):
+    n = f'{X}_sd1_film_{which}'
+    return nn.Sequential(OrderedDict([
+        (n + '0', nn.Linear(G, f, bias=False)),
+        (n + '0_bn', nn.BatchNorm1d(f)),
+        (n + '0_swish', Swish()),
+        (n + '1', nn.Linear(f, f, bias=True)),
+    ]))
+
+
+class CondRealNVPFlow3D(nn.Module):
+    """One elementary coupling: kept coordinates -> (mu, logvar) of the warped ones, conditioned on g."""
+
+    def __init__(self, f_n_features, g_n_features, weight_std=0.01, warp_inds=[0],
+                 centered_translation=False, eps=1e-6):
+        super().__init__()
+        self.f_n_features, self.g_n_features = f_n_features, g_n_features
+        self.weight_std = weight_std
+        self.warp_inds = list(warp_inds)
+        if tuple(self.warp_inds) not in WARP_PATTERNS:
+            raise ValueError(f'warp_inds {warp_inds} is not one of {WARP_PATTERNS}')
+        self.keep_inds = [d for d in (0, 1, 2) if d not in self.warp_inds]
+        self.centered_translation = centered_translation  # stored, never used (as in the reference)
+        self.register_buffer('eps', torch.tensor([eps], dtype=torch.float32))
+        self._eps_value = float(eps)
+        f, G, k, w = f_n_features, g_n_features, len(self.keep_inds), len(self.warp_inds)
+        for X in ('mu', 'logvar'):
+            setattr(self, f'T_{X}_0', nn.Sequential(OrderedDict([
+                (f'{X}_sd0', SharedDot(k, f, 1)),
+                (f'{X}_sd0_bn', nn.BatchNorm1d(f)),
+                (f'{X}_sd0_relu', nn.ReLU(inplace=True)),
+                (f'{X}_sd1', SharedDot(f, f, 1)),
+                (f'{X}_sd1_bn', nn.BatchNorm1d(f, affine=False)),
+            ])))
+            setattr(self, f'T_{X}_0_cond_w', _film_head(X, 'w', f, G))
+            setattr(self, f'T_{X}_0_cond_b', _film_head(X, 'b', f, G))
+            setattr(self, f'T_{X}_1', nn.Sequential(OrderedDict([
+                (f'{X}_sd1_relu', nn.ReLU(inplace=True)),
+                (f'{X}_sd2', SharedDot(f, w, 1, bias=True)),
+            ])))
+            # near-identity start: last layers ~ N(0, weight_std), zero bias (reference flows.py:52-58,87-93)
+            with torch.no_grad():
+                for head in (getattr(self, f'T_{X}_0_cond_w')[-1], getattr(self, f'T_{X}_0_cond_b')[-1],
+                             getattr(self, f'T_{X}_1')[-1]):
+                    head.weight.normal_(std=weight_std)
+                    head.bias.zero_()
+        self._engine = None
+        self._stamp = 0
+
+    # -- parameter gathering -------------------------------------------------------------------
+    def raw_tensors(self):
+        """This coupling's record of the raw arena, in the order fixed by csrc/gwtf_layout.h."""
+        out = []
+        k, w = len(self.keep_inds), len(self.warp_inds)
+        for X in ('logvar', 'mu'):
+            t0 = getattr(self, f'T_{X}_0')
+            sd0, bn0, sd1, bn1 = t0[0], t0[1], t0[3], t0[4]
+            w0 = sd0.weight[0]
+            out += [F.pad(w0, (0, 2 - k)) if k < 2 else w0, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var,
+                    sd1.weight[0], bn1.running_mean, bn1.running_var]
+            for which in ('w', 'b'):
+                head = getattr(self, f'T_{X}_0_cond_{which}')
+                out += [head[0].weight, head[1].weight, head[1].bias, head[1].running_mean, head[1].running_var,
+                        head[3].weight, head[3].bias]
+            sd2 = getattr(self, f'T_{X}_1')[1]
+            w2, b2 = sd2.weight[0], sd2.bias[0]
+            out += [F.pad(w2, (0, 0, 0, 2 - w)) if w < 2 else w2, F.pad(b2, (0, 2 - w)) if w < 2 else b2]
+        return out
+
+    def tracked_tensors(self):
+        """Every tensor whose in-place modification must invalidate the packed-weight cache."""
+        return [t for t in list(self.parameters()) + list(self.buffers()) if t.dtype == torch.float32]
+
+    # -- packed-weight cache invalidation ---------------------------------------------------------
+    # The reference optimiser writes through ``p.data`` (lib/networks/optimizers.py:69-72), which does
+    # not bump tensor version counters, so besides versions the cache is keyed on a stamp bumped by
+    # everything a training script does between two eval forwards: train()/eval(), .to()/.cuda(),
+    # load_state_dict().  Call ``invalidate_packed_weights()`` after any other out-of-band edit.
+    def invalidate_packed_weights(self):
+        self._stamp = getattr(self, '_stamp', 0) + 1
+
+    def train(self, mode=True):
+        self.invalidate_packed_weights()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_packed_weights()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        self.invalidate_packed_weights()
+        if prefix + 'eps' in state_dict:
+            self._eps_value = float(state_dict[prefix + 'eps'].reshape(-1)[0])
+
+    def forward(self, p, g, mode='direct'):
+        """-> (p_out, mu, logvar), each (B,3,N); reference flows.py:95-117."""
+        if self._engine is None:
+            self._engine = StackEngine([self])
+        ps, mus, lvs = self._engine.run_lists(p, g, mode)
+        return ps[0], mus[0], lvs[0]
+
+
+class CondRealNVPFlow3DTriple(nn.Module):
+    """Three couplings warping [0],[1],[2] (pattern 0) or [0,1],[0,2],[1,2] (pattern 1)."""
+
+    def __init__(self, f_n_features, g_n_features, weight_std=0.02, pattern=0, centered_translation=False):
+        super().__init__()
+        if pattern not in (0, 1):
+            raise ValueError(f'pattern must be 0 or 1, got {pattern}')
+        self.f_n_features, self.g_n_features = f_n_features, g_n_features
+        self.weight_std, self.pattern, self.centered_translation = weight_std, pattern, centered_translation
+        for j in range(3):
+            setattr(self, f'nvp{j + 1}', CondRealNVPFlow3D(
+                f_n_features, g_n_features, weight_std=weight_std, warp_inds=list(WARP_PATTERNS[3 * pattern + j]),
+                centered_translation=centered_translation))
+        self._engine = None
+
+    def couplings(self):
+        return [self.nvp1, self.nvp2, self.nvp3]
+
+    def forward(self, p, g, mode='direct'):
+        """-> ([p1,p2,p3], [mu1..3], [logvar1..3]) in nvp1..3 order for both modes; reference flows.py:150-160."""
+        if self._engine is None:
+            self._engine = StackEngine(self.couplings())
+        return self._engine.run_lists(p, g, mode)
+
+
+class _NoBackwardYet(torch.autograd.Function):
+    """Keeps outputs attached to the graph so a training script fails loudly AT backward rather
+    than silently training nothing.  The HIP backward kernels replace this."""
+
+    @staticmethod
+    def forward(ctx, raw, p, g, *outs):
+        ctx.mark_non_differentiable()
+        return tuple(o.view_as(o) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        raise NotImplementedError('go_with_the_flows_amd: the HIP backward of the coupling stack is not built yet; '
+                                  'run the forward under torch.no_grad() (there is no autograd/CPU fallback)')
+
+
+class StackEngine:
+    """Host-side driver of the HIP path for a run of consecutive couplings (direct order).
+
+    Gathers the couplings' parameters into the raw arena, packs them (cached until a parameter or
+    buffer changes), runs the FiLM kernel and the fused stack kernel."""
+
+    def __init__(self, couplings):
+        self.couplings = list(couplings)
+        c0 = self.couplings[0]
+        self.C = len(self.couplings)
+        self.f, self.G = c0.f_n_features, c0.g_n_features
+        pats = [WARP_PATTERNS.index(tuple(c.warp_inds)) for c in self.couplings]
+        self.pattern0 = pats[0]
+        if any(pt != (self.pattern0 + i) % 6 for i, pt in enumerate(pats)):
+            raise ValueError(f'couplings do not follow the cyclic warp pattern: {pats}')
+        if self.f > 64:
+            raise NotImplementedError(f'f_n_features={self.f} > 64 is not supported by the gfx950 kernels yet')
+        self._tracked, self._tracked_stamp = [], None
+        self._cache_key = None
+        self._packed = None
+
+    def raw_arena(self):
+        return torch.cat([t.reshape(-1) for c in self.couplings for t in c.raw_tensors()])
+
+    def _key(self, training):
+        stamp = sum(c._stamp for c in self.couplings)
+        if stamp != self._tracked_stamp:  # buffers are re-created by .to()/.cuda(): re-collect
+            self._tracked = [t for c in self.couplings for t in c.tracked_tensors()]
+            self._tracked_stamp = stamp
+        return (training, stamp, sum(t._version for t in self._tracked))
+
+    def packed(self, training):
+        key = self._key(training)
+        if key != self._cache_key:
+            with torch.no_grad():
+                raw = self.raw_arena()
+                self._packed = _lib.pack_weights(raw, self.C, self.f, self.G, training)
+            self._cache_key = key
+        return self._packed
+
+    def _check(self, p, g):
+        dev = self.couplings[0].eps.device
+        if dev.type != 'cuda':
+            raise _lib.GwtfError('module parameters are on the CPU: move the module to a HIP device (.cuda()); '
+                                 'go_with_the_flows_amd has no CPU path')
+        if p.dim() != 3 or p.shape[1] != 3:
+            raise ValueError(f'p must be (B,3,N), got {tuple(p.shape)}')
+        if g.dim() != 2 or g.shape[0] != p.shape[0] or g.shape[1] != self.G:
+            raise ValueError(f'g must be ({p.shape[0]},{self.G}), got {tuple(g.shape)}')
+        if p.device != dev or g.device != dev:
+            raise _lib.GwtfError(f'p ({p.device}) / g ({g.device}) must be on the module device {dev}')
+
+    def run(self, p, g, mode, want_lists):
+        if mode not in ('direct', 'inverse'):
+            raise ValueError(f"mode must be 'direct' or 'inverse', got {mode!r}")
+        self._check(p, g)
+        c0 = self.couplings[0]
+        if c0.training:
+            raise NotImplementedError('train-mode BatchNorm (batch statistics) HIP path is not built yet; '
+                                      'call .eval() -- there is no torch fallback')
+        pw, pf = self.packed(False)
+        pc, gc = p.contiguous().float(), g.contiguous().float()
+        eps = c0._eps_value
+        film = _lib.film_forward(gc, pf, self.C, self.f, eps, False)
+        out, logdet, lists = _lib.stack_forward(pc, pw, film, self.C, self.f, self.pattern0, eps, mode, want_lists)
+        needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
+                                                  any(t.requires_grad for t in self._tracked))
+        if needs_grad:
+            anchor = next(t for t in self._tracked if t.requires_grad) if not (p.requires_grad or g.requires_grad) else p
+            res = _NoBackwardYet.apply(anchor, p, g, out, logdet, *([lists] if want_lists else []))
+            out, logdet = res[0], res[1]
+            lists = res[2] if want_lists else None
+        return out, logdet, lists
+
+    def run_lists(self, p, g, mode):
+        _, _, lists = self.run(p, g, mode, True)
+        return list(lists[0].unbind(0)), list(lists[1].unbind(0)), list(lists[2].unbind(0))

@@ -1,0 +1,100 @@
+/* gwtf.h -- C ABI of libgwtf_hip.so: the MI355X (gfx950) implementation of the discrete
+ * point-flow decoder hot path of janisgp/go_with_the_flows.
+ *
+ * The reference has no native code on this path; each entry point below replaces a span of
+ * Python/torch code, cited as reference file:line.  Conventions for every function:
+ *   - returns 0 on success, otherwise a hipError_t value (or GWTF_E_* below); never throws;
+ *   - all pointers are DEVICE pointers to contiguous fp32 (int32 where stated) buffers owned by
+ *     the caller; the library allocates nothing and keeps no mutable global state;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and returns immediately:
+ *     no internal streams, events or synchronisation (same convention as the reference's own
+ *     native ops, lib/metrics/pytorch_structural_losses/src/structural_loss.cpp:35);
+ *   - callable from one host thread per process (one process per GPU).
+ * Buffer layouts are specified in go_with_the_flows_amd/csrc/gwtf_layout.h.
+ */
+#ifndef GWTF_H
+#define GWTF_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GWTF_ABI_VERSION 1
+#define GWTF_E_BADARG 10001   /* shape / mode / width outside what the kernels support */
+#define GWTF_MODE_DIRECT 0    /* sampling direction  base -> data (reference models.py:202) */
+#define GWTF_MODE_INVERSE 1   /* density direction   data -> base (reference models.py:197) */
+
+int gwtf_abi_version(void);
+/* Human-readable text for a non-zero return value (static storage). */
+const char* gwtf_error_string(int code);
+
+/* Sizes (in floats) of the buffers the caller must provide. FP = f rounded up to 16. */
+int    gwtf_padded_width(int f);
+size_t gwtf_raw_coupling_floats(int f, int G);        /* one coupling record of the raw arena   */
+size_t gwtf_packed_w_coupling_floats(int f);          /* one coupling of packed stack weights   */
+size_t gwtf_packed_film_coupling_floats(int f, int G);/* one coupling of packed FiLM weights    */
+size_t gwtf_film_out_floats(int f);                   /* FiLM output per (shape, coupling)      */
+
+/* Weight packer.  Folds eval-mode BatchNorm into the adjacent SharedDot / Linear weights, pads
+ * f to FP and lays the weights out in MFMA-fragment / coalesced order.
+ * Replaces the per-call parameter reads of nn.BatchNorm1d + SharedDot in
+ * lib/networks/flows.py:25-50,60-85 (module construction) as consumed by :95-107.
+ *   raw          [C][gwtf_raw_coupling_floats]   parameters + running statistics, direct order
+ *   packed_w     [C][gwtf_packed_w_coupling_floats]
+ *   packed_film  [C][gwtf_packed_film_coupling_floats]
+ *   training     0: fold running statistics (model.eval()); 1: leave the per-shape FiLM BatchNorm
+ *                un-folded so gwtf_film_forward takes batch statistics (model.train()). */
+int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film,
+                      int C, int f, int G, int training, void* stream);
+
+/* Per-shape FiLM conditioning for all C couplings: the four Linear->BN->Swish->Linear heads of each
+ * coupling applied to the latent g, then a = eps + exp(w(g)), b' = a*c1 + b(g).
+ * Replaces T_{mu,logvar}_0_cond_{w,b}(g) and torch.add(eps, torch.exp(.)) in
+ * lib/networks/flows.py:100-101,105-106 (modules built at :33-45,68-80).
+ *   g        [B][G]
+ *   film_out [B][C][gwtf_film_out_floats]
+ *   eps      the coupling's `eps` buffer (reference flows.py:21, 1e-6)
+ *   training 1: BatchNorm over the B rows uses batch statistics; bn_stats_out (may be NULL)
+ *            receives [C][2 branches][2 heads][2][f] = {batch mean, biased batch var}. */
+int gwtf_film_forward(const float* g, const float* packed_film, float* film_out, float* bn_stats_out,
+                      int B, int G, int C, int f, float eps, int training, void* stream);
+
+/* Fused coupling stack: all C elementary couplings applied to every point, with the log-det
+ * accumulation.  Replaces LocalCondRNVPDecoder.forward (lib/networks/decoders.py:61-79) ->
+ * CondRealNVPFlow3DTriple.forward (flows.py:150-160) -> CondRealNVPFlow3D.forward (flows.py:95-117)
+ * and the `sum(logvars)` of lib/networks/losses.py:14,115.
+ *   p        [B][3][N]   input coordinates (data for INVERSE, base samples for DIRECT)
+ *   out      [B][3][N]   coordinates after the whole stack (ps[0] for INVERSE, ps[-1] for DIRECT)
+ *   logdet   [B][3][N]   sum over the C couplings of logvar (per coordinate; the reference's
+ *                        definition of the log-det, NOT including the base logvar0)
+ *   ps, mus, logvars     optional (all three NULL, or all three non-NULL) [C][B][3][N]: the
+ *                        per-coupling lists the reference returns, slot j = direct-order coupling j
+ *   pattern0 warp pattern index of coupling 0 (0 for a decoder / pattern-0 Triple; see gwtf_layout.h)
+ *   mode     GWTF_MODE_DIRECT / GWTF_MODE_INVERSE */
+int gwtf_stack_forward(const float* p, const float* packed_w, const float* film,
+                       float* out, float* logdet, float* ps, float* mus, float* logvars,
+                       int B, int N, int C, int f, int pattern0, float eps, int mode, void* stream);
+
+/* Mixture negative log-likelihood over K flow components.
+ * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
+ * PointFlowNLL, :11-20).
+ *   z, logdet [K][B][3][N]  outputs of gwtf_stack_forward(INVERSE) per component
+ *   mu0, lv0  [K][B][3]     base Gaussian of each component (reference models.py:169-193)
+ *   logits    [B][K]        un-normalised mixture log-weights
+ *   point_lse [B][N]        optional: per-point logsumexp_k(log w_k + log p_k)
+ *   nll_shape [B]           per-shape  -sum_n point_lse   (zeroed by the call)
+ * The batch mean of nll_shape is the reference's pnll. */
+int gwtf_mixture_nll(const float* z, const float* logdet, const float* mu0, const float* lv0,
+                     const float* logits, float* point_lse, float* nll_shape,
+                     int K, int B, int N, void* stream);
+
+/* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
+ * (16, 32 or 64; anything else restores the size-based default).  Process-wide, not thread-safe. */
+void gwtf_debug_set_points_per_wave(int points);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GWTF_H */

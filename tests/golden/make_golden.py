@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in this directory by running the GENUINE reference on CPU.
+
+Build-container only: needs /root/reference (read-only).  The reference is imported, never
+copied; only inputs/outputs (data) are written.  Weights are not stored: they are regenerated from
+a seed by ``go_with_the_flows_amd.synth.synth_state`` (pure numpy), and this script asserts that the
+reference's ``state_dict`` keys/shapes/dtypes equal our module's, which pins the checkpoint contract.
+
+    python tests/golden/make_golden.py        # rewrites tests/golden/*.npz and contract.json
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+if not os.path.isdir(REF):
+    sys.exit('reference checkout not present: fixtures can only be regenerated in the build container')
+sys.path.insert(0, ROOT)
+sys.path.insert(1, REF)
+
+import numpy as np
+import torch
+
+from lib.networks import flows as rflows            # noqa: E402  (the reference)
+from lib.networks import decoders as rdec           # noqa: E402
+from lib.networks import losses as rloss            # noqa: E402
+from lib.networks.flow_mixture import Flow_Mixture_Model  # noqa: E402
+import go_with_the_flows_amd as ours                # noqa: E402
+from go_with_the_flows_amd.synth import synth_state, synth_inputs  # noqa: E402
+
+torch.set_num_threads(4)
+T = torch.from_numpy
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def load_into(ref_module, our_module, seed):
+    rs, os_ = ref_module.state_dict(), our_module.state_dict()
+    assert list(rs.keys()) == list(os_.keys()), 'state_dict key order/names differ from the reference'
+    for k in rs:
+        assert rs[k].shape == os_[k].shape and rs[k].dtype == os_[k].dtype, k
+    st = synth_state(os_, seed)
+    ref_module.load_state_dict({k: T(v) for k, v in st.items()})
+    return st
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'{name}.npz  {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+BN_PROBES = ('T_mu_0.mu_sd0_bn', 'T_logvar_0.logvar_sd1_bn', 'T_mu_0_cond_w.mu_sd1_film_w0_bn',
+             'T_logvar_0_cond_b.logvar_sd1_film_b0_bn')
+
+
+def g1_single_couplings():
+    """Every warp pattern, both modes, eval and train BatchNorm."""
+    f, G, B, N = 8, 16, 3, 16
+    out = {'dims': np.array([f, G, B, N])}
+    for pi, warp in enumerate(ours.WARP_PATTERNS):
+        ref = rflows.CondRealNVPFlow3D(f, G, warp_inds=list(warp))
+        mine = ours.CondRealNVPFlow3D(f, G, warp_inds=list(warp))
+        seed = 100 + pi
+        p, g = synth_inputs(B, N, G, 200 + pi)
+        out[f'p{pi}'], out[f'g{pi}'] = p, g
+        for training in (False, True):
+            for mode in ('direct', 'inverse'):
+                load_into(ref, mine, seed)
+                ref.train(training)
+                with torch.no_grad():
+                    po, mu, lv = ref(T(p), T(g), mode=mode)
+                tag = f'{pi}_{"train" if training else "eval"}_{mode}'
+                out['pout_' + tag], out['mu_' + tag], out['lv_' + tag] = npy(po), npy(mu), npy(lv)
+                if training:
+                    sd = ref.state_dict()
+                    for probe in BN_PROBES:
+                        out[f'rm_{tag}_{probe}'] = npy(sd[probe + '.running_mean'])
+                        out[f'rv_{tag}_{probe}'] = npy(sd[probe + '.running_var'])
+    save('g1_couplings', **out)
+
+
+def g2_triples():
+    f, G, B, N = 8, 16, 2, 16
+    out = {'dims': np.array([f, G, B, N])}
+    for pattern in (0, 1):
+        ref = rflows.CondRealNVPFlow3DTriple(f, G, pattern=pattern)
+        mine = ours.CondRealNVPFlow3DTriple(f, G, pattern=pattern)
+        load_into(ref, mine, 300 + pattern)
+        ref.eval()
+        p, g = synth_inputs(B, N, G, 310 + pattern)
+        out[f'p{pattern}'], out[f'g{pattern}'] = p, g
+        for mode in ('direct', 'inverse'):
+            with torch.no_grad():
+                ps, mus, lvs = ref(T(p), T(g), mode=mode)
+            out[f'ps_{pattern}_{mode}'] = np.stack([npy(t) for t in ps])
+            out[f'mus_{pattern}_{mode}'] = np.stack([npy(t) for t in mus])
+            out[f'lvs_{pattern}_{mode}'] = np.stack([npy(t) for t in lvs])
+    save('g2_triples', **out)
+
+
+def decoder_case(name, L, f, G, B, N, seed, full_lists, train_too):
+    ref = rdec.LocalCondRNVPDecoder(L, f, G)
+    mine = ours.LocalCondRNVPDecoder(L, f, G)
+    p, g = synth_inputs(B, N, G, seed + 1)
+    out = {'dims': np.array([L, f, G, B, N, seed]), 'p': p, 'g': g,
+           'param_count': np.array(rdec.LocalCondRNVPDecoder.get_param_count(L, f, G))}
+    for training in ((False, True) if train_too else (False,)):
+        for mode in ('direct', 'inverse'):
+            load_into(ref, mine, seed)
+            ref.train(training)
+            with torch.no_grad():
+                ps, mus, lvs = ref(T(p), T(g), mode=mode)
+            tag = f'{"train" if training else "eval"}_{mode}'
+            out['first_' + tag], out['last_' + tag] = npy(ps[0]), npy(ps[-1])
+            out['logdet_' + tag] = npy(sum(lvs))
+            if full_lists:
+                out['ps_' + tag] = np.stack([npy(t) for t in ps])
+                out['mus_' + tag] = np.stack([npy(t) for t in mus])
+                out['lvs_' + tag] = np.stack([npy(t) for t in lvs])
+            # fp64 run of the same reference module: sizes the tolerance
+            if not training:
+                ref64 = rdec.LocalCondRNVPDecoder(L, f, G).double()
+                ref64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
+                ref64.eval()
+                with torch.no_grad():
+                    ps64, _, lvs64 = ref64(T(p).double(), T(g).double(), mode=mode)
+                out['first64_' + tag] = npy(ps64[0])
+                out['last64_' + tag] = npy(ps64[-1])
+                out['logdet64_' + tag] = npy(sum(lvs64))
+    save(name, **out)
+
+
+def g5_losses():
+    """PointFlowNLL (K=1) and FlowMixtureNLL (K=4, non-uniform logits) on genuine decoder outputs."""
+    L, f, G, B, N, K = 2, 8, 16, 3, 32, 4
+    out = {'dims': np.array([L, f, G, B, N, K])}
+    p, g = synth_inputs(B, N, G, 501)
+    rng = np.random.default_rng(502)
+    logits = rng.normal(0, 1.0, (B, K)).astype(np.float32)
+    mu0 = rng.normal(0, 0.2, (K, B, 3)).astype(np.float32)
+    lv0 = rng.normal(-0.5, 0.3, (K, B, 3)).astype(np.float32)
+    out.update(p=p, g=g, logits=logits, mu0=mu0, lv0=lv0)
+    comps, zs, lds = [], [], []
+    for k in range(K):
+        ref = rdec.LocalCondRNVPDecoder(L, f, G)
+        mine = ours.LocalCondRNVPDecoder(L, f, G)
+        load_into(ref, mine, 510 + k)
+        ref.eval()
+        with torch.no_grad():
+            ps, mus, lvs = ref(T(p), T(g), mode='inverse')
+        m0 = T(mu0[k]).unsqueeze(2).expand(B, 3, N)
+        l0 = T(lv0[k]).unsqueeze(2).expand(B, 3, N)
+        # exactly how one_flow_decode assembles the lists (reference models.py:195-205)
+        comps.append({'p_prior_samples': ps + [T(p)], 'p_prior_mus': [m0] + mus, 'p_prior_logvars': [l0] + lvs})
+        zs.append(npy(ps[0]))
+        lds.append(npy(sum(lvs)))
+    out['z'], out['logdet'] = np.stack(zs), np.stack(lds)
+    with torch.no_grad():
+        out['pointflow_nll_k0'] = npy(rloss.PointFlowNLL()(comps[0]))
+        out['mixture_nll'] = npy(rloss.FlowMixtureNLL()(comps, T(logits)))
+        out['mixture_nll_k1'] = npy(rloss.FlowMixtureNLL()(comps[:1], T(logits[:, :1])))
+    save('g5_losses', **out)
+
+
+def g6_keep_drift():
+    """33 couplings with zeroed output layers: every coordinate drifts by sqrt(1+eps)^33."""
+    L, f, G, B, N = 11, 8, 16, 1, 8
+    ref = rdec.LocalCondRNVPDecoder(L, f, G)
+    mine = ours.LocalCondRNVPDecoder(L, f, G)
+    st = load_into(ref, mine, 600)
+    sd = ref.state_dict()
+    for k in sd:
+        if k.endswith('sd2.weight') or k.endswith('sd2.bias'):
+            sd[k].zero_()
+    ref.load_state_dict(sd)
+    ref.eval()
+    p, g = synth_inputs(B, N, G, 601)
+    out = {'dims': np.array([L, f, G, B, N]), 'p': p, 'g': g}
+    for mode in ('direct', 'inverse'):
+        with torch.no_grad():
+            ps, _, lvs = ref(T(p), T(g), mode=mode)
+        out['out_' + mode] = npy(ps[-1] if mode == 'direct' else ps[0])
+        out['logdet_' + mode] = npy(sum(lvs))
+    save('g6_keep_drift', **out)
+
+
+def g7_model_training_forward():
+    """Caller semantics: full Flow_Mixture_Model.forward in training mode + Flow_Mixture_Loss (tiny dims).
+    Captures what crosses the decoder boundary (g_sample, base Gaussians, logits) and the loss terms."""
+    cfg = dict(train_mode='p_rnvp_mc_g_rnvp_vae', util_mode='training', deterministic=False,
+               pc_enc_init_n_channels=3, pc_enc_init_n_features=8, pc_enc_n_features=[16, 32],
+               g_latent_space_size=16, g_prior_n_flows=2, g_prior_n_features=16, g_posterior_n_layers=1,
+               p_latent_space_size=3, p_prior_n_layers=1, p_decoder_n_flows=2, p_decoder_n_features=8,
+               p_decoder_base_type='free', p_decoder_base_var=-3.9551, n_components=2,
+               params_reduce_mode='none', weights_type='learned_weights',
+               pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0)
+    torch.manual_seed(7)
+    model = Flow_Mixture_Model(**cfg)
+    K = cfg['n_components']
+    decoder_states = []
+    for k in range(K):
+        mine = ours.LocalCondRNVPDecoder(2, 8, 16)
+        decoder_states.append(load_into(model.pc_decoder[k], mine, 700 + k))
+    model.eval()  # BatchNorm in eval; `mode` attribute stays 'training' so the inverse path is taken
+    B, N = 3, 32
+    p, _ = synth_inputs(B, N, 16, 710)
+    gcloud, _ = synth_inputs(B, N, 16, 711)
+    captured = {}
+
+    def hook(mod, args, kwargs, output):
+        captured.setdefault('g_sample', npy(args[1]))
+
+    h = model.pc_decoder[0].register_forward_hook(hook, with_kwargs=True)
+    torch.manual_seed(8)
+    with torch.no_grad():
+        out_enc, out_dec, logits = model(T(gcloud), T(p), None, None, False, False)
+        loss, pnll, gnll, gent = rloss.Flow_Mixture_Loss(**cfg)(out_enc, out_dec, logits)
+    h.remove()
+    save('g7_model_forward',
+         dims=np.array([B, N, K]), p=p, g_sample=captured['g_sample'], logits=npy(logits),
+         mu0=np.stack([npy(o['p_prior_mus'][0][:, :, 0]) for o in out_dec]),
+         lv0=np.stack([npy(o['p_prior_logvars'][0][:, :, 0]) for o in out_dec]),
+         z=np.stack([npy(o['p_prior_samples'][0]) for o in out_dec]),
+         logdet=np.stack([npy(sum(o['p_prior_logvars'][1:])) for o in out_dec]),
+         n_lists=np.array([len(out_dec[0]['p_prior_samples']), len(out_dec[0]['p_prior_mus']),
+                           len(out_dec[0]['p_prior_logvars'])]),
+         loss=npy(loss), pnll=npy(pnll), gnll=npy(gnll), gent=npy(gent))
+
+
+def g8_gradients():
+    """Gradients of a scalar NLL-like loss through a small decoder (inverse), for the backward kernels."""
+    L, f, G, B, N = 2, 8, 16, 2, 32
+    ref = rdec.LocalCondRNVPDecoder(L, f, G)
+    mine = ours.LocalCondRNVPDecoder(L, f, G)
+    load_into(ref, mine, 800)
+    ref.eval()
+    p, g = synth_inputs(B, N, G, 801)
+    pt, gt = T(p).requires_grad_(True), T(g).requires_grad_(True)
+    ps, mus, lvs = ref(pt, gt, mode='inverse')
+    loss = 0.5 * (sum(lvs) + ps[0] ** 2).sum() / B
+    loss.backward()
+    out = {'dims': np.array([L, f, G, B, N]), 'p': p, 'g': g, 'loss': npy(loss), 'dp': npy(pt.grad), 'dg': npy(gt.grad)}
+    named = dict(ref.named_parameters())
+    for key in ('flows.0.nvp1.T_mu_0.mu_sd0.weight', 'flows.1.nvp2.T_logvar_0.logvar_sd1.weight',
+                'flows.0.nvp3.T_mu_1.mu_sd2.weight', 'flows.1.nvp1.T_logvar_1.logvar_sd2.bias',
+                'flows.0.nvp2.T_logvar_0_cond_w.logvar_sd1_film_w1.weight',
+                'flows.1.nvp3.T_mu_0_cond_b.mu_sd1_film_b0.weight',
+                'flows.0.nvp1.T_mu_0.mu_sd0_bn.weight', 'flows.0.nvp1.T_mu_0.mu_sd0_bn.bias'):
+        out['grad::' + key] = npy(named[key].grad)
+    save('g8_gradients', **out)
+
+
+def contract():
+    """Reference state_dict keys/shapes for a small decoder, as JSON (checkpoint contract)."""
+    ref = rdec.LocalCondRNVPDecoder(2, 8, 16)
+    spec = [[k, list(v.shape), str(v.dtype).replace('torch.', '')] for k, v in ref.state_dict().items()]
+    with open(os.path.join(HERE, 'contract.json'), 'w') as fh:
+        json.dump({'ctor': [2, 8, 16], 'state_dict': spec}, fh, indent=0)
+    print('contract.json', len(spec), 'entries')
+
+
+if __name__ == '__main__':
+    contract()
+    g1_single_couplings()
+    g2_triples()
+    decoder_case('g3_decoder_4x64x128', 4, 64, 128, 4, 512, 400, full_lists=False, train_too=True)
+    decoder_case('g3s_decoder_lists', 2, 8, 16, 2, 24, 410, full_lists=True, train_too=True)
+    decoder_case('g4_width37', 2, 37, 128, 2, 64, 420, full_lists=False, train_too=False)
+    decoder_case('g4_width33', 2, 33, 512, 2, 64, 430, full_lists=False, train_too=False)
+    decoder_case('g4_width19', 2, 19, 128, 2, 64, 440, full_lists=False, train_too=False)
+    g5_losses()
+    g6_keep_drift()
+    g7_model_training_forward()
+    g8_gradients()

@@ -1,0 +1,225 @@
+"""Parity of the HIP path (through the C ABI) against the golden fixtures and the CPU oracle.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, TOL_COORD, TOL_LOGDET, TOL_NLL_REL
+from helpers import decoder_and_state, coupling_and_state, triple_and_state, state64, maxabs
+import go_with_the_flows_amd as gw
+from go_with_the_flows_amd import _lib
+from go_with_the_flows_amd.synth import synth_inputs
+from oracle import flow_oracle as fo
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(autouse=True)
+def _default_tiling():
+    _lib.lib().gwtf_debug_set_points_per_wave(0)
+    yield
+    _lib.lib().gwtf_debug_set_points_per_wave(0)
+
+
+def test_library_is_loaded_and_has_no_fallback():
+    assert _lib.lib().gwtf_abi_version() == _lib.ABI_VERSION
+    m, _ = decoder_and_state(1, 8, 16, 1)
+    with pytest.raises(_lib.GwtfError):       # CPU tensors / CPU module: refuse, do not fall back
+        m.eval()(torch.zeros(1, 3, 4), torch.zeros(1, 16))
+
+
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+def test_g1_single_coupling_all_patterns(mode):
+    G1 = golden('g1_couplings')
+    f, G, B, N = G1['dims']
+    for pi, warp in enumerate(gw.WARP_PATTERNS):
+        m, _ = coupling_and_state(f, G, warp, 100 + pi)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            po, mu, lv = m(dev(G1[f'p{pi}']), dev(G1[f'g{pi}']), mode=mode)
+        tag = f'{pi}_eval_{mode}'
+        assert maxabs(host(po), G1['pout_' + tag]) < TOL_COORD
+        assert maxabs(host(mu), G1['mu_' + tag]) < TOL_COORD
+        assert maxabs(host(lv), G1['lv_' + tag]) < TOL_LOGDET
+        keep = fo.keep_of(warp)
+        assert np.all(host(mu)[:, keep] == 0) and np.all(host(lv)[:, keep] == 0)
+
+
+@pytest.mark.parametrize('pattern', [0, 1])
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+def test_g2_triple_ordering(mode, pattern):
+    G2 = golden('g2_triples')
+    f, G, B, N = G2['dims']
+    m, _ = triple_and_state(f, G, pattern, 300 + pattern)
+    m = m.to(DEV).eval()
+    with torch.no_grad():
+        ps, mus, lvs = m(dev(G2[f'p{pattern}']), dev(G2[f'g{pattern}']), mode=mode)
+    assert len(ps) == len(mus) == len(lvs) == 3
+    assert maxabs(host(torch.stack(ps)), G2[f'ps_{pattern}_{mode}']) < TOL_COORD
+    assert maxabs(host(torch.stack(mus)), G2[f'mus_{pattern}_{mode}']) < TOL_COORD
+    assert maxabs(host(torch.stack(lvs)), G2[f'lvs_{pattern}_{mode}']) < TOL_LOGDET
+
+
+DECODER_CASES = ['g3_decoder_4x64x128', 'g3s_decoder_lists', 'g4_width37', 'g4_width33', 'g4_width19']
+
+
+@pytest.mark.parametrize('name', DECODER_CASES)
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+@pytest.mark.parametrize('pts_per_wave', [0, 16, 32, 64])
+def test_decoder_golden(name, mode, pts_per_wave):
+    D = golden(name)
+    L, f, G, B, N, seed = D['dims']
+    m, _ = decoder_and_state(L, f, G, seed)
+    m = m.to(DEV).eval()
+    _lib.lib().gwtf_debug_set_points_per_wave(pts_per_wave)
+    tag = f'eval_{mode}'
+    with torch.no_grad():
+        ps, mus, lvs = m(dev(D['p']), dev(D['g']), mode=mode)
+        out, logdet = m.forward_fused(dev(D['p']), dev(D['g']), mode=mode)
+    assert len(ps) == len(mus) == len(lvs) == 3 * L
+    assert maxabs(host(ps[0]), D['first_' + tag]) < TOL_COORD
+    assert maxabs(host(ps[-1]), D['last_' + tag]) < TOL_COORD
+    assert maxabs(host(sum(lvs)), D['logdet_' + tag]) < TOL_LOGDET
+    assert maxabs(host(logdet), D['logdet_' + tag]) < TOL_LOGDET
+    assert np.array_equal(host(out), host(ps[0] if mode == 'inverse' else ps[-1]))   # fused == list variant, bit for bit
+    if 'ps_' + tag in D.files:
+        assert maxabs(host(torch.stack(ps)), D['ps_' + tag]) < TOL_COORD
+        assert maxabs(host(torch.stack(mus)), D['mus_' + tag]) < TOL_COORD
+        assert maxabs(host(torch.stack(lvs)), D['lvs_' + tag]) < TOL_LOGDET
+    # distance to the reference's own fp64 run stays inside the stated tolerance too
+    ref64 = D['first64_' + tag] if mode == 'inverse' else D['last64_' + tag]
+    assert maxabs(host(out), ref64) < TOL_COORD
+    assert maxabs(host(logdet), D['logdet64_' + tag]) < TOL_LOGDET
+
+
+def test_g6_kept_coordinate_drift():
+    D = golden('g6_keep_drift')
+    L, f, G, B, N = D['dims']
+    m, st = decoder_and_state(L, f, G, 600)
+    sd = m.state_dict()
+    for k in sd:
+        if k.endswith('sd2.weight') or k.endswith('sd2.bias'):
+            sd[k].zero_()
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    for mode in ('direct', 'inverse'):
+        with torch.no_grad():
+            out, ld = m.forward_fused(dev(D['p']), dev(D['g']), mode=mode)
+        assert maxabs(host(out), D['out_' + mode]) < 1e-6
+        assert np.all(host(ld) == 0)
+        assert abs(np.median(host(out) / D['p']) - 1.0) > 1e-5   # kept coordinates are NOT passed through
+
+
+RAGGED = [(1, 1), (1, 15), (2, 17), (3, 63), (2, 65), (1, 255), (2, 257), (5, 100), (2, 1000)]
+
+
+@pytest.mark.parametrize('B,N', RAGGED)
+@pytest.mark.parametrize('f', [8, 19, 33, 48, 64])
+def test_ragged_shapes_vs_oracle(B, N, f):
+    """Sizes that do not fill a wavefront / workgroup, every padded-width bucket, against the oracle."""
+    L, G = 2, 24
+    m, st = decoder_and_state(L, f, G, 900 + f)
+    m = m.to(DEV).eval()
+    p, g = synth_inputs(B, N, G, 1000 + B * 7 + N)
+    for mode in ('direct', 'inverse'):
+        ref_out, ref_ld = fo.decoder_fused(p, g, st, L, mode)
+        for ppw in (16, 32, 64):
+            _lib.lib().gwtf_debug_set_points_per_wave(ppw)
+            with torch.no_grad():
+                out, ld = m.forward_fused(dev(p), dev(g), mode=mode)
+            assert maxabs(host(out), ref_out) < TOL_COORD, (mode, ppw)
+            assert maxabs(host(ld), ref_ld) < TOL_LOGDET, (mode, ppw)
+
+
+def test_noncontiguous_and_cache_invalidation():
+    L, f, G, B, N = 1, 16, 8, 2, 40
+    m, st = decoder_and_state(L, f, G, 77)
+    m = m.to(DEV).eval()
+    p, g = synth_inputs(B, N, G, 78)
+    pt = dev(np.ascontiguousarray(p.transpose(0, 2, 1))).transpose(1, 2)    # (B,3,N) view, not contiguous
+    with torch.no_grad():
+        out, ld = m.forward_fused(pt, dev(g), 'inverse')
+    ref_out, ref_ld = fo.decoder_fused(p, g, st, L, 'inverse')
+    assert maxabs(host(out), ref_out) < TOL_COORD
+    # in-place edit (version bump) and load_state_dict both invalidate the packed weights
+    with torch.no_grad():
+        m.flows[0].nvp1.T_mu_1[1].bias.add_(0.25)
+    st2 = {k: v.copy() for k, v in st.items()}
+    st2['flows.0.nvp1.T_mu_1.mu_sd2.bias'] = st2['flows.0.nvp1.T_mu_1.mu_sd2.bias'] + np.float32(0.25)
+    with torch.no_grad():
+        out2, _ = m.forward_fused(dev(p), dev(g), 'inverse')
+    assert maxabs(host(out2), fo.decoder_fused(p, g, st2, L, 'inverse')[0]) < TOL_COORD
+    assert maxabs(host(out2), host(out)) > 1e-2
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    with torch.no_grad():
+        out3, _ = m.forward_fused(dev(p), dev(g), 'inverse')
+    assert np.array_equal(host(out3), host(out))
+
+
+@pytest.mark.parametrize('cfg', [(4, 64, 128, 32, 2048), (11, 37, 128, 8, 2048), (6, 19, 128, 32, 2048)])
+def test_full_size_properties(cfg):
+    """BASELINE.json sizes: too slow for the python oracle on every run, so check size-independent properties:
+    inverse(direct(x)) round trip, log-det antisymmetry along the round trip, per-shape independence
+    (a shape's result does not depend on its batch neighbours) and determinism."""
+    L, f, G, B, N = cfg
+    m, st = decoder_and_state(L, f, G, 1234)
+    m = m.to(DEV).eval()
+    p, g = synth_inputs(B, N, G, 4321)
+    pd, gd = dev(p), dev(g)
+    with torch.no_grad():
+        z, ld_inv = m.forward_fused(pd, gd, 'inverse')
+        x, ld_dir = m.forward_fused(z, gd, 'direct')
+        z2, _ = m.forward_fused(pd, gd, 'inverse')
+        zs, lds = m.forward_fused(pd[1:3].contiguous(), gd[1:3].contiguous(), 'inverse')
+    assert torch.equal(z, z2)
+    assert torch.equal(zs, z[1:3]) and torch.equal(lds, ld_inv[1:3])
+    # the reference's inverse is not the exact inverse of its direct pass (kept coords are rescaled before
+    # mu/logvar are evaluated): the round-trip error is bounded by that drift, not by rounding
+    scale = float(p.std())
+    assert maxabs(host(x), p) < 2e-3 * max(1.0, float(np.abs(host(z)).max()))
+    assert maxabs(host(ld_dir), host(ld_inv)) < 2e-3
+    assert np.isfinite(host(z)).all() and np.isfinite(host(ld_inv)).all()
+    # one shape against the oracle at full N
+    ref_out, ref_ld = fo.decoder_fused(p[:1], g[:1], st, L, 'inverse')
+    assert maxabs(host(z[:1]), ref_out) < TOL_COORD
+    assert maxabs(host(ld_inv[:1]), ref_ld) < TOL_LOGDET
+
+
+def test_g5_mixture_nll():
+    D = golden('g5_losses')
+    L, f, G, B, N, K = D['dims']
+    nll, plse = _lib.mixture_nll(dev(D['z']), dev(D['logdet']), dev(D['mu0']), dev(D['lv0']), dev(D['logits']), True)
+    loss = float(host(nll).mean())
+    assert abs(loss - float(D['mixture_nll'])) / abs(float(D['mixture_nll'])) < TOL_NLL_REL
+    _, per_shape = fo.mixture_nll_fused(D['z'], D['logdet'], D['mu0'], D['lv0'], D['logits'])
+    assert np.max(np.abs(host(nll) - per_shape) / np.abs(per_shape)) < TOL_NLL_REL
+    # K=1 degenerates to PointFlowNLL summed over points
+    nll1 = _lib.mixture_nll(dev(D['z'][:1]), dev(D['logdet'][:1]), dev(D['mu0'][:1]), dev(D['lv0'][:1]),
+                            dev(D['logits'][:, :1]))
+    assert abs(float(host(nll1).mean()) - float(D['mixture_nll_k1'])) / abs(float(D['mixture_nll_k1'])) < TOL_NLL_REL
+    assert np.max(np.abs(host(nll1) - D['pointflow_nll_k0'].sum(axis=(1, 2))) / np.abs(host(nll1))) < TOL_NLL_REL
+
+
+def test_g7_caller_semantics_end_to_end():
+    """Decoder (inverse) + mixture NLL exactly as the training loop chains them (reference training.py:40-42)."""
+    D = golden('g7_model_forward')
+    B, N, K = D['dims']
+    zs, lds = [], []
+    for k in range(K):
+        m, _ = decoder_and_state(2, 8, 16, 700 + k)
+        m = m.to(DEV).eval()
+        with torch.no_grad():
+            z, ld = m.forward_fused(dev(D['p']), dev(D['g_sample']), 'inverse')
+        zs.append(z), lds.append(ld)
+    z, ld = torch.stack(zs), torch.stack(lds)
+    assert maxabs(host(z), D['z']) < TOL_COORD and maxabs(host(ld), D['logdet']) < TOL_LOGDET
+    nll = _lib.mixture_nll(z, ld, dev(D['mu0']), dev(D['lv0']), dev(D['logits']))
+    assert abs(float(host(nll).mean()) - float(D['pnll'])) / abs(float(D['pnll'])) < TOL_NLL_REL
