@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: point-flow forward + log-det throughput on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload airplane|m1|ae|k16]
+
+One "step" = one pass of the hot path over one batch of synthetic clouds that are already resident in
+HBM: for every mixture component, the FiLM kernel + the fused coupling-stack kernel (inverse direction,
+eval-mode BatchNorm), producing the base-space coordinates and the per-coordinate sum of logvars.
+Weight packing is module preparation (cached while parameters are unchanged) and is outside the step,
+like BatchNorm folding for inference.  Metric (BASELINE.json): Mpoints/s, one "point" = one 3-D point
+pushed through one component's full stack.  N>1: one process per GPU (torch.distributed.run),
+batch of shapes sharded, per-GPU batch fixed (weak scaling), no data-path collective.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import go_with_the_flows_amd as gw                      # noqa: E402
+from go_with_the_flows_amd import _lib                  # noqa: E402
+from go_with_the_flows_amd.synth import load_synth_, synth_inputs  # noqa: E402
+
+# Resolved dimensions of BASELINE.json's configs: K components, L triples, f, G, per-GPU B, N
+WORKLOADS = {
+    'airplane': dict(K=4, L=11, f=37, G=128, B=64, N=2048, mode='inverse',
+                     name='configs[1] airplane generative (config_generative_modeling_airplane.yaml): '
+                          'K=4 flows x 33 couplings, f=37, G=128, B=64 x N=2048, inverse + sum(logvars), eval BN'),
+    'm1': dict(K=1, L=4, f=64, G=128, B=32, N=2048, mode='inverse',
+               name='north-star shape: single flow, 12 couplings, f=64, G=128, B=32 x N=2048, inverse + sum(logvars)'),
+    'ae': dict(K=4, L=11, f=33, G=512, B=16, N=2048, mode='inverse',
+               name='configs[2] autoencoding per-GPU shard: K=4 x 33 couplings, f=33, G=512, B=16 x N=2048'),
+    'k16': dict(K=16, L=6, f=19, G=128, B=32, N=2048, mode='direct',
+                name='configs[3] K=16 mixture sampling, batched: each point visits one of 16 flows, 18 couplings, f=19'),
+}
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (= fp32 vector peak)
+
+
+def flops_per_point(L, f):
+    """Algorithmic flop per point per component: C*(4f^2 + 12f), unpadded f."""
+    return 3 * L * (4 * f * f + 12 * f)
+
+
+def host_cores():
+    """CPU cores this process may actually use: affinity mask capped by the cgroup quota (a GPU box gives
+    each job a share of a much larger host; oversubscribing the torch thread pool is catastrophically slow)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfg, budget_s=15.0):
+    """PyTorch-CPU port of the reference forward (oracle/torch_port.py) on a bounded sample of the workload."""
+    from oracle import torch_port as tp
+    torch.set_num_threads(host_cores())
+    dec = gw.LocalCondRNVPDecoder(cfg['L'], cfg['f'], cfg['G'])
+    st = load_synth_(dec, 2)
+    tst = {k: torch.from_numpy(v) for k, v in st.items()}
+    bs = min(cfg['B'], 8)
+    p, g = synth_inputs(bs, cfg['N'], cfg['G'], 0)
+    pt, gt = torch.from_numpy(p), torch.from_numpy(g)
+    tp.decoder_fused(pt, gt, tst, cfg['L'], cfg['mode'])      # warm-up
+    times, t_start = [], time.perf_counter()
+    while len(times) < 3 or (time.perf_counter() - t_start < budget_s and len(times) < 50):
+        t0 = time.perf_counter()
+        tp.decoder_fused(pt, gt, tst, cfg['L'], cfg['mode'])
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {'value': round(bs * cfg['N'] / med / 1e6, 4), 'unit': 'Mpoints/s', 'cores': torch.get_num_threads(),
+            'kind': 'port',
+            'sample': f'oracle/torch_port.py (PyTorch-CPU restatement of the reference forward, pinned to its golden '
+                      f'vectors), one component, {bs} shapes x {cfg["N"]} points, median of {len(times)} reps'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--workload', default='airplane', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--points-per-wave', type=int, default=0, help='tuning hook: 16/32/64, 0 = library default')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`')
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)   # RCCL; used only for the barrier + max-over-ranks
+
+    cfg = WORKLOADS[args.workload]
+    K, L, f, G, B, N, mode = (cfg[k] for k in ('K', 'L', 'f', 'G', 'B', 'N', 'mode'))
+    _lib.lib().gwtf_debug_set_points_per_wave(args.points_per_wave)
+
+    decoders = []
+    for k in range(K):
+        d = gw.LocalCondRNVPDecoder(L, f, G)
+        load_synth_(d, 2 + k)
+        decoders.append(d.to(dev).eval())
+    p, g = synth_inputs(B, N, G, 1000 * rank)          # every rank owns its own shard of shapes
+    pd, gd = torch.from_numpy(p).to(dev), torch.from_numpy(g).to(dev)
+    engines = [d.engine() for d in decoders]
+    eps = decoders[0].flows[0].nvp1._eps_value
+    sideways = mode == 'direct' and K > 1                # sampling: each point visits ONE component
+    if sideways:
+        chunks = [c.contiguous() for c in pd.chunk(K, dim=2)]
+
+    def step(timers=None):
+        outs = []
+        for k, eng in enumerate(engines):
+            pw, pf = eng.packed(False)
+            film = _lib.film_forward(gd, pf, eng.C, f, eps, False)
+            if timers is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            outs.append(_lib.stack_forward(chunks[k] if sideways else pd, pw, film, eng.C, f, 0, eps, mode, False))
+            if timers is not None:
+                e1.record()
+                timers.append((e0, e1))
+        return outs
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        timers = []
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(timers)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    comp_passes = 1 if sideways else K
+    pts_per_step_per_gpu = B * N * comp_passes
+    value = world * pts_per_step_per_gpu * args.steps / elapsed / 1e6
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in timers]))           # one stack launch, HIP events
+    pts_per_launch = B * (N // K if sideways else N)
+    achieved = flops_per_point(L, f) * pts_per_launch / (kern_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get(args.workload)
+        line = {
+            'metric': 'point-flow fwd+logdet Mpoints/sec (B x 2048 pts)', 'value': round(value, 3), 'unit': 'Mpoints/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': cfg['name'], 'per_gpu_batch': B, 'points_per_shape': N, 'components': K,
+                       'couplings_per_component': 3 * L, 'f': f, 'G': G, 'direction': mode,
+                       'point_definition': 'one 3-D point through one component stack (coords + sum logvars)',
+                       'sharding': f'batch of shapes over {world} rank(s), no data-path collective'},
+            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                         'kernel': 'stack_kernel (fused coupling stack)', 'kernel_ms': round(kern_ms, 4),
+                         'flop_per_point': flops_per_point(L, f), 'points_per_launch': pts_per_launch},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

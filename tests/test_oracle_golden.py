@@ -152,3 +152,19 @@ def test_g7_caller_semantics():
     pnll, _ = fo.mixture_nll_fused(np.stack(zs), np.stack(lds), D['mu0'], D['lv0'], D['logits'])
     assert abs(pnll - D['pnll']) / abs(D['pnll']) < 1e-6
     assert abs((D['pnll'] + D['gnll'] - D['gent']) - D['loss']) < 1e-3
+
+
+@pytest.mark.parametrize('name', ['g3_decoder_4x64x128', 'g4_width37', 'g4_width19'])
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+def test_torch_port_matches_reference(name, mode):
+    """The PyTorch-CPU port timed as bench.py's cpu_baseline computes the reference's numbers."""
+    import torch
+    from oracle import torch_port as tp
+    D = golden(name)
+    L, f, G, B, N, seed = D['dims']
+    _, st = decoder_and_state(L, f, G, seed)
+    tst = {k: torch.from_numpy(v) for k, v in st.items()}
+    out, ld = tp.decoder_fused(torch.from_numpy(D['p']), torch.from_numpy(D['g']), tst, L, mode)
+    tag = f'eval_{mode}'
+    assert maxabs(out.numpy(), D['first_' + tag] if mode == 'inverse' else D['last_' + tag]) < 5e-6
+    assert maxabs(ld.numpy(), D['logdet_' + tag]) < 5e-6
