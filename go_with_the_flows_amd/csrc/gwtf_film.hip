@@ -4,9 +4,9 @@
 // (lib/networks/flows.py:33-45 / 68-80, used at :100-101,105-106):
 //     w = Linear_f->f( Swish( BN( Linear_G->f(g) ) ) ),   b = same structure, other weights
 //     h <- (eps + exp(w)) * BN1(sd1(.)) + b
-// This kernel produces, per (shape, coupling, branch, feature j), the float4 the fused stack kernel's
-// epilogue consumes: { a, a*c1 + b, W2[0][j], W2[1][j] } with a = eps + exp(w) and c1 the (eval-mode)
-// sd1_bn shift, plus the sd2 biases.  It is B rows of work per head -- latency, not throughput --
+// This kernel produces, per (shape, coupling, branch, feature j), what the fused stack kernel consumes:
+// c = c1 + b/a (start value of the sd1 accumulators), W2[0][j]*a, W2[1][j]*a, with a = eps + exp(w) > 0 and
+// c1 the (eval-mode) sd1_bn shift -- relu(a*(y+c1)+b) = a*relu(y+c) -- plus the sd2 biases.  It is B rows of work per head -- latency, not throughput --
 // so it is a plain VALU kernel: one workgroup per (coupling, branch), lane = output feature,
 // each wave carries R shapes so every weight load is reused R times; g is staged through LDS.
 #include <hip/hip_runtime.h>
@@ -69,13 +69,18 @@ __global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ g, 
       for (int r = 0; r < kR; ++r) {
         const int b = b0 + wave * kR + r;
         if (b < B) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          float cv = 0.f, u0 = 0.f, u1 = 0.f;
           if (lane < f) {
             const float a = eps + expf(acc[0][r]);
-            v = make_float4(a, fmaf(a, c1, acc[1][r]), w20, w21);
+            cv = c1 + acc[1][r] / a;
+            u0 = w20 * a;
+            u1 = w21 * a;
           }
-          *reinterpret_cast<float4*>(out + ((size_t)b * C + c) * FS + (size_t)br * 4 * FP + 4 * lane) = v;
-          if (lane < 2) out[((size_t)b * C + c) * FS + 8 * FP + 2 * br + lane] = w[P.b2() + lane];
+          float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + lane;
+          ob[0] = cv;
+          ob[FP] = u0;
+          ob[2 * FP] = u1;
+          if (lane < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + lane] = w[P.b2() + lane];
         }
       }
     }
@@ -158,6 +163,115 @@ __global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ g, 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Eval-mode fast path.  No cross-shape dependency (BatchNorm is folded), so the grid also tiles B:
+// one workgroup per (coupling, branch, tile of kBTe shapes).  Weights and the g tile are staged
+// through LDS in G-chunks with coalesced float4 loads (the first version read them straight from
+// L2 inside the dot-product loop and was latency-bound: 89 us for 66 workgroups); lane = output
+// feature, each wave carries kRe shapes so a weight read from LDS feeds 2*kRe FMAs.
+constexpr int kBTe = 16;            // shapes per workgroup
+constexpr int kRe = kBTe / kWaves;  // shapes per wave
+constexpr int kGC = 64;             // rows of L0T per LDS chunk
+
+__global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict__ g, const float* __restrict__ pf,
+                                                        float* __restrict__ out, int B, int G, int C, int f, int FP,
+                                                        float eps) {
+  extern __shared__ __align__(16) float smem[];
+  const int c = blockIdx.x, br = blockIdx.y, b0 = blockIdx.z * kBTe;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const GwtfPackF P(FP, G);
+  const float* w = pf + ((size_t)c * 2 + br) * P.branch_size();
+  const size_t FS = gwtf_film_out_size(FP);
+  const bool act = lane < FP;
+  float* wl = smem;                                // [2][kGC][FP] weight chunk (also reused for L1T: [2][FP][FP])
+  float* gt = wl + 2 * (size_t)(kGC > FP ? kGC : FP) * FP;  // [kBTe][kGC] latent chunk
+  float* hb = gt + (size_t)kBTe * kGC;             // [kBTe][2][FP] hidden activations
+
+  float acc[2][kRe];
+#pragma unroll
+  for (int r = 0; r < kRe; ++r) acc[0][r] = acc[1][r] = 0.f;
+  for (int i0 = 0; i0 < G; i0 += kGC) {
+    const int rows = min(kGC, G - i0);
+    __syncthreads();
+    // stage L0T rows [i0, i0+rows) of both heads: contiguous rows*FP floats each
+    for (int which = 0; which < 2; ++which) {
+      const float4* src = reinterpret_cast<const float4*>(w + P.l0t(which) + (size_t)i0 * FP);
+      float4* dst = reinterpret_cast<float4*>(wl + (size_t)which * kGC * FP);
+      for (int t = threadIdx.x; t < rows * FP / 4; t += blockDim.x) dst[t] = src[t];
+    }
+    for (int t = threadIdx.x; t < kBTe * kGC; t += blockDim.x) {
+      const int r = t / kGC, i = t - r * kGC;
+      gt[t] = (b0 + r < B && i < rows) ? g[(size_t)(b0 + r) * G + i0 + i] : 0.f;
+    }
+    __syncthreads();
+    if (act) {
+      for (int i = 0; i < rows; ++i) {
+        const float w0 = wl[(size_t)i * FP + lane], w1 = wl[(size_t)(kGC + i) * FP + lane];
+#pragma unroll
+        for (int r = 0; r < kRe; ++r) {
+          const float gv = gt[(wave * kRe + r) * kGC + i];
+          acc[0][r] = fmaf(gv, w0, acc[0][r]);
+          acc[1][r] = fmaf(gv, w1, acc[1][r]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // BatchNorm (folded) + Swish -> hb ; stage L1T of both heads into wl
+  if (act) {
+#pragma unroll
+    for (int which = 0; which < 2; ++which) {
+      const float s = w[P.s(which) + lane], t = w[P.t(which) + lane];
+#pragma unroll
+      for (int r = 0; r < kRe; ++r) {
+        const float h = fmaf(acc[which][r], s, t);
+        hb[((size_t)(wave * kRe + r) * 2 + which) * FP + lane] = h / (1.0f + expf(-h));
+      }
+    }
+  }
+  for (int which = 0; which < 2; ++which) {
+    const float4* src = reinterpret_cast<const float4*>(w + P.l1t(which));
+    float4* dst = reinterpret_cast<float4*>(wl + (size_t)which * FP * FP);
+    for (int t = threadIdx.x; t < FP * FP / 4; t += blockDim.x) dst[t] = src[t];
+  }
+  __syncthreads();
+  if (!act) return;
+  float o[2][kRe];
+#pragma unroll
+  for (int r = 0; r < kRe; ++r) {
+    o[0][r] = w[P.l1b(0) + lane];
+    o[1][r] = w[P.l1b(1) + lane];
+  }
+  for (int i = 0; i < FP; ++i) {
+    const float w0 = wl[(size_t)i * FP + lane], w1 = wl[(size_t)(FP + i) * FP + lane];
+#pragma unroll
+    for (int r = 0; r < kRe; ++r) {
+      o[0][r] = fmaf(hb[((size_t)(wave * kRe + r) * 2 + 0) * FP + i], w0, o[0][r]);
+      o[1][r] = fmaf(hb[((size_t)(wave * kRe + r) * 2 + 1) * FP + i], w1, o[1][r]);
+    }
+  }
+  const float c1 = w[P.c1() + lane], w20 = w[P.w2() + lane], w21 = w[P.w2() + FP + lane];
+#pragma unroll
+  for (int r = 0; r < kRe; ++r) {
+    const int b = b0 + wave * kRe + r;
+    if (b < B) {
+      float cv = 0.f, u0 = 0.f, u1 = 0.f;
+      if (lane < f) {
+        const float a = eps + expf(o[0][r]);
+        cv = c1 + o[1][r] / a;
+        u0 = w20 * a;
+        u1 = w21 * a;
+      }
+      float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + lane;
+      ob[0] = cv;
+      ob[FP] = u0;
+      ob[2 * FP] = u1;
+      if (lane < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + lane] = w[P.b2() + lane];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int gwtf_film_forward(const float* g, const float* packed_film, float* film_out, float* bn_stats_out, int B,
@@ -176,10 +290,10 @@ extern "C" int gwtf_film_forward(const float* g, const float* packed_film, float
     hipLaunchKernelGGL(film_kernel<true>, dim3(C, 2), dim3(256), smem, st, g, packed_film, film_out, bn_stats_out, B, G, C,
                        f, FP, eps);
   } else {
-    e = hipFuncSetAttribute((const void*)film_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(film_kernel<false>, dim3(C, 2), dim3(256), smem, st, g, packed_film, film_out, bn_stats_out, B, G, C,
-                       f, FP, eps);
+    const int rowsmax = kGC > FP ? kGC : FP;
+    const size_t smem_e = (2 * (size_t)rowsmax * FP + (size_t)kBTe * kGC + (size_t)kBTe * 2 * FP) * sizeof(float);
+    hipLaunchKernelGGL(film_eval_kernel, dim3(C, 2, (B + kBTe - 1) / kBTe), dim3(256), smem_e, st, g, packed_film,
+                       film_out, B, G, C, f, FP, eps);
   }
   return (int)hipGetLastError();
 }

@@ -80,9 +80,11 @@ struct GwtfPackF {
 };
 
 // FILM OUTPUT (written by gwtf_film_forward, read by the fused kernel through LDS), per (shape b, coupling c):
-//   epi[branch][FP] float4 : {a, a*C1 + b, W2[0][j], W2[1][j]} with a = eps + exp(cond_w(g)), b = cond_b(g)
-//   bias float4            : {b2_logvar[0], b2_logvar[1], b2_mu[0], b2_mu[1]}
-GWTF_HD size_t gwtf_film_out_size(int FP) { return 8 * (size_t)FP + 4; }
+//   for branch in {logvar, mu}:  c[FP] | w20a[FP] | w21a[FP]   with a = eps + exp(cond_w(g)) > 0, b = cond_b(g):
+//       c = C1 + b/a   (start value of the sd1 accumulators:  relu(a*(y + C1) + b) = a * relu(y + c))
+//       w2ka = W2[k][j] * a
+//   bias float4 : {b2_logvar[0], b2_logvar[1], b2_mu[0], b2_mu[1]}
+GWTF_HD size_t gwtf_film_out_size(int FP) { return 6 * (size_t)FP + 4; }
 
 // warp pattern of coupling c in direct order (reference flows.py:129-148, decoders.py:49-52):
 // index (pattern0 + c) % 6 -> 0:[0] 1:[1] 2:[2] 3:[0,1] 4:[0,2] 5:[1,2]

@@ -11,7 +11,8 @@
 //     A[i][k] = W1'[16m+i][4kk+k]   (sd1 weight, sd1_bn scale folded; fragment-ordered image in LDS)
 //     B[k][j] = h0[4kk+k][point j]  (sd0 + sd0_bn + ReLU, computed in the lane that owns (k,j) -- 3 VALU ops)
 //     D[16m + 4q + r][point j]      (q = lane>>4, r = accumulator register)
-//   so FiLM + ReLU + the f->w contraction (sd2) happen in-lane on the accumulators, followed by a
+//   so ReLU + the f->w contraction (sd2) happen in-lane on the accumulators (FiLM is folded into the
+//   accumulator start value and into the sd2 weights by the FiLM kernel), followed by a
 //   transpose-reduce over the four lane quarters that leaves quarter q with the totals of point block q.
 //   Each lane then owns ONE point for the transcendental tail (softsign, exp, sqrt, affine) and the
 //   log-det accumulation; new coordinates are re-broadcast to the quarters with ds_bpermute.
@@ -35,7 +36,7 @@ struct Cfg {
   static constexpr int MBS = MB == 3 ? 4 : MB;
   static constexpr int AIMG = KK * 64 * MBS;           // floats, one branch
   static constexpr int PW = 2 * AIMG + 8 * FP;         // packed weights per coupling
-  static constexpr int FS = 8 * FP + 4;                // FiLM output per (shape, coupling)
+  static constexpr int FS = 6 * FP + 4;                // FiLM output per (shape, coupling)
   static constexpr int LAYER = PW + FS;                // one LDS buffer, multiple of 4 floats
   static constexpr int LAYER_PAD = (LAYER + 255) / 256 * 256;  // whole 1-KiB DMA pieces
 };
@@ -83,14 +84,105 @@ __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
   }
 }
 
+// One elementary coupling on the wave's tile.  KEEP2 = two kept coordinates / one warped (patterns 0-2),
+// otherwise one kept / two warped (patterns 3-5).  Every VALU instruction here costs the SIMD 4 cycles that
+// the matrix pipe cannot use (measured: v_mfma_f32 and VALU of two waves on one SIMD do not overlap,
+// tools/diag/coissue.hip), so the body is specialised to issue as few as possible:
+//   - the accumulators start at c = b'/a (FiLM shift over FiLM scale, a > 0) instead of zero, so
+//     relu(a*y + b') * W2  becomes  relu(acc) * (W2*a): one v_max + one v_fma per warped coordinate;
+//   - the second sd0 input / second sd2 output only exist in the variant that needs them.
+template <int MB, int NB, int MODE, bool KEEP2>
+__device__ __forceinline__ void coupling_body(const float* __restrict__ L, int kk_steps, int lane, int q, int k0, int k1,
+                                              int w0, int w1, float eps, float s_keep, const float (&x)[NB][3],
+                                              float (&xo)[3], float (&mu_d)[3], float (&lv_d)[3]) {
+  using K = Cfg<MB>;
+  constexpr int FP = K::FP, MBS = K::MBS;
+  float xa[NB], xb[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
+    xb[nb] = KEEP2 ? sel3(x[nb][0], x[nb][1], x[nb][2], k1) : 0.f;
+  }
+  float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // [branch][warped slot] for this lane's own point
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    const float* fe = L + K::PW + br * 3 * FP + 4 * q;   // c | w20a | w21a, this lane's 4 features per block
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(fe + 16 * m);
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) acc[m][nb] = c4;
+    }
+    const float* aimg = L + br * K::AIMG + lane * MBS;
+    const f32x4* sd0 = reinterpret_cast<const f32x4*>(L + 2 * K::AIMG + br * 4 * FP) + q;
+    // k-loop over input features, 4 per MFMA; only ceil(f/4) steps carry non-zero weights
+#pragma unroll 2
+    for (int kk = 0; kk < kk_steps; ++kk) {
+      const f32x4 s0 = sd0[4 * kk];
+      float a[MB];
+      load_afrag<MB>(aimg + kk * 64 * MBS, a);
+      float h[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+        h[nb] = fmaxf(KEEP2 ? fmaf(s0[0], xa[nb], fmaf(s0[1], xb[nb], s0[2])) : fmaf(s0[0], xa[nb], s0[2]), 0.f);
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], h[nb], acc[m][nb], 0, 0, 0);
+    }
+    // ReLU + sd2 on the accumulators (FiLM already folded in)
+    float o0[NB], o1[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o0[nb] = o1[nb] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(fe + FP + 16 * m);
+      f32x4 u1 = {0.f, 0.f, 0.f, 0.f};
+      if (!KEEP2) u1 = *reinterpret_cast<const f32x4*>(fe + 2 * FP + 16 * m);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float v = fmaxf(acc[m][nb][r], 0.f);
+          o0[nb] = fmaf(u0[r], v, o0[nb]);
+          if (!KEEP2) o1[nb] = fmaf(u1[r], v, o1[nb]);
+        }
+    }
+    res[br][0] = quarter_reduce<NB>(o0, q);
+    if (!KEEP2) res[br][1] = quarter_reduce<NB>(o1, q);
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
+
+  // transcendental tail on this lane's own point
+  float lv_w[2] = {0.f, 0.f}, mu_w[2] = {0.f, 0.f}, sc_w[2] = {s_keep, s_keep};
+#pragma unroll
+  for (int s = 0; s < (KEEP2 ? 1 : 2); ++s) {
+    const float t = res[0][s] + bias[s];
+    lv_w[s] = t / (1.0f + fabsf(t));                 // softsign (flows.py:99)
+    mu_w[s] = res[1][s] + bias[2 + s];
+    sc_w[s] = sqrtf(eps + expf(lv_w[s]));            // flows.py:113,115
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const bool is0 = d == w0, is1 = !KEEP2 && d == w1;
+    lv_d[d] = is0 ? lv_w[0] : (is1 ? lv_w[1] : 0.f);
+    mu_d[d] = is0 ? mu_w[0] : (is1 ? mu_w[1] : 0.f);
+    const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : s_keep);
+    if (MODE == GWTF_MODE_DIRECT)
+      xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
+    else
+      xo[d] = __fdiv_rn(__fsub_rn(xo[d], mu_d[d]), sc);
+  }
+}
+
 template <int MB, int NB, int MODE, bool LISTS>
 __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p, const float* __restrict__ pw,
                                                     const float* __restrict__ film, float* __restrict__ out,
                                                     float* __restrict__ logdet, float* __restrict__ ps,
                                                     float* __restrict__ mus, float* __restrict__ lvs, int B, int N, int C,
-                                                    int pattern0, float eps, int tiles_per_shape) {
+                                                    int pattern0, float eps, int tiles_per_shape, int kk_steps) {
   using K = Cfg<MB>;
-  constexpr int FP = K::FP, KK = K::KK, MBS = K::MBS;
   __shared__ __align__(16) float lds[2][K::LAYER_PAD];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -137,83 +229,16 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     __syncthreads();
     if (step + 1 < C) stage(buf ^ 1, MODE == GWTF_MODE_INVERSE ? c - 1 : c + 1);
 
-    const float* L = lds[buf];
+    const int pat = (pattern0 + c) % 6;
     int k0, k1, w0, w1;
-    gwtf_pattern_dims((pattern0 + c) % 6, &k0, &k1, &w0, &w1);
-    float xa[NB], xb[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-      xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
-      xb[nb] = k1 < 0 ? 0.f : sel3(x[nb][0], x[nb][1], x[nb][2], k1);
-    }
-
-    float res[2][2];  // [branch][warped slot] for this lane's own point
-#pragma unroll
-    for (int br = 0; br < 2; ++br) {
-      f32x4 acc[MB][NB];
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[m][nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* aimg = L + br * K::AIMG + lane * MBS;
-      const f32x4* sd0 = reinterpret_cast<const f32x4*>(L + 2 * K::AIMG + br * 4 * FP) + q;
-#pragma unroll 4
-      for (int kk = 0; kk < KK; ++kk) {
-        const f32x4 s0 = sd0[4 * kk];
-        float a[MB];
-        load_afrag<MB>(aimg + kk * 64 * MBS, a);
-        float h[NB];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) h[nb] = fmaxf(fmaf(s0[0], xa[nb], fmaf(s0[1], xb[nb], s0[2])), 0.f);
-#pragma unroll
-        for (int m = 0; m < MB; ++m)
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], h[nb], acc[m][nb], 0, 0, 0);
-      }
-      // FiLM + ReLU + sd2 on the accumulators
-      const f32x4* epi = reinterpret_cast<const f32x4*>(L + K::PW + br * 4 * FP) + 4 * q;
-      float o0[NB], o1[NB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) o0[nb] = o1[nb] = 0.f;
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const f32x4 e = epi[16 * m + r];
-#pragma unroll
-          for (int nb = 0; nb < NB; ++nb) {
-            const float v = fmaxf(fmaf(e[0], acc[m][nb][r], e[1]), 0.f);
-            o0[nb] = fmaf(e[2], v, o0[nb]);
-            o1[nb] = fmaf(e[3], v, o1[nb]);
-          }
-        }
-      res[br][0] = quarter_reduce<NB>(o0, q);
-      res[br][1] = quarter_reduce<NB>(o1, q);
-    }
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 8 * FP);
-
-    // transcendental tail on this lane's own point
-    float lv_w[2], mu_w[2], sc_w[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const float t = res[0][s] + bias[s];
-      lv_w[s] = t / (1.0f + fabsf(t));                 // softsign (flows.py:99)
-      mu_w[s] = res[1][s] + bias[2 + s];
-      sc_w[s] = sqrtf(eps + expf(lv_w[s]));            // flows.py:113,115
-    }
+    gwtf_pattern_dims(pat, &k0, &k1, &w0, &w1);
     float mu_d[3], lv_d[3];
+    if (pat < 3)
+      coupling_body<MB, NB, MODE, true>(lds[buf], kk_steps, lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
+    else
+      coupling_body<MB, NB, MODE, false>(lds[buf], kk_steps, lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const bool is0 = d == w0, is1 = d == w1;
-      lv_d[d] = is0 ? lv_w[0] : (is1 ? lv_w[1] : 0.f);
-      mu_d[d] = is0 ? mu_w[0] : (is1 ? mu_w[1] : 0.f);
-      const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : s_keep);
-      if (MODE == GWTF_MODE_DIRECT)
-        xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
-      else
-        xo[d] = __fdiv_rn(__fsub_rn(xo[d], mu_d[d]), sc);
-      ld[d] += lv_d[d];
-    }
+    for (int d = 0; d < 3; ++d) ld[d] += lv_d[d];
     if (LISTS && own_valid) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
@@ -239,16 +264,18 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   }
 }
 
+int g_force_nb = 0;  // test/tuning hooks, see gwtf_debug_set_*
+
 template <int MB, int NB>
 int launch(const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps, float* mus,
-           float* lvs, int B, int N, int C, int pattern0, float eps, int mode, hipStream_t st) {
+           float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps, hipStream_t st) {
   const int pts_wg = 4 * 16 * NB;
   const int tiles = (N + pts_wg - 1) / pts_wg;
   const dim3 grid((unsigned)(B * tiles)), block(256);
   const bool lists = ps != nullptr;
 #define GWTF_LAUNCH(MODE_, LISTS_)                                                                                      \
   hipLaunchKernelGGL((stack_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, \
-                     B, N, C, pattern0, eps, tiles)
+                     B, N, C, pattern0, eps, tiles, kk_steps)
   if (mode == GWTF_MODE_DIRECT) {
     if (lists) GWTF_LAUNCH(GWTF_MODE_DIRECT, true); else GWTF_LAUNCH(GWTF_MODE_DIRECT, false);
   } else {
@@ -260,15 +287,16 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
 
 template <int MB>
 int launch_nb(int nb, const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps,
-              float* mus, float* lvs, int B, int N, int C, int pattern0, float eps, int mode, hipStream_t st) {
+              float* mus, float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps,
+              hipStream_t st) {
   switch (nb) {
-    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, st);
-    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, st);
-    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, st);
+    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, st);
+    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, st);
+    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, st);
   }
 }
 
-int g_force_nb = 0;  // test/tuning hook, see gwtf_debug_set_points_per_wave
+
 
 }  // namespace
 
@@ -284,17 +312,18 @@ extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const f
   const bool any = ps || mus || logvars, all = ps && mus && logvars;
   if (any && !all) return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  // points per wave: enough workgroups to give every SIMD two waves when the problem allows it
+  // points per wave: the largest tile that still gives each of the 1024 SIMDs two waves
   int nb = g_force_nb;
   if (nb != 1 && nb != 2 && nb != 4) {
     const long pts = (long)B * N;
-    nb = pts >= 4L * 2048 * 64 ? 4 : (pts >= 2L * 2048 * 32 ? 2 : 1);
+    nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
   }
+  const int kk_steps = (f + 3) / 4;
   switch (gwtf_padded_width(f) / 16) {
-    case 1: return launch_nb<1>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
-    case 2: return launch_nb<2>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
-    case 3: return launch_nb<3>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
-    case 4: return launch_nb<4>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, st);
+    case 1: return launch_nb<1>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
+    case 2: return launch_nb<2>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
+    case 3: return launch_nb<3>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
+    case 4: return launch_nb<4>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
     default: return GWTF_E_BADARG;
   }
 }
