@@ -42,20 +42,30 @@ struct GwtfRaw {  // offsets inside one branch record
   GWTF_HD size_t coupling_size() const { return 2 * branch_size(); }
 };
 
-// PACKED STACK WEIGHTS (read by the fused kernel through LDS), per coupling:
-//   Aimg[branch][kk][lane][MBS]  : sd1 weight with sd1_bn's 1/sqrt(var+eps) folded into its rows, in
-//                                  MFMA-A fragment order: value W[16*m + (lane&15)][4*kk + (lane>>4)]
-//   sd0[branch][FP] float4       : {w0[j][0]*s, w0[j][1]*s, beta - mean*s, 0},  s = gamma/sqrt(var+eps)
+// PACKED STACK WEIGHTS (read by the fused kernel through LDS), per coupling.
+// The f x f contraction (sd1) runs on v_mfma_f32_16x16x32_f16 with every fp32 operand split into two
+// f16 parts, x = hi + lo (both round-to-nearest, |lo| <= 2^-12 |x|, representation error 2^-23 |x|, f16
+// subnormals are honoured by the MFMA -- tools/diag/f16probe.hip), and three products
+// W_hi*h_hi + W_hi*h_lo + W_lo*h_hi accumulated in fp32 (the dropped W_lo*h_lo is below 2^-24 relative).
+// K positions are dealt round-robin over the four 16-lane quarters so that a k-step with few valid
+// features costs every lane equally little: position (q = lane>>4, j) of k-step ks <-> input feature
+// 32*ks + 4*j + q.
+//   A16[branch][ks][m][part][lane][8] f16 : part 0 = hi, 1 = lo of W[16*m + (lane&15)][32*ks + 4*j + (lane>>4)],
+//                                           W = sd1.weight with sd1_bn's 1/sqrt(var+eps) folded into its rows
+//   SD0[branch][ks][q][3][8] f32          : {w0[.][0]*s, w0[.][1]*s, beta - mean*s} for features 32*ks + 4*j + q,
+//                                           s = gamma/sqrt(var+eps) of sd0_bn
+// The record is padded to a whole number of 1-KiB LDS-DMA pieces.
 struct GwtfPackW {
   int FP;
   GWTF_HD GwtfPackW(int FP_) : FP(FP_) {}
   GWTF_HD int MB() const { return FP / 16; }
-  GWTF_HD int MBS() const { return MB() == 3 ? 4 : MB(); }  // per-lane stride: keep ds_read 16-B aligned
-  GWTF_HD int KK() const { return FP / 4; }
-  GWTF_HD size_t aimg_size() const { return (size_t)KK() * 64 * MBS(); }
-  GWTF_HD size_t aimg(int branch) const { return branch * aimg_size(); }
-  GWTF_HD size_t sd0(int branch) const { return 2 * aimg_size() + (size_t)branch * 4 * FP; }
-  GWTF_HD size_t coupling_size() const { return 2 * aimg_size() + 8 * (size_t)FP; }
+  GWTF_HD int KS() const { return (FP + 31) / 32; }
+  GWTF_HD size_t a16_size() const { return (size_t)KS() * MB() * 2 * 256; }  // floats (2 f16 each), one branch
+  GWTF_HD size_t a16(int branch) const { return branch * a16_size(); }
+  GWTF_HD size_t sd0_size() const { return (size_t)KS() * 4 * 24; }
+  GWTF_HD size_t sd0(int branch) const { return 2 * a16_size() + branch * sd0_size(); }
+  GWTF_HD size_t used_size() const { return 2 * a16_size() + 2 * sd0_size(); }
+  GWTF_HD size_t coupling_size() const { return (used_size() + 255) / 256 * 256; }
 };
 
 // PACKED FILM WEIGHTS (read by gwtf_film_forward), per coupling, per branch:

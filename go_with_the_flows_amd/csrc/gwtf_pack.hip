@@ -3,6 +3,7 @@
 // (a few hundred KB).  Layouts: gwtf_layout.h.  Arithmetic being folded: reference
 // lib/networks/flows.py:25-31 (sd0 -> BN -> ReLU -> sd1 -> BN(affine=False)) in eval mode.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 #include "gwtf_layout.h"
 #include "../../include/gwtf.h"
 
@@ -10,38 +11,52 @@ namespace {
 
 __device__ __forceinline__ float inv_std(float var) { return 1.0f / sqrtf(var + GWTF_BN_EPS); }
 
-// packed stack weights
+// packed stack weights (split-f16 fragment images + sd0 parameters), see gwtf_layout.h
 __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__ out, int C, int f, int G, int FP) {
   const GwtfRaw R(f, G);
   const GwtfPackW P(FP);
   const size_t per = P.coupling_size();
   const size_t total = per * (size_t)C;
-  const int MBS = P.MBS();
+  const int MB = P.MB(), KS = P.KS();
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx / per);
     size_t o = idx - (size_t)c * per;
     float v = 0.f;
-    if (o < 2 * P.aimg_size()) {
-      const int br = (int)(o / P.aimg_size());
-      o -= (size_t)br * P.aimg_size();
+    if (o < 2 * P.a16_size()) {
+      // one float slot = two consecutive f16 (j = 2*jp, 2*jp+1) of one lane's 8-element fragment
+      const int br = (int)(o / P.a16_size());
+      o -= (size_t)br * P.a16_size();
       const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
-      const int m = (int)(o % MBS);
-      const int lane = (int)((o / MBS) % 64);
-      const int kk = (int)(o / ((size_t)MBS * 64));
-      const int j = 16 * m + (lane & 15);   // output feature (row of sd1.weight)
-      const int i = 4 * kk + (lane >> 4);   // input feature
-      if (m < P.MB() && j < f && i < f) v = rb[R.sd1_w() + (size_t)j * f + i] * inv_std(rb[R.bn1() + f + j]);
-    } else {
-      o -= 2 * P.aimg_size();
-      const int br = (int)(o / (4 * (size_t)FP));
-      o -= (size_t)br * 4 * FP;
+      const int jp = (int)(o % 4);
+      const int lane = (int)((o / 4) % 64);
+      const int part = (int)((o / 256) % 2);
+      const int m = (int)((o / 512) % MB);
+      const int ks = (int)(o / ((size_t)512 * MB));
+      const int jo = 16 * m + (lane & 15);  // output feature (row of sd1.weight)
+      __half2 pk = __floats2half2_rn(0.f, 0.f);
+      if (ks < KS && jo < f) {
+        const float sc = inv_std(rb[R.bn1() + f + jo]);
+        float e[2];
+        for (int t = 0; t < 2; ++t) {
+          const int ji = 32 * ks + 4 * (2 * jp + t) + (lane >> 4);  // input feature
+          float w = 0.f;
+          if (ji < f) w = rb[R.sd1_w() + (size_t)jo * f + ji] * sc;
+          const float hi = __half2float(__float2half_rn(w));
+          e[t] = part == 0 ? hi : (w - hi);
+        }
+        pk = __floats2half2_rn(e[0], e[1]);
+      }
+      v = __builtin_bit_cast(float, pk);
+    } else if ((o -= 2 * P.a16_size()) < 2 * P.sd0_size()) {
+      const int br = (int)(o / P.sd0_size());
+      o -= (size_t)br * P.sd0_size();
       const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
-      const int j = (int)(o / 4), e = (int)(o % 4);
-      if (j < f) {
+      const int j = (int)(o % 8), e = (int)((o / 8) % 3), q = (int)((o / 24) % 4), ks = (int)(o / 96);
+      const int ft = 32 * ks + 4 * j + q;
+      if (ft < f) {
         const float* bn = rb + R.bn0();
-        const float s = bn[j] * inv_std(bn[3 * f + j]);
-        if (e < 2) v = rb[R.sd0_w() + 2 * j + e] * s;
-        else if (e == 2) v = bn[f + j] - bn[2 * f + j] * s;
+        const float s = bn[ft] * inv_std(bn[3 * f + ft]);
+        v = e < 2 ? rb[R.sd0_w() + 2 * ft + e] * s : bn[f + ft] - bn[2 * f + ft] * s;
       }
     }
     out[idx] = v;

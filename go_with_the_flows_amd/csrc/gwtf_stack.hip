@@ -7,16 +7,17 @@
 //
 // Work decomposition
 //   workgroup = 4 waves, one shape b, 4*16*NB consecutive points; wave = 16*NB points.
-//   The f x f per-point contraction (sd1) runs on v_mfma_f32_16x16x4_f32 with features on M and points on N:
-//     A[i][k] = W1'[16m+i][4kk+k]   (sd1 weight, sd1_bn scale folded; fragment-ordered image in LDS)
-//     B[k][j] = h0[4kk+k][point j]  (sd0 + sd0_bn + ReLU, computed in the lane that owns (k,j) -- 3 VALU ops)
-//     D[16m + 4q + r][point j]      (q = lane>>4, r = accumulator register)
+//   The f x f per-point contraction (sd1) runs on v_mfma_f32_16x16x32_f16 with features on M and points on N,
+//   every fp32 operand split into f16 hi + lo and three products accumulated in fp32 (gwtf_layout.h):
+//     A[i][k] = W1'[16m+i][feature(k)]   (sd1 weight, sd1_bn scale folded; fragment-ordered images in LDS)
+//     B[k][j] = h0[feature(k)][point j]  (sd0 + sd0_bn + ReLU, computed and split in the lane that owns (k,j))
+//     D[16m + 4q + r][point j]           (q = lane>>4, r = accumulator register)
 //   so ReLU + the f->w contraction (sd2) happen in-lane on the accumulators (FiLM is folded into the
 //   accumulator start value and into the sd2 weights by the FiLM kernel), followed by a
 //   transpose-reduce over the four lane quarters that leaves quarter q with the totals of point block q.
 //   Each lane then owns ONE point for the transcendental tail (softsign, exp, sqrt, affine) and the
 //   log-det accumulation; new coordinates are re-broadcast to the quarters with ds_bpermute.
-//   Per coupling the packed weights (2*FP^2 + 8*FP floats) and this shape's FiLM vectors are copied
+//   Per coupling the packed weights (~2*FP^2 + 6*FP floats) and this shape's FiLM vectors are copied
 //   global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double buffer while the previous coupling
 //   computes; one barrier per coupling.
 #include <hip/hip_runtime.h>
@@ -26,41 +27,29 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
 template <int MB>
 struct Cfg {
   static constexpr int FP = 16 * MB;
-  static constexpr int KK = FP / 4;
-  static constexpr int MBS = MB == 3 ? 4 : MB;
-  static constexpr int AIMG = KK * 64 * MBS;           // floats, one branch
-  static constexpr int PW = 2 * AIMG + 8 * FP;         // packed weights per coupling
-  static constexpr int FS = 6 * FP + 4;                // FiLM output per (shape, coupling)
-  static constexpr int LAYER = PW + FS;                // one LDS buffer, multiple of 4 floats
-  static constexpr int LAYER_PAD = (LAYER + 255) / 256 * 256;  // whole 1-KiB DMA pieces
+  static constexpr int KS = (FP + 31) / 32;               // k-steps of 32 input features
+  static constexpr int A16 = KS * MB * 2 * 256;           // floats, one branch (hi + lo f16 fragment images)
+  static constexpr int SD0 = KS * 4 * 24;                 // floats, one branch
+  static constexpr int PW = (2 * A16 + 2 * SD0 + 255) / 256 * 256;  // packed weights per coupling (whole DMA pieces)
+  static constexpr int FS = 6 * FP + 4;                   // FiLM output per (shape, coupling)
+  static constexpr int FSP = (FS + 255) / 256 * 256;
+  static constexpr int LAYER = PW + FSP;                  // one LDS buffer
 };
 
 __device__ __forceinline__ float sel3(float a, float b, float c, int d) { return d == 0 ? a : (d == 1 ? b : c); }
 
-template <int MB>
-__device__ __forceinline__ void load_afrag(const float* p, float (&a)[MB]);
-template <>
-__device__ __forceinline__ void load_afrag<1>(const float* p, float (&a)[1]) { a[0] = p[0]; }
-template <>
-__device__ __forceinline__ void load_afrag<2>(const float* p, float (&a)[2]) {
-  const float2 v = *reinterpret_cast<const float2*>(p);
-  a[0] = v.x; a[1] = v.y;
-}
-template <>
-__device__ __forceinline__ void load_afrag<3>(const float* p, float (&a)[3]) {
-  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-  a[0] = v[0]; a[1] = v[1]; a[2] = v[2];
-}
-template <>
-__device__ __forceinline__ void load_afrag<4>(const float* p, float (&a)[4]) {
-  const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-  a[0] = v[0]; a[1] = v[1]; a[2] = v[2]; a[3] = v[3];
+// x = hi + lo with both parts rounded to nearest f16 (|lo| <= 2^-12 |x|): 1 + 2 + 2 + 1 VALU for two values
+__device__ __forceinline__ void split_pair(float h0, float h1, f16x2& hi, f16x2& lo) {
+  hi = f16x2{(_Float16)h0, (_Float16)h1};
+  lo = f16x2{(_Float16)(h0 - (float)hi[0]), (_Float16)(h1 - (float)hi[1])};
 }
 
 // Sum the per-quarter partials o[nb] over the four 16-lane quarters so that the lane in quarter q ends
@@ -86,8 +75,10 @@ __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
 
 // One elementary coupling on the wave's tile.  KEEP2 = two kept coordinates / one warped (patterns 0-2),
 // otherwise one kept / two warped (patterns 3-5).  Every VALU instruction here costs the SIMD 4 cycles that
-// the matrix pipe cannot use (measured: v_mfma_f32 and VALU of two waves on one SIMD do not overlap,
+// the matrix pipe cannot use (measured: MFMA and VALU of two waves on one SIMD do not overlap,
 // tools/diag/coissue.hip), so the body is specialised to issue as few as possible:
+//   - the f x f contraction runs at the f16 matrix rate on split operands (gwtf_layout.h): 3 MFMAs of 16 cycles
+//     per 16x16x32 block instead of 8 fp32 MFMAs of 32 cycles, at fp32-grade accuracy;
 //   - the accumulators start at c = b'/a (FiLM shift over FiLM scale, a > 0) instead of zero, so
 //     relu(a*y + b') * W2  becomes  relu(acc) * (W2*a): one v_max + one v_fma per warped coordinate;
 //   - the second sd0 input / second sd2 output only exist in the variant that needs them.
@@ -96,14 +87,15 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
                                               int w0, int w1, float eps, float s_keep, const float (&x)[NB][3],
                                               float (&xo)[3], float (&mu_d)[3], float (&lv_d)[3]) {
   using K = Cfg<MB>;
-  constexpr int FP = K::FP, MBS = K::MBS;
+  constexpr int FP = K::FP, KS = K::KS;
   float xa[NB], xb[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
     xb[nb] = KEEP2 ? sel3(x[nb][0], x[nb][1], x[nb][2], k1) : 0.f;
   }
-  float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};  // [branch][warped slot] for this lane's own point
+  const int nj_last = kk_steps - 8 * (KS - 1);   // valid k positions per lane in the last k-step (1..8)
+  float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};    // [branch][warped slot] for this lane's own point
 #pragma unroll
   for (int br = 0; br < 2; ++br) {
     const float* fe = L + K::PW + br * 3 * FP + 4 * q;   // c | w20a | w21a, this lane's 4 features per block
@@ -114,22 +106,53 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) acc[m][nb] = c4;
     }
-    const float* aimg = L + br * K::AIMG + lane * MBS;
-    const f32x4* sd0 = reinterpret_cast<const f32x4*>(L + 2 * K::AIMG + br * 4 * FP) + q;
-    // k-loop over input features, 4 per MFMA; only ceil(f/4) steps carry non-zero weights
-#pragma unroll 2
-    for (int kk = 0; kk < kk_steps; ++kk) {
-      const f32x4 s0 = sd0[4 * kk];
-      float a[MB];
-      load_afrag<MB>(aimg + kk * 64 * MBS, a);
-      float h[NB];
+    const float* aimg = L + br * K::A16 + lane * 4;
+    const float* sd0 = L + 2 * K::A16 + br * K::SD0 + q * 24;
 #pragma unroll
-      for (int nb = 0; nb < NB; ++nb)
-        h[nb] = fmaxf(KEEP2 ? fmaf(s0[0], xa[nb], fmaf(s0[1], xb[nb], s0[2])) : fmaf(s0[0], xa[nb], s0[2]), 0.f);
+    for (int ks = 0; ks < KS; ++ks) {
+      // sd0 + sd0_bn + ReLU for this lane's 8 k positions (features 32*ks + 4*j + q), split into f16 hi/lo
+      const f32x4* sp = reinterpret_cast<const f32x4*>(sd0 + ks * 96);
+      const f32x4 wa[2] = {sp[0], sp[1]};
+      const f32x4 wb[2] = {KEEP2 ? sp[2] : f32x4{0.f, 0.f, 0.f, 0.f}, KEEP2 ? sp[3] : f32x4{0.f, 0.f, 0.f, 0.f}};
+      const f32x4 cc[2] = {sp[4], sp[5]};
+      f16x8 bhi[NB], blo[NB];
 #pragma unroll
-      for (int m = 0; m < MB; ++m)
+      for (int jp = 0; jp < 4; ++jp) {
+        if (ks + 1 < KS || 2 * jp < nj_last) {     // wave-uniform: skip k positions beyond ceil(f/4)
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], h[nb], acc[m][nb], 0, 0, 0);
+          for (int nb = 0; nb < NB; ++nb) {
+            float h[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+              const int j = 2 * jp + t;
+              const float pre = KEEP2 ? fmaf(wa[j >> 2][j & 3], xa[nb], fmaf(wb[j >> 2][j & 3], xb[nb], cc[j >> 2][j & 3]))
+                                      : fmaf(wa[j >> 2][j & 3], xa[nb], cc[j >> 2][j & 3]);
+              h[t] = fmaxf(pre, 0.f);
+            }
+            f16x2 hi, lo;
+            split_pair(h[0], h[1], hi, lo);
+            bhi[nb][2 * jp] = hi[0]; bhi[nb][2 * jp + 1] = hi[1];
+            blo[nb][2 * jp] = lo[0]; blo[nb][2 * jp + 1] = lo[1];
+          }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            bhi[nb][2 * jp] = bhi[nb][2 * jp + 1] = (_Float16)0.f;
+            blo[nb][2 * jp] = blo[nb][2 * jp + 1] = (_Float16)0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);
+        const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 1) * 256);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[nb], acc[m][nb], 0, 0, 0);
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[nb], acc[m][nb], 0, 0, 0);
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[nb], acc[m][nb], 0, 0, 0);
+        }
+      }
     }
     // ReLU + sd2 on the accumulators (FiLM already folded in)
     float o0[NB], o1[NB];
@@ -183,7 +206,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
                                                     float* __restrict__ mus, float* __restrict__ lvs, int B, int N, int C,
                                                     int pattern0, float eps, int tiles_per_shape, int kk_steps) {
   using K = Cfg<MB>;
-  __shared__ __align__(16) float lds[2][K::LAYER_PAD];
+  __shared__ __align__(16) float lds[2][K::LAYER];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
@@ -195,18 +218,19 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   const bool own_valid = n_own < N && q < NB;  // q >= NB holds duplicates of quarter q & (NB-1)
   const bool own_inrange = n_own < N;
 
-  // global -> LDS staging of one coupling (LDS-DMA, 1 KiB per wave-instruction)
+  // global -> LDS staging of one coupling (LDS-DMA, 1 KiB per wave-instruction): whole pieces of packed
+  // weights, then this shape's FiLM record (its last piece is partial)
   auto stage = [&](int buf, int c) {
-    const float* src_w = pw + (size_t)c * K::PW;
-    const float* src_f = film + ((size_t)b * C + c) * K::FS;
-    constexpr int PIECES = K::LAYER_PAD / 256;
-    for (int piece = wave; piece < PIECES; piece += 4) {
-      const int fo = piece * 256 + lane * 4;  // float offset inside the layer image
-      if (fo < K::LAYER) {
-        const float* src = fo < K::PW ? src_w + fo : src_f + (fo - K::PW);
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
-      }
+    const float* src_w = pw + (size_t)c * K::PW + lane * 4;
+    const float* src_f = film + ((size_t)b * C + c) * K::FS + lane * 4;
+#pragma unroll
+    for (int i = 0; i < (K::PW / 256 + 3) / 4; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < K::PW / 256)
+        __builtin_amdgcn_global_load_lds((glb_void*)(src_w + piece * 256), (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
     }
+    if (wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
+      __builtin_amdgcn_global_load_lds((glb_void*)(src_f + wave * 256), (lds_void*)&lds[buf][K::PW + wave * 256], 16, 0, 0);
   };
 
   // this lane's own point (one per lane) and the per-quarter copies used to build the MFMA B operand

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Condense a tools/profile.sh output directory into the text summary committed under profiles/."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+root = sys.argv[1]
+for w in ('airplane', 'm1'):
+    print(f'===== workload {w} =====')
+    st = glob.glob(os.path.join(root, f'trace_{w}', '*kernel_stats.csv'))
+    if st:
+        print('-- rocprofv3 --kernel-trace --stats (top kernels) --')
+        for i, r in enumerate(csv.DictReader(open(st[0]))):
+            if i < 6:
+                print(f"{r['Name'][:90]:90s} calls={r['Calls']:>6s} avg_ns={float(r['AverageNs']):>12.1f} pct={r['Percentage']}")
+    agg = collections.defaultdict(list)
+    meta = {}
+    for d in ('pmc_sq', 'pmc_mfma', 'pmc_fetch', 'pmc_write'):
+        for f in glob.glob(os.path.join(root, f'{d}_{w}', '*counter_collection.csv')):
+            for r in csv.DictReader(open(f)):
+                if 'stack_kernel' in r['Kernel_Name']:
+                    agg[r['Counter_Name']].append(float(r['Counter_Value']))
+                    meta = {k: r[k] for k in ('Grid_Size', 'Workgroup_Size', 'LDS_Block_Size', 'VGPR_Count', 'Accum_VGPR_Count', 'SGPR_Count')}
+    if agg:
+        print('-- PMC, stack_kernel, mean per dispatch --', meta)
+        for k in sorted(agg):
+            print(f'{k:28s} {sum(agg[k]) / len(agg[k]):16.1f}   (n={len(agg[k])})')
+        g = lambda k: sum(agg[k]) / len(agg[k]) if agg.get(k) else float('nan')
+        waves = float(meta['Grid_Size']) / 64
+        print(f'waves={waves:.0f}  VALU/wave={g("SQ_INSTS_VALU") / waves:.0f}  MFMA/wave={g("SQ_INSTS_MFMA") / waves:.0f}')
+        print(f'HBM bytes per dispatch: read = 2*FETCH_SIZE*1024 = {2 * g("FETCH_SIZE") * 1024:.3e} (gfx950 correction x2), '
+              f'write = WRITE_SIZE*1024 = {g("WRITE_SIZE") * 1024:.3e}')
