@@ -166,108 +166,126 @@ __global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ g, 
 
 // ---------------------------------------------------------------------------------------------
 // Eval-mode fast path.  No cross-shape dependency (BatchNorm is folded), so the grid also tiles B:
-// one workgroup per (coupling, branch, tile of kBTe shapes).  Weights and the g tile are staged
-// through LDS in G-chunks with coalesced float4 loads (the first version read them straight from
-// L2 inside the dot-product loop and was latency-bound: 89 us for 66 workgroups); lane = output
-// feature, each wave carries kRe shapes so a weight read from LDS feeds 2*kRe FMAs.
-constexpr int kBTe = 16;            // shapes per workgroup
-constexpr int kRe = kBTe / kWaves;  // shapes per wave
-constexpr int kGC = 64;             // rows of L0T per LDS chunk
+// one workgroup per (coupling, branch, tile of 16 shapes).  Both Linear layers of both heads run on
+// v_mfma_f32_16x16x4_f32 (exact fp32, bitwise an fmaf chain) with the 16 shapes on M:
+//     layer 1:  H[16 x FP]  = g_tile[16 x G] . L0T[G x FP]      per head, K = G
+//     layer 2:  O[16 x FP]  = swish(bn(H))   . L1T[FP x FP]     per head, K = FP
+// Wave w owns feature block w (16 output features) of BOTH heads, so the final a = eps + exp(w-head),
+// c = c1 + b-head / a is computed in-lane from its two accumulators.  The contraction index is free to be
+// renamed, so k-slot (step 4*kg + t, quarter q) is mapped to column 16*kg + 4*q + t: a lane's A operands
+// of four consecutive MFMAs are four consecutive floats.  (History: a VALU version with operands read from
+// L2 inside the dot-product loop took 89 us for 66 workgroups; VALU from LDS 24 us; MFMA with LDS-staged
+// operands and a barrier per chunk 15-18 us -- every phase was a dependent load->sync->compute step.)
+constexpr int kBTe = 16;   // shapes per workgroup = one MFMA M tile
+constexpr int kGCH = 128;  // latent columns per register-resident chunk
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// The whole kernel is one dependent chain (load -> 2 GEMMs -> exp), so it is written for latency: all
+// operands of a K chunk are fetched straight from L2 into registers with independent, unpredicated loads
+// issued back to back (no LDS staging, no barrier; L0T is zero-padded to a multiple of 16 rows by the packer
+// and out-of-range latent columns / shapes are clamped, their products land on zero weights or discarded
+// rows), the layer-2 weights are prefetched before layer 1 starts, and the only LDS traffic is the 16 x FP
+// transpose of the hidden activations between the two layers.
+template <int MB>
 __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict__ g, const float* __restrict__ pf,
-                                                        float* __restrict__ out, int B, int G, int C, int f, int FP,
-                                                        float eps) {
-  extern __shared__ __align__(16) float smem[];
+                                                        float* __restrict__ out, int B, int G, int C, int f, float eps) {
+  constexpr int FP = 16 * MB;
+  __shared__ __align__(16) float hb[2][16][FP + 4];   // [head][shape][feature]
   const int c = blockIdx.x, br = blockIdx.y, b0 = blockIdx.z * kBTe;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
   const GwtfPackF P(FP, G);
+  const int GP = P.GP();
   const float* w = pf + ((size_t)c * 2 + br) * P.branch_size();
   const size_t FS = gwtf_film_out_size(FP);
-  const bool act = lane < FP;
-  float* wl = smem;                                // [2][kGC][FP] weight chunk (also reused for L1T: [2][FP][FP])
-  float* gt = wl + 2 * (size_t)(kGC > FP ? kGC : FP) * FP;  // [kBTe][kGC] latent chunk
-  float* hb = gt + (size_t)kBTe * kGC;             // [kBTe][2][FP] hidden activations
+  const bool own = wave < MB;                        // this wave's feature block exists
+  const int ft = 16 * wave + i16;                    // output feature owned by this lane (both heads)
+  const int brow = b0 + i16;                         // shape whose latent row this lane feeds to the A operand
+  const float* grow = g + (size_t)(brow < B ? brow : B - 1) * G;
+  const float* l0 = w + P.l0t(0) + ft;
+  const float* l1 = w + P.l0t(1) + ft;
 
-  float acc[2][kRe];
+  f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  f32x4 w1[2][MB];                                   // layer-2 B operands (prefetched)
+  if (own) {
 #pragma unroll
-  for (int r = 0; r < kRe; ++r) acc[0][r] = acc[1][r] = 0.f;
-  for (int i0 = 0; i0 < G; i0 += kGC) {
-    const int rows = min(kGC, G - i0);
-    __syncthreads();
-    // stage L0T rows [i0, i0+rows) of both heads: contiguous rows*FP floats each
-    for (int which = 0; which < 2; ++which) {
-      const float4* src = reinterpret_cast<const float4*>(w + P.l0t(which) + (size_t)i0 * FP);
-      float4* dst = reinterpret_cast<float4*>(wl + (size_t)which * kGC * FP);
-      for (int t = threadIdx.x; t < rows * FP / 4; t += blockDim.x) dst[t] = src[t];
-    }
-    for (int t = threadIdx.x; t < kBTe * kGC; t += blockDim.x) {
-      const int r = t / kGC, i = t - r * kGC;
-      gt[t] = (b0 + r < B && i < rows) ? g[(size_t)(b0 + r) * G + i0 + i] : 0.f;
-    }
-    __syncthreads();
-    if (act) {
-      for (int i = 0; i < rows; ++i) {
-        const float w0 = wl[(size_t)i * FP + lane], w1 = wl[(size_t)(kGC + i) * FP + lane];
+    for (int kg = 0; kg < MB; ++kg)
 #pragma unroll
-        for (int r = 0; r < kRe; ++r) {
-          const float gv = gt[(wave * kRe + r) * kGC + i];
-          acc[0][r] = fmaf(gv, w0, acc[0][r]);
-          acc[1][r] = fmaf(gv, w1, acc[1][r]);
+      for (int which = 0; which < 2; ++which)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w1[which][kg][t] = w[P.l1t(which) + (size_t)(16 * kg + 4 * q + t) * FP + ft];
+    for (int i0 = 0; i0 < GP; i0 += kGCH) {
+      f32x4 a4[kGCH / 16], b4[2][kGCH / 16];
+#pragma unroll
+      for (int kg = 0; kg < kGCH / 16; ++kg) {
+        if (i0 + 16 * kg < GP) {                     // wave-uniform
+          const int col = i0 + 16 * kg + 4 * q;      // k-slot (4*kg + t, q) <-> latent column col + t
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            a4[kg][t] = grow[col + t < G ? col + t : G - 1];
+            b4[0][kg][t] = l0[(size_t)(col + t) * FP];
+            b4[1][kg][t] = l1[(size_t)(col + t) * FP];
+          }
+        }
+      }
+#pragma unroll
+      for (int kg = 0; kg < kGCH / 16; ++kg) {
+        if (i0 + 16 * kg < GP) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[kg][t], b4[0][kg][t], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[kg][t], b4[1][kg][t], acc[1], 0, 0, 0);
+          }
         }
       }
     }
-  }
-  __syncthreads();
-  // BatchNorm (folded) + Swish -> hb ; stage L1T of both heads into wl
-  if (act) {
+    // BatchNorm (folded) + Swish; hidden activations -> LDS for the layer-2 A operand
 #pragma unroll
     for (int which = 0; which < 2; ++which) {
-      const float s = w[P.s(which) + lane], t = w[P.t(which) + lane];
+      const float sc = w[P.s(which) + ft], sh = w[P.t(which) + ft];
 #pragma unroll
-      for (int r = 0; r < kRe; ++r) {
-        const float h = fmaf(acc[which][r], s, t);
-        hb[((size_t)(wave * kRe + r) * 2 + which) * FP + lane] = h / (1.0f + expf(-h));
+      for (int r = 0; r < 4; ++r) {
+        const float h = fmaf(acc[which][r], sc, sh);
+        hb[which][4 * q + r][ft] = h / (1.0f + expf(-h));
       }
     }
   }
-  for (int which = 0; which < 2; ++which) {
-    const float4* src = reinterpret_cast<const float4*>(w + P.l1t(which));
-    float4* dst = reinterpret_cast<float4*>(wl + (size_t)which * FP * FP);
-    for (int t = threadIdx.x; t < FP * FP / 4; t += blockDim.x) dst[t] = src[t];
-  }
   __syncthreads();
-  if (!act) return;
-  float o[2][kRe];
+  if (!own) return;
+  f32x4 o[2];
 #pragma unroll
-  for (int r = 0; r < kRe; ++r) {
-    o[0][r] = w[P.l1b(0) + lane];
-    o[1][r] = w[P.l1b(1) + lane];
+  for (int which = 0; which < 2; ++which) {
+    const float bias = w[P.l1b(which) + ft];
+    o[which] = f32x4{bias, bias, bias, bias};
   }
-  for (int i = 0; i < FP; ++i) {
-    const float w0 = wl[(size_t)i * FP + lane], w1 = wl[(size_t)(FP + i) * FP + lane];
 #pragma unroll
-    for (int r = 0; r < kRe; ++r) {
-      o[0][r] = fmaf(hb[((size_t)(wave * kRe + r) * 2 + 0) * FP + i], w0, o[0][r]);
-      o[1][r] = fmaf(hb[((size_t)(wave * kRe + r) * 2 + 1) * FP + i], w1, o[1][r]);
+  for (int kg = 0; kg < MB; ++kg) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(&hb[0][i16][16 * kg + 4 * q]);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(&hb[1][i16][16 * kg + 4 * q]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      o[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[t], w1[0][kg][t], o[0], 0, 0, 0);
+      o[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[t], w1[1][kg][t], o[1], 0, 0, 0);
     }
   }
-  const float c1 = w[P.c1() + lane], w20 = w[P.w2() + lane], w21 = w[P.w2() + FP + lane];
+  const float c1 = w[P.c1() + ft], w20 = w[P.w2() + ft], w21 = w[P.w2() + FP + ft];
 #pragma unroll
-  for (int r = 0; r < kRe; ++r) {
-    const int b = b0 + wave * kRe + r;
+  for (int r = 0; r < 4; ++r) {
+    const int b = b0 + 4 * q + r;
     if (b < B) {
       float cv = 0.f, u0 = 0.f, u1 = 0.f;
-      if (lane < f) {
+      if (ft < f) {
         const float a = eps + expf(o[0][r]);
         cv = c1 + o[1][r] / a;
         u0 = w20 * a;
         u1 = w21 * a;
       }
-      float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + lane;
+      float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + ft;
       ob[0] = cv;
       ob[FP] = u0;
       ob[2 * FP] = u1;
-      if (lane < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + lane] = w[P.b2() + lane];
+      if (ft < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + ft] = w[P.b2() + ft];
     }
   }
 }
@@ -290,10 +308,13 @@ extern "C" int gwtf_film_forward(const float* g, const float* packed_film, float
     hipLaunchKernelGGL(film_kernel<true>, dim3(C, 2), dim3(256), smem, st, g, packed_film, film_out, bn_stats_out, B, G, C,
                        f, FP, eps);
   } else {
-    const int rowsmax = kGC > FP ? kGC : FP;
-    const size_t smem_e = (2 * (size_t)rowsmax * FP + (size_t)kBTe * kGC + (size_t)kBTe * 2 * FP) * sizeof(float);
-    hipLaunchKernelGGL(film_eval_kernel, dim3(C, 2, (B + kBTe - 1) / kBTe), dim3(256), smem_e, st, g, packed_film,
-                       film_out, B, G, C, f, FP, eps);
+    const dim3 grid(C, 2, (B + kBTe - 1) / kBTe);
+    switch (FP / 16) {
+      case 1: hipLaunchKernelGGL(film_eval_kernel<1>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
+      case 2: hipLaunchKernelGGL(film_eval_kernel<2>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
+      case 3: hipLaunchKernelGGL(film_eval_kernel<3>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
+      default: hipLaunchKernelGGL(film_eval_kernel<4>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
+    }
   }
   return (int)hipGetLastError();
 }

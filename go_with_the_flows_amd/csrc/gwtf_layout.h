@@ -69,16 +69,17 @@ struct GwtfPackW {
 };
 
 // PACKED FILM WEIGHTS (read by gwtf_film_forward), per coupling, per branch:
-//   for which in {w,b}: L0T[G][FP] | S[FP] | T[FP] | L1T[FP][FP] | L1B[FP]
+//   for which in {w,b}: L0T[GP][FP] (GP = G rounded up to 16, zero rows beyond G) | S[FP] | T[FP] | L1T[FP][FP] | L1B[FP]
 //   C1[FP] (sd1_bn shift: -mean/sqrt(var+eps)) | W2[2][FP] | B2[4] (sd2 bias, 2 used)
 // eval: S = gamma/sqrt(var+eps), T = beta - mean*S (running statistics)
 // train: S = gamma, T = beta (batch statistics are taken inside the FiLM kernel)
 struct GwtfPackF {
   int FP, G;
   GWTF_HD GwtfPackF(int FP_, int G_) : FP(FP_), G(G_) {}
-  GWTF_HD size_t mlp_size() const { return (size_t)G * FP + 3 * (size_t)FP + (size_t)FP * FP; }
+  GWTF_HD int GP() const { return (G + 15) / 16 * 16; }
+  GWTF_HD size_t mlp_size() const { return (size_t)GP() * FP + 3 * (size_t)FP + (size_t)FP * FP; }
   GWTF_HD size_t l0t(int which) const { return which * mlp_size(); }
-  GWTF_HD size_t s(int which) const { return l0t(which) + (size_t)G * FP; }
+  GWTF_HD size_t s(int which) const { return l0t(which) + (size_t)GP() * FP; }
   GWTF_HD size_t t(int which) const { return s(which) + FP; }
   GWTF_HD size_t l1t(int which) const { return t(which) + FP; }
   GWTF_HD size_t l1b(int which) const { return l1t(which) + (size_t)FP * FP; }

@@ -79,10 +79,10 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
       const int which = (int)(o / P.mlp_size());
       o -= (size_t)which * P.mlp_size();
       const float* bn = rb + R.film_bn(which);
-      if (o < (size_t)G * FP) {  // L0T[i][j] = L0[j][i]
+      if (o < (size_t)P.GP() * FP) {  // L0T[i][j] = L0[j][i], rows G..GP-1 zero
         const int i = (int)(o / FP), j = (int)(o % FP);
-        if (j < f) v = rb[R.film_l0(which) + (size_t)j * G + i];
-      } else if ((o -= (size_t)G * FP) < (size_t)FP) {  // S
+        if (j < f && i < G) v = rb[R.film_l0(which) + (size_t)j * G + i];
+      } else if ((o -= (size_t)P.GP() * FP) < (size_t)FP) {  // S
         const int j = (int)o;
         if (j < f) v = training ? bn[j] : bn[j] * inv_std(bn[3 * f + j]);
       } else if ((o -= FP) < (size_t)FP) {  // T

@@ -8,6 +8,7 @@ hand-written HIP kernels (``csrc/``) through the C ABI in ``include/gwtf.h``: on
 launch (cached while parameters are unchanged), one FiLM launch, one fused stack launch.
 There is no torch/CPU fallback: tensors must live on a HIP device.
 """
+import operator
 from collections import OrderedDict
 
 import torch
@@ -16,6 +17,8 @@ import torch.nn.functional as F
 
 from . import _lib
 from .layers import SharedDot, Swish
+
+_VERSION = operator.attrgetter('_version')
 
 # index -> warped coordinates; couplings of a decoder cycle through these (reference flows.py:129-148)
 WARP_PATTERNS = ((0,), (1,), (2,), (0, 1), (0, 2), (1, 2))
@@ -193,7 +196,7 @@ class StackEngine:
         if stamp != self._tracked_stamp:  # buffers are re-created by .to()/.cuda(): re-collect
             self._tracked = [t for c in self.couplings for t in c.tracked_tensors()]
             self._tracked_stamp = stamp
-        return (training, stamp, sum(t._version for t in self._tracked))
+        return (training, stamp, sum(map(_VERSION, self._tracked)))
 
     def packed(self, training):
         key = self._key(training)
