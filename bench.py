@@ -92,6 +92,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--workload', default='airplane', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch through the eager module path instead of one hipGraph per step')
     ap.add_argument('--points-per-wave', type=int, default=0, help='tuning hook: 16/32/64, 0 = library default')
     args = ap.parse_args()
 
@@ -124,22 +125,56 @@ def main():
     engines = [d.engine() for d in decoders]
     eps = decoders[0].flows[0].nvp1._eps_value
     sideways = mode == 'direct' and K > 1                # sampling: each point visits ONE component
-    if sideways:
-        chunks = [c.contiguous() for c in pd.chunk(K, dim=2)]
+    stack = gw.MixtureStack(decoders)                    # K components: one FiLM launch + one stack launch
+    counts = [N // K] * K
+
+    def launch_step():
+        if sideways:
+            return stack.forward_partition(pd, gd, counts, mode)
+        return stack.forward_all(pd, gd, mode)
 
     def step(timers=None):
-        outs = []
-        for k, eng in enumerate(engines):
-            pw, pf = eng.packed(False)
-            film = _lib.film_forward(gd, pf, eng.C, f, eps, False)
+        """Eager path with HIP events around the stack launch (kernel-duration probe)."""
+        pw, film, _ = stack._film(gd)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if sideways:
+            segs = [(k * (N // K), (k + 1) * (N // K)) for k in range(K)]
+            res = _lib.stack_forward_multi(pd, pw, film, K, stack.C, f, 0, eps, mode, segments=segs, shared_points=False)
+        else:
+            res = _lib.stack_forward_multi(pd, pw, film, K, stack.C, f, 0, eps, mode)
+        e1.record()
+        if timers is not None:
+            timers.append((e0, e1))
+        return res
+
+    eager_step = step
+    graph = None
+    if not args.eager:
+        # one hipGraph per step, bound to the resident p / g
+        with torch.no_grad():
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                launch_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                graph_out = launch_step()
+
+        def step(timers=None):                      # noqa: F811
             if timers is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            outs.append(_lib.stack_forward(chunks[k] if sideways else pd, pw, film, eng.C, f, 0, eps, mode, False))
-            if timers is not None:
+                graph.replay()
                 e1.record()
                 timers.append((e0, e1))
-        return outs
+            else:
+                graph.replay()
+            return graph_out
+    else:
+        def step(timers=None):                      # noqa: F811
+            return eager_step(timers) if timers is not None else launch_step()
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -165,8 +200,18 @@ def main():
     comp_passes = 1 if sideways else K
     pts_per_step_per_gpu = B * N * comp_passes
     value = world * pts_per_step_per_gpu * args.steps / elapsed / 1e6
+    if graph is not None:
+        # per-kernel duration of the dominant kernel: same launches, same inputs, eager, HIP events around each
+        # stack launch on the launch stream (a graph replay cannot be bracketed per kernel)
+        timers = []
+        with torch.no_grad():
+            for _ in range(3):
+                eager_step()
+            for _ in range(max(10, args.steps // 2)):
+                eager_step(timers)
+        torch.cuda.synchronize(dev)
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in timers]))           # one stack launch, HIP events
-    pts_per_launch = B * (N // K if sideways else N)
+    pts_per_launch = B * N * comp_passes                                         # all components in one launch
     achieved = flops_per_point(L, f) * pts_per_launch / (kern_ms * 1e-3) / 1e12
 
     if rank == 0:
@@ -182,7 +227,8 @@ def main():
             'config': {'workload': cfg['name'], 'per_gpu_batch': B, 'points_per_shape': N, 'components': K,
                        'couplings_per_component': 3 * L, 'f': f, 'G': G, 'direction': mode,
                        'point_definition': 'one 3-D point through one component stack (coords + sum logvars)',
-                       'sharding': f'batch of shapes over {world} rank(s), no data-path collective'},
+                       'sharding': f'batch of shapes over {world} rank(s), no data-path collective',
+                       'launch': ('eager: ' if args.eager else 'one hipGraph replay per step: ') + '1 FiLM + 1 stack launch for all components'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
                          'kernel': 'stack_kernel (fused coupling stack)', 'kernel_ms': round(kern_ms, 4),

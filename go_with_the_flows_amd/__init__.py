@@ -2,7 +2,8 @@
 from .layers import SharedDot, Swish
 from .flows import CondRealNVPFlow3D, CondRealNVPFlow3DTriple, WARP_PATTERNS
 from .decoders import LocalCondRNVPDecoder
+from .mixture import MixtureStack, flow_mixture_nll
 from ._lib import GwtfError
 
 __all__ = ['SharedDot', 'Swish', 'CondRealNVPFlow3D', 'CondRealNVPFlow3DTriple', 'LocalCondRNVPDecoder',
-           'WARP_PATTERNS', 'GwtfError']
+           'WARP_PATTERNS', 'GwtfError', 'MixtureStack', 'flow_mixture_nll']

@@ -28,6 +28,8 @@ _SIGNATURES = {
     'gwtf_film_forward': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_stack_forward_multi': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
+                                 [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
 }
@@ -123,6 +125,37 @@ def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists):
                                    _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], B, N, C, f, pattern0, float(eps),
                                    _MODES[mode], _stream(p)))
     return out, logdet, lists
+
+
+def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segments=None, shared_points=True):
+    """K components in one launch.  shared_points=True: every component maps all of p -> outputs (K,B,3,N).
+    Otherwise ``segments`` (list of K (begin,end)) partitions the N points among the components -> (B,3,N)."""
+    L = lib()
+    B, three, N = p.shape
+    if three != 3:
+        raise GwtfError(f'p must be (B,3,N), got {tuple(p.shape)}')
+    if film.shape[0] != B or film.shape[1] != K * C:
+        raise GwtfError(f'film is {tuple(film.shape)}, expected ({B},{K * C},...)')
+    seg = None
+    if segments is not None:
+        flat = [int(v) for be in segments for v in be]
+        if len(flat) != 2 * K:
+            raise GwtfError('segments must hold K (begin, end) pairs')
+        seg = (ctypes.c_int * (2 * K))(*flat)
+    if shared_points:
+        out = torch.empty(K, B, 3, N, device=p.device, dtype=torch.float32)
+        logdet = torch.empty(K, B, 3, N, device=p.device, dtype=torch.float32)
+        stride = B * 3 * N
+    else:
+        # points outside every segment are not touched by the kernel: define them
+        out = torch.zeros(B, 3, N, device=p.device, dtype=torch.float32)
+        logdet = torch.zeros(B, 3, N, device=p.device, dtype=torch.float32)
+        stride = 0
+    with torch.cuda.device(p.device):
+        check(L.gwtf_stack_forward_multi(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                         _ptr(logdet, 'logdet'), None, None, None, seg, K, B, N, C, f, pattern0,
+                                         float(eps), _MODES[mode], 0, stride, _stream(p)))
+    return out, logdet
 
 
 def mixture_nll(z, logdet, mu0, lv0, logits, want_point_lse=False):

@@ -22,6 +22,7 @@
 
 #define GWTF_BN_EPS 1e-5f
 #define GWTF_MAX_FP 64
+#define GWTF_MAX_COMPONENTS 64
 
 struct GwtfRaw {  // offsets inside one branch record
   int f, G;

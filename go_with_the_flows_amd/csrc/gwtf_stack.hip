@@ -199,30 +199,53 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
   }
 }
 
+// Work list of one launch: component k applies ITS stack to points [begin[k], end[k]) of every shape.
+// Passed by value in the kernel arguments (wave-uniform, scalar loads).
+struct Jobs {
+  int K;
+  int tiles_cum[GWTF_MAX_COMPONENTS + 1];  // prefix sum of B * tiles(k)
+  int begin[GWTF_MAX_COMPONENTS], end[GWTF_MAX_COMPONENTS];
+};
+
 template <int MB, int NB, int MODE, bool LISTS>
 __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p, const float* __restrict__ pw,
                                                     const float* __restrict__ film, float* __restrict__ out,
                                                     float* __restrict__ logdet, float* __restrict__ ps,
                                                     float* __restrict__ mus, float* __restrict__ lvs, int B, int N, int C,
-                                                    int pattern0, float eps, int tiles_per_shape, int kk_steps) {
+                                                    int pattern0, float eps, int kk_steps, const Jobs jobs,
+                                                    size_t p_stride_k, size_t out_stride_k) {
   using K = Cfg<MB>;
   __shared__ __align__(16) float lds[2][K::LAYER];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
-  const int b = blockIdx.x / tiles_per_shape;
-  const int tile = blockIdx.x - b * tiles_per_shape;
-  const int n_wave0 = (tile * 4 + wave) * 16 * NB;
+  int comp = 0;
+  while (comp + 1 < jobs.K && (int)blockIdx.x >= jobs.tiles_cum[comp + 1]) ++comp;
+  const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
+  const int tiles_per_shape = (n_end - n_begin + 64 * NB - 1) / (64 * NB);
+  const int local = blockIdx.x - jobs.tiles_cum[comp];
+  const int b = local / tiles_per_shape;
+  const int tile = local - b * tiles_per_shape;
+  const int n_wave0 = n_begin + (tile * 4 + wave) * 16 * NB;
   const int own_nb = q & (NB - 1);
   const int n_own = n_wave0 + 16 * own_nb + i16;
-  const bool own_valid = n_own < N && q < NB;  // q >= NB holds duplicates of quarter q & (NB-1)
-  const bool own_inrange = n_own < N;
+  const bool own_valid = n_own < n_end && q < NB;  // q >= NB holds duplicates of quarter q & (NB-1)
+  const bool own_inrange = n_own < n_end;
+  p += comp * p_stride_k;
+  out += comp * out_stride_k;
+  logdet += comp * out_stride_k;
+  if (LISTS) {
+    const size_t ls = out_stride_k ? (size_t)C * B * 3 * N : 0;
+    ps += comp * ls; mus += comp * ls; lvs += comp * ls;
+  }
+  pw += (size_t)comp * C * K::PW;
+  const int KC = jobs.K * C;     // FiLM records per shape: [b][component][coupling]
 
   // global -> LDS staging of one coupling (LDS-DMA, 1 KiB per wave-instruction): whole pieces of packed
   // weights, then this shape's FiLM record (its last piece is partial)
   auto stage = [&](int buf, int c) {
     const float* src_w = pw + (size_t)c * K::PW + lane * 4;
-    const float* src_f = film + ((size_t)b * C + c) * K::FS + lane * 4;
+    const float* src_f = film + ((size_t)b * KC + (size_t)comp * C + c) * K::FS + lane * 4;
 #pragma unroll
     for (int i = 0; i < (K::PW / 256 + 3) / 4; ++i) {
       const int piece = wave + 4 * i;
@@ -288,18 +311,25 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   }
 }
 
-int g_force_nb = 0;  // test/tuning hooks, see gwtf_debug_set_*
-
 template <int MB, int NB>
 int launch(const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps, float* mus,
-           float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps, hipStream_t st) {
-  const int pts_wg = 4 * 16 * NB;
-  const int tiles = (N + pts_wg - 1) / pts_wg;
-  const dim3 grid((unsigned)(B * tiles)), block(256);
+           float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps, const int* segs, int K,
+           size_t p_stride_k, size_t out_stride_k, hipStream_t st) {
+  Jobs jobs;
+  jobs.K = K;
+  jobs.tiles_cum[0] = 0;
+  for (int k = 0; k < K; ++k) {
+    jobs.begin[k] = segs ? segs[2 * k] : 0;
+    jobs.end[k] = segs ? segs[2 * k + 1] : N;
+    const int cnt = jobs.end[k] - jobs.begin[k];
+    jobs.tiles_cum[k + 1] = jobs.tiles_cum[k] + B * ((cnt + 64 * NB - 1) / (64 * NB));
+  }
+  if (jobs.tiles_cum[K] == 0) return 0;
+  const dim3 grid((unsigned)jobs.tiles_cum[K]), block(256);
   const bool lists = ps != nullptr;
 #define GWTF_LAUNCH(MODE_, LISTS_)                                                                                      \
   hipLaunchKernelGGL((stack_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, \
-                     B, N, C, pattern0, eps, tiles, kk_steps)
+                     B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k)
   if (mode == GWTF_MODE_DIRECT) {
     if (lists) GWTF_LAUNCH(GWTF_MODE_DIRECT, true); else GWTF_LAUNCH(GWTF_MODE_DIRECT, false);
   } else {
@@ -312,42 +342,56 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
 template <int MB>
 int launch_nb(int nb, const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps,
               float* mus, float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps,
-              hipStream_t st) {
+              const int* segs, int K, size_t p_stride_k, size_t out_stride_k, hipStream_t st) {
   switch (nb) {
-    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, st);
-    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, st);
-    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, st);
+    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, st);
+    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, st);
+    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, st);
   }
 }
 
-
+int g_force_nb = 0;  // test/tuning hook, see gwtf_debug_set_points_per_wave
 
 }  // namespace
 
 extern "C" void gwtf_debug_set_points_per_wave(int pts) { g_force_nb = pts / 16; }
 
-extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const float* film, float* out, float* logdet,
-                                  float* ps, float* mus, float* logvars, int B, int N, int C, int f, int pattern0,
-                                  float eps, int mode, void* stream) {
-  if (B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || !p || !packed_w || !film || !out || !logdet)
+extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float* film, float* out,
+                                        float* logdet, float* ps, float* mus, float* logvars, const int* segments,
+                                        int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                                        size_t p_stride_k, size_t out_stride_k, void* stream) {
+  if (B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || K <= 0 || K > GWTF_MAX_COMPONENTS || !p ||
+      !packed_w || !film || !out || !logdet)
     return GWTF_E_BADARG;
   if (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) return GWTF_E_BADARG;
   if (pattern0 < 0 || pattern0 > 5) return GWTF_E_BADARG;
   const bool any = ps || mus || logvars, all = ps && mus && logvars;
   if (any && !all) return GWTF_E_BADARG;
+  long pts = 0;
+  for (int k = 0; k < K; ++k) {
+    const int b0 = segments ? segments[2 * k] : 0, e0 = segments ? segments[2 * k + 1] : N;
+    if (b0 < 0 || e0 < b0 || e0 > N) return GWTF_E_BADARG;
+    pts += (long)B * (e0 - b0);
+  }
   hipStream_t st = (hipStream_t)stream;
   // points per wave: the largest tile that still gives each of the 1024 SIMDs two waves
   int nb = g_force_nb;
-  if (nb != 1 && nb != 2 && nb != 4) {
-    const long pts = (long)B * N;
-    nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
-  }
+  if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
   const int kk_steps = (f + 3) / 4;
+#define GWTF_ARGS nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, segments, K, p_stride_k, out_stride_k, st
   switch (gwtf_padded_width(f) / 16) {
-    case 1: return launch_nb<1>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
-    case 2: return launch_nb<2>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
-    case 3: return launch_nb<3>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
-    case 4: return launch_nb<4>(nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, st);
+    case 1: return launch_nb<1>(GWTF_ARGS);
+    case 2: return launch_nb<2>(GWTF_ARGS);
+    case 3: return launch_nb<3>(GWTF_ARGS);
+    case 4: return launch_nb<4>(GWTF_ARGS);
     default: return GWTF_E_BADARG;
   }
+#undef GWTF_ARGS
+}
+
+extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const float* film, float* out, float* logdet,
+                                  float* ps, float* mus, float* logvars, int B, int N, int C, int f, int pattern0,
+                                  float eps, int mode, void* stream) {
+  return gwtf_stack_forward_multi(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, 1, B, N, C, f, pattern0, eps,
+                                  mode, 0, 0, stream);
 }

@@ -42,3 +42,8 @@ class LocalCondRNVPDecoder(nn.Module):
         """-> (out, logdet): ``out`` = ps[0] (inverse) / ps[-1] (direct); ``logdet`` = sum_j logvars[j], (B,3,N)."""
         out, logdet, _ = self.engine().run(p, g, mode, False)
         return out, logdet
+
+    def capture(self, p, g, mode='inverse', want_lists=False):
+        """hipGraph-captured ``forward_fused`` bound to the storage of ``p`` and ``g``; see ``StackEngine.capture``.
+        ``replay()`` returns ``[(out, logdet, lists)]``."""
+        return self.engine().capture(p, g, mode, want_lists)

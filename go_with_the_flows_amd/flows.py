@@ -241,6 +241,55 @@ class StackEngine:
             lists = res[2] if want_lists else None
         return out, logdet, lists
 
+    def capture(self, p, g, mode, want_lists=False):
+        """hipGraph capture of (FiLM + fused stack) on the CURRENT packed weights and on the storage of ``p``/``g``.
+
+        Returns a ``GraphedStack``: ``replay()`` re-runs both kernels with one graph launch and returns the SAME
+        output tensors every time (static buffers: consume them before the next replay; refill ``p``/``g`` in
+        place to change inputs).  Eval mode only; re-capture after any parameter change."""
+        if mode not in ('direct', 'inverse'):
+            raise ValueError(f"mode must be 'direct' or 'inverse', got {mode!r}")
+        self._check(p, g)
+        if self.couplings[0].training:
+            raise NotImplementedError('graph capture is an inference feature: call .eval() first')
+        if not (p.is_contiguous() and g.is_contiguous() and p.dtype == torch.float32 and g.dtype == torch.float32):
+            raise ValueError('capture needs contiguous float32 p and g (their storage is baked into the graph)')
+        return GraphedStack([self], p, g, mode, want_lists)
+
     def run_lists(self, p, g, mode):
         _, _, lists = self.run(p, g, mode, True)
         return list(lists[0].unbind(0)), list(lists[1].unbind(0)), list(lists[2].unbind(0))
+
+
+class GraphedStack:
+    """One hipGraph holding the FiLM + stack launches of one or more engines (e.g. the K mixture components)
+    that read the same ``p``/``g`` storage.  Removes the per-launch host work (Python, ctypes, allocator) from
+    the step: two kernels of 10-200 us each are otherwise host-bound on small batches."""
+
+    def __init__(self, engines, p, g, mode, want_lists=False, per_engine_p=None):
+        self.engines = list(engines)
+        self.p, self.g, self.mode = p, g, mode
+        packs = [e.packed(False) for e in self.engines]
+        eps = self.engines[0].couplings[0]._eps_value
+        ps = per_engine_p if per_engine_p is not None else [p] * len(self.engines)
+
+        def body():
+            res = []
+            for e, (pw, pf), pk in zip(self.engines, packs, ps):
+                film = _lib.film_forward(g, pf, e.C, e.f, eps, False)
+                res.append(_lib.stack_forward(pk, pw, film, e.C, e.f, e.pattern0, eps, mode, want_lists))
+            return res
+
+        side = torch.cuda.Stream(device=p.device)
+        side.wait_stream(torch.cuda.current_stream(p.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            body()                                   # warm-up outside capture (lazy module loading etc.)
+        torch.cuda.current_stream(p.device).wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.results = body()
+        self._keepalive = packs
+
+    def replay(self):
+        self.graph.replay()
+        return self.results

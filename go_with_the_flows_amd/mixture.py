@@ -1,0 +1,74 @@
+"""K flow components as one launch + the fused mixture NLL.
+
+The reference loops over ``self.pc_decoder[i]`` in Python (lib/networks/flow_mixture.py:163-166: K sequential
+decoders on the SAME points when training; the N points split among the components by a multinomial draw when
+sampling, :146-177) and then over B x K in ``FlowMixtureNLL`` (lib/networks/losses.py:109-131).  Here the K
+components' packed weights are concatenated, one FiLM launch covers all K*C couplings, one stack launch covers
+all components, and one reduction kernel produces the per-shape NLL.
+"""
+import torch
+
+from . import _lib
+
+
+class MixtureStack:
+    """Batched driver for an ``nn.ModuleList`` of ``LocalCondRNVPDecoder`` with identical (n_flows, f, G)."""
+
+    def __init__(self, decoders):
+        self.decoders = list(decoders)
+        self.engines = [d.engine() for d in self.decoders]
+        e0 = self.engines[0]
+        if any((e.C, e.f, e.G, e.pattern0) != (e0.C, e0.f, e0.G, e0.pattern0) for e in self.engines):
+            raise ValueError('all mixture components must share n_flows, f_n_features and g_n_features')
+        self.K, self.C, self.f, self.G = len(self.engines), e0.C, e0.f, e0.G
+        self._cat_key, self._cat = None, None
+
+    def packed(self):
+        packs = [e.packed(False) for e in self.engines]
+        key = tuple(id(pk[0]) for pk in packs)
+        if key != self._cat_key:
+            self._cat = (torch.cat([pk[0] for pk in packs]), torch.cat([pk[1] for pk in packs]))
+            self._cat_key, self._keep = key, packs
+        return self._cat
+
+    def _film(self, g):
+        pw, pf = self.packed()
+        eps = self.engines[0].couplings[0]._eps_value
+        return pw, _lib.film_forward(g, pf, self.K * self.C, self.f, eps, False), eps
+
+    def forward_all(self, p, g, mode='inverse'):
+        """Every component on every point -> (out, logdet), each (K,B,3,N).  Training / density path."""
+        e0 = self.engines[0]
+        if e0.couplings[0].training:
+            raise NotImplementedError('train-mode BatchNorm HIP path is not built yet; call .eval()')
+        e0._check(p, g)
+        pw, film, eps = self._film(g.contiguous().float())
+        return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode)
+
+    def forward_partition(self, p, g, counts, mode='direct'):
+        """Sampling path: the N points are laid out component by component, ``counts[k]`` points for component k
+        (sum == N); each point goes through ONE component.  -> (out, logdet), each (B,3,N)."""
+        e0 = self.engines[0]
+        if e0.couplings[0].training:
+            raise NotImplementedError('train-mode BatchNorm HIP path is not built yet; call .eval()')
+        e0._check(p, g)
+        if len(counts) != self.K or sum(int(c) for c in counts) != p.shape[2]:
+            raise ValueError('counts must have K entries summing to N')
+        segs, off = [], 0
+        for cnt in counts:
+            segs.append((off, off + int(cnt)))
+            off += int(cnt)
+        pw, film, eps = self._film(g.contiguous().float())
+        return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode,
+                                        segments=segs, shared_points=False)
+
+
+def flow_mixture_nll(z, logdet, mu0, lv0, logits, want_point_lse=False):
+    """FlowMixtureNLL on fused decoder outputs (reference losses.py:88-137).
+
+    z, logdet (K,B,3,N): final inverse coordinates / sum of coupling logvars per component;
+    mu0, lv0 (K,B,3): base Gaussians; logits (B,K).  -> (pnll scalar = batch mean, per-shape (B,) [, per-point lse])."""
+    res = _lib.mixture_nll(z.contiguous(), logdet.contiguous(), mu0.contiguous().float(), lv0.contiguous().float(),
+                           logits.contiguous().float(), want_point_lse)
+    nll = res[0] if want_point_lse else res
+    return (nll.mean(), nll, res[1]) if want_point_lse else (nll.mean(), nll)

@@ -77,6 +77,21 @@ int gwtf_stack_forward(const float* p, const float* packed_w, const float* film,
                        float* out, float* logdet, float* ps, float* mus, float* logvars,
                        int B, int N, int C, int f, int pattern0, float eps, int mode, void* stream);
 
+/* K flow components in ONE launch (the loop over `self.pc_decoder[i]` in Flow_Mixture_Model.decode,
+ * lib/networks/flow_mixture.py:163-166).  Component k applies its own C-coupling stack to the points
+ * [segments[2k], segments[2k+1]) of every shape (segments == NULL: every component takes all N points).
+ *   packed_w [K][C][...]            the K components' packed weights, concatenated
+ *   film     [B][K*C][...]          gwtf_film_forward run once on the concatenated FiLM weights with C' = K*C
+ *   p        base + k*p_stride_k    (floats; 0: all components read the same clouds)
+ *   out, logdet base + k*out_stride_k  (floats; B*3*N for the density path -> [K][B][3][N], the layout
+ *                                   gwtf_mixture_nll reads; 0 for the sampling path where the segments partition N)
+ *   ps, mus, logvars                optional lists, [K][C][B][3][N] when out_stride_k != 0 else [C][B][3][N]
+ *   segments                        HOST array of 2K ints, or NULL;  K <= 64 */
+int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float* film,
+                             float* out, float* logdet, float* ps, float* mus, float* logvars,
+                             const int* segments, int K, int B, int N, int C, int f, int pattern0, float eps,
+                             int mode, size_t p_stride_k, size_t out_stride_k, void* stream);
+
 /* Mixture negative log-likelihood over K flow components.
  * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
  * PointFlowNLL, :11-20).

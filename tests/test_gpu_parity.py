@@ -228,3 +228,58 @@ def test_g7_caller_semantics_end_to_end():
     assert maxabs(host(z), D['z']) < TOL_COORD and maxabs(host(ld), D['logdet']) < TOL_LOGDET
     nll = _lib.mixture_nll(z, ld, dev(D['mu0']), dev(D['lv0']), dev(D['logits']))
     assert abs(float(host(nll).mean()) - float(D['pnll'])) / abs(float(D['pnll'])) < TOL_NLL_REL
+
+
+def test_graph_capture_replay_matches_eager():
+    L, f, G, B, N = 2, 33, 16, 3, 200
+    m, st = decoder_and_state(L, f, G, 55)
+    m = m.to(DEV).eval()
+    p, g = synth_inputs(B, N, G, 56)
+    pd, gd = dev(p), dev(g)
+    with torch.no_grad():
+        ref_out, ref_ld = m.forward_fused(pd, gd, 'inverse')
+    graphed = m.capture(pd, gd, 'inverse')
+    (out, ld, _), = graphed.replay()
+    assert torch.equal(out, ref_out) and torch.equal(ld, ref_ld)
+    p2, g2 = synth_inputs(B, N, G, 57)
+    pd.copy_(dev(p2)), gd.copy_(dev(g2))                 # new inputs in place, same graph
+    (out2, ld2, _), = graphed.replay()
+    o_ref, l_ref = fo.decoder_fused(p2, g2, st, L, 'inverse')
+    assert maxabs(host(out2), o_ref) < TOL_COORD and maxabs(host(ld2), l_ref) < TOL_LOGDET
+
+
+def test_mixture_batched_launch_matches_per_component():
+    """K components in one launch == K separate launches, bit for bit; NLL of the batched outputs == golden."""
+    D = golden('g5_losses')
+    L, f, G, B, N, K = D['dims']
+    decs = [decoder_and_state(L, f, G, 510 + k)[0].to(DEV).eval() for k in range(K)]
+    ms = gw.MixtureStack(decs)
+    pd, gd = dev(D['p']), dev(D['g'])
+    with torch.no_grad():
+        z, ld = ms.forward_all(pd, gd, 'inverse')
+        for k in range(K):
+            zk, ldk = decs[k].forward_fused(pd, gd, 'inverse')
+            assert torch.equal(z[k], zk) and torch.equal(ld[k], ldk)
+    assert maxabs(host(z), D['z']) < TOL_COORD and maxabs(host(ld), D['logdet']) < TOL_LOGDET
+    pnll, per_shape = gw.flow_mixture_nll(z, ld, dev(D['mu0']), dev(D['lv0']), dev(D['logits']))
+    assert abs(float(pnll) - float(D['mixture_nll'])) / abs(float(D['mixture_nll'])) < TOL_NLL_REL
+
+
+@pytest.mark.parametrize('counts', [[10, 0, 7, 15], [32, 0, 0, 0], [1, 1, 1, 29], [8, 8, 8, 8]])
+def test_mixture_partitioned_sampling_path(counts):
+    """Sampling semantics (reference flow_mixture.py:146-177): each point goes through ONE component."""
+    D = golden('g5_losses')
+    L, f, G, B, N, K = D['dims']
+    pairs = [decoder_and_state(L, f, G, 510 + k) for k in range(K)]
+    decs = [m.to(DEV).eval() for m, _ in pairs]
+    ms = gw.MixtureStack(decs)
+    zin, g = synth_inputs(B, N, G, 99)
+    with torch.no_grad():
+        x, ld = ms.forward_partition(dev(zin), dev(g), counts, 'direct')
+    off = 0
+    for k, cnt in enumerate(counts):
+        if cnt:
+            ref_x, ref_ld = fo.decoder_fused(zin[:, :, off:off + cnt], g, pairs[k][1], L, 'direct')
+            assert maxabs(host(x)[:, :, off:off + cnt], ref_x) < TOL_COORD
+            assert maxabs(host(ld)[:, :, off:off + cnt], ref_ld) < TOL_LOGDET
+        off += cnt
