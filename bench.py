@@ -42,6 +42,7 @@ WORKLOADS = {
                 name='configs[3] K=16 mixture sampling, batched: each point visits one of 16 flows, 18 couplings, f=19'),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (= fp32 vector peak)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak; the contraction runs as 3 f16 products per fp32 product
 
 
 def flops_per_point(L, f):
@@ -231,6 +232,10 @@ def main():
                        'launch': ('eager: ' if args.eager else 'one hipGraph replay per step: ') + '1 FiLM + 1 stack launch for all components'},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
+                         'peak_split_f16': round(MFMA_F16_PEAK_TFLOPS / 3, 1),
+                         'frac_split_f16': round(achieved / (MFMA_F16_PEAK_TFLOPS / 3), 4),
+                         'note': 'fp32 result; sd1 contraction = 3 f16 MFMA products of hi/lo-split operands, fp32 '
+                                 'accumulate (fp32-grade accuracy), so frac vs the fp32 MFMA peak can exceed 1',
                          'kernel': 'stack_kernel (fused coupling stack)', 'kernel_ms': round(kern_ms, 4),
                          'flop_per_point': flops_per_point(L, f), 'points_per_launch': pts_per_launch},
         }

@@ -1,0 +1,45 @@
+"""One-process-per-GPU plumbing: batch-of-shapes sharding and the barrier/max timing used by bench.py.
+
+The path needs no data exchange in the forward direction (every shape is independent given g): ranks own
+disjoint slices of the batch, exactly as the reference shards it (DistributedSampler + per-rank batch
+``B // world`` with the remainder on the low ranks, train_ae.py:77-78,100-109).  Backend 'nccl' is RCCL on
+ROCm; 'gloo' is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_shapes, rank, world):
+    """[begin, end) of the shapes rank owns: B//world each, +1 for the first B % world ranks (train_ae.py:77-78)."""
+    base, rem = divmod(n_shapes, world)
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None, device=None):
+    """init_process_group from torchrun's env (RANK/WORLD_SIZE/MASTER_*); returns (rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = backend or ('nccl' if torch.cuda.is_available() else 'gloo')
+        kw = {'device_id': device} if (backend == 'nccl' and device is not None) else {}
+        dist.init_process_group(backend, **kw)
+    return rank, world
+
+
+def max_over_ranks(value, device='cpu'):
+    """MAX-all-reduce of a python float (bench timing contract)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(t):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t

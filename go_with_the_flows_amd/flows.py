@@ -208,14 +208,14 @@ class StackEngine:
         return self._packed
 
     def _check(self, p, g):
-        dev = self.couplings[0].eps.device
-        if dev.type != 'cuda':
-            raise _lib.GwtfError('module parameters are on the CPU: move the module to a HIP device (.cuda()); '
-                                 'go_with_the_flows_amd has no CPU path')
         if p.dim() != 3 or p.shape[1] != 3:
             raise ValueError(f'p must be (B,3,N), got {tuple(p.shape)}')
         if g.dim() != 2 or g.shape[0] != p.shape[0] or g.shape[1] != self.G:
             raise ValueError(f'g must be ({p.shape[0]},{self.G}), got {tuple(g.shape)}')
+        dev = self.couplings[0].eps.device
+        if dev.type != 'cuda':
+            raise _lib.GwtfError('module parameters are on the CPU: move the module to a HIP device (.cuda()); '
+                                 'go_with_the_flows_amd has no CPU path')
         if p.device != dev or g.device != dev:
             raise _lib.GwtfError(f'p ({p.device}) / g ({g.device}) must be on the module device {dev}')
 
