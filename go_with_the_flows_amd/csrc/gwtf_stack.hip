@@ -46,10 +46,16 @@ struct Cfg {
 
 __device__ __forceinline__ float sel3(float a, float b, float c, int d) { return d == 0 ? a : (d == 1 ? b : c); }
 
-// x = hi + lo with both parts rounded to nearest f16 (|lo| <= 2^-12 |x|): 1 + 2 + 2 + 1 VALU for two values
-__device__ __forceinline__ void split_pair(float h0, float h1, f16x2& hi, f16x2& lo) {
-  hi = f16x2{(_Float16)h0, (_Float16)h1};
-  lo = f16x2{(_Float16)(h0 - (float)hi[0]), (_Float16)(h1 - (float)hi[1])};
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo with both parts rounded to nearest f16 (|lo| <= 2^-12 |x|): v_cvt_pk_f16_f32, two mixed-precision
+// FMAs (h - float(hi), the f16 operand converted inside v_fma_mix_f32), v_cvt_pk_f16_f32: 4 VALU for two values
+__device__ __forceinline__ void split_pair(f32x2 h, f16x2& hi, f16x2& lo) {
+  hi = __builtin_convertvector(h, f16x2);
+  f32x2 r;
+  r[0] = __builtin_fmaf((float)hi[0], -1.0f, h[0]);
+  r[1] = __builtin_fmaf((float)hi[1], -1.0f, h[1]);
+  lo = __builtin_convertvector(r, f16x2);
 }
 
 // Sum the per-quarter partials o[nb] over the four 16-lane quarters so that the lane in quarter q ends
@@ -99,13 +105,9 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
 #pragma unroll
   for (int br = 0; br < 2; ++br) {
     const float* fe = L + K::PW + br * 3 * FP + 4 * q;   // c | w20a | w21a, this lane's 4 features per block
-    f32x4 acc[MB][NB];
+    f32x4 acc[MB][NB], cinit[MB];   // accumulators start at c: it is the C operand of the first MFMA (no copies)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      const f32x4 c4 = *reinterpret_cast<const f32x4*>(fe + 16 * m);
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) acc[m][nb] = c4;
-    }
+    for (int m = 0; m < MB; ++m) cinit[m] = *reinterpret_cast<const f32x4*>(fe + 16 * m);
     const float* aimg = L + br * K::A16 + lane * 4;
     const float* sd0 = L + 2 * K::A16 + br * K::SD0 + q * 24;
 #pragma unroll
@@ -119,18 +121,20 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
 #pragma unroll
       for (int jp = 0; jp < 4; ++jp) {
         if (ks + 1 < KS || 2 * jp < nj_last) {     // wave-uniform: skip k positions beyond ceil(f/4)
+          // two k positions at a time: packed fp32 FMAs (v_pk_fma_f32: 6 cycles for two FMAs instead of 8)
+          const int j0 = 2 * jp;
+          const f32x2 wa2 = {wa[j0 >> 2][j0 & 3], wa[j0 >> 2][(j0 & 3) + 1]};
+          const f32x2 wb2 = {wb[j0 >> 2][j0 & 3], wb[j0 >> 2][(j0 & 3) + 1]};
+          const f32x2 cc2 = {cc[j0 >> 2][j0 & 3], cc[j0 >> 2][(j0 & 3) + 1]};
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
-            float h[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              const int j = 2 * jp + t;
-              const float pre = KEEP2 ? fmaf(wa[j >> 2][j & 3], xa[nb], fmaf(wb[j >> 2][j & 3], xb[nb], cc[j >> 2][j & 3]))
-                                      : fmaf(wa[j >> 2][j & 3], xa[nb], cc[j >> 2][j & 3]);
-              h[t] = fmaxf(pre, 0.f);
-            }
+            const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
+            f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
+                              : __builtin_elementwise_fma(wa2, xa2, cc2);
+            pre[0] = fmaxf(pre[0], 0.f);
+            pre[1] = fmaxf(pre[1], 0.f);
             f16x2 hi, lo;
-            split_pair(h[0], h[1], hi, lo);
+            split_pair(pre, hi, lo);
             bhi[nb][2 * jp] = hi[0]; bhi[nb][2 * jp + 1] = hi[1];
             blo[nb][2 * jp] = lo[0]; blo[nb][2 * jp + 1] = lo[1];
           }
@@ -148,7 +152,7 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
         const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 1) * 256);
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[nb], acc[m][nb], 0, 0, 0);
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[nb], ks == 0 ? cinit[m] : acc[m][nb], 0, 0, 0);
           acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[nb], acc[m][nb], 0, 0, 0);
           acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[nb], acc[m][nb], 0, 0, 0);
         }
