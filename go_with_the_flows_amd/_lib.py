@@ -30,6 +30,11 @@ _SIGNATURES = {
     'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stack_forward_multi': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
                                  [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_fp]),
+    'gwtf_train_moments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_fold0': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_stats': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_fold1': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, _c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
+    'gwtf_train_apply': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
 }
@@ -99,9 +104,13 @@ def pack_weights(raw, C, f, G, training):
 
 
 def film_forward(g, packed_film, C, f, eps, training, want_stats=False):
+    """eval: the (B,C,6FP+4) record the stack kernel consumes.  training: RAW FiLM {a,b} as (B,C,2,2,FP)."""
     L = lib()
     B, G = g.shape
-    out = torch.empty(B, C, L.gwtf_film_out_floats(f), device=g.device, dtype=torch.float32)
+    if training:
+        out = torch.empty(B, C, 2, 2, L.gwtf_padded_width(f), device=g.device, dtype=torch.float32)
+    else:
+        out = torch.empty(B, C, L.gwtf_film_out_floats(f), device=g.device, dtype=torch.float32)
     stats = torch.empty(C, 2, 2, 2, f, device=g.device, dtype=torch.float32) if (training and want_stats) else None
     with torch.cuda.device(g.device):
         check(L.gwtf_film_forward(_ptr(g, 'g'), _ptr(packed_film, 'packed_film'), _ptr(out, 'film_out'),
@@ -168,3 +177,63 @@ def mixture_nll(z, logdet, mu0, lv0, logits, want_point_lse=False):
                                  _ptr(logits, 'logits'), _ptr(plse, 'point_lse'), _ptr(nll, 'nll_shape'), K, B, N,
                                  _stream(z)))
     return (nll, plse) if want_point_lse else nll
+
+
+def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum=None, g_all=None, row0=0):
+    """Train-mode (batch-statistic BatchNorm) forward of a coupling stack: fold0 -> stats -> fold1 -> apply per
+    coupling (csrc/gwtf_train.hip).  ``group_sum`` (optional callable) sums small statistic tensors in place over
+    the ranks of a data-parallel group (SyncBatchNorm semantics); ``g_all``/``row0``: the latents of ALL ranks and
+    this rank's first row, so the per-shape FiLM BatchNorm sees the global batch.
+    Returns out, logdet, lists, bn_batch (C,2,4,2,f) = {batch mean, unbiased batch var} of the 8 BatchNorms per
+    coupling (kind 0 sd0_bn, 1 sd1_bn, 2 film_w0_bn, 3 film_b0_bn; branch 0 logvar, 1 mu)."""
+    L = lib()
+    B, _, N = p.shape
+    dev = p.device
+    FP = L.gwtf_padded_width(f)
+    R, PW, FS = L.gwtf_raw_coupling_floats(f, G), L.gwtf_packed_w_coupling_floats(f), L.gwtf_film_out_floats(f)
+    st = _stream(p)
+    gfull = g if g_all is None else g_all
+    Bg = gfull.shape[0]
+    if Bg < 2:
+        raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
+    with torch.cuda.device(dev):
+        pw, pf = pack_weights(raw, C, f, G, True)
+        film_all, fstats = film_forward(gfull, pf, C, f, eps, True, want_stats=True)
+        film_raw = film_all[row0:row0 + B].contiguous()
+        mom = torch.zeros(C + 1, 16, device=dev, dtype=torch.float32)
+        ystats = torch.zeros(C, 2 * FP * 2, device=dev, dtype=torch.float32)
+        bn_batch = torch.zeros(C, 2, 4, 2, f, device=dev, dtype=torch.float32)
+        film_rec = torch.empty(B, C, FS, device=dev, dtype=torch.float32)
+        bufs = [torch.empty_like(p), torch.empty_like(p)]
+        logdet = torch.empty_like(p)
+        lists = torch.empty(3, C, B, 3, N, device=dev, dtype=torch.float32) if want_lists else None
+        lp = [lists[i].data_ptr() for i in range(3)] if want_lists else [None, None, None]
+        n_total = torch.tensor([float(B) * N], device=dev, dtype=torch.float64)
+        if group_sum is not None:
+            group_sum(n_total)
+        n_total = float(n_total.item())
+        check(L.gwtf_train_moments(_ptr(p, 'p'), mom[0].data_ptr(), B, N, st))
+        order = range(C) if mode == 'direct' else range(C - 1, -1, -1)
+        cur = p
+        for step, c in enumerate(order):
+            pat = (pattern0 + c) % 6
+            if group_sum is not None:
+                group_sum(mom[step])
+            raw_c, pw_c = raw[c * R:(c + 1) * R], pw[c * PW:(c + 1) * PW]
+            check(L.gwtf_train_fold0(raw_c.data_ptr(), mom[step].data_ptr(), n_total, pat, pw_c.data_ptr(),
+                                     bn_batch[c].data_ptr(), f, G, st))
+            check(L.gwtf_train_stats(cur.data_ptr(), pw_c.data_ptr(), ystats[c].data_ptr(), B, N, f, pat, st))
+            if group_sum is not None:
+                group_sum(ystats[c])
+            check(L.gwtf_train_fold1(raw_c.data_ptr(), ystats[c].data_ptr(), n_total, film_raw.data_ptr(),
+                                     film_rec.data_ptr(), bn_batch[c].data_ptr(), c, B, C, f, G, st))
+            nxt = bufs[step & 1]
+            check(L.gwtf_train_apply(cur.data_ptr(), pw.data_ptr(), film_rec.data_ptr(), nxt.data_ptr(),
+                                     logdet.data_ptr() if step > 0 else None, logdet.data_ptr(), lp[0], lp[1], lp[2],
+                                     mom[step + 1].data_ptr() if step + 1 < C else None, c, B, N, C, f, pattern0,
+                                     float(eps), _MODES[mode], st))
+            cur = nxt
+        # per-shape FiLM BatchNorms: biased batch var -> unbiased
+        bn_batch[:, :, 2:4, 0, :] = fstats[:, :, :, 0, :]
+        bn_batch[:, :, 2:4, 1, :] = fstats[:, :, :, 1, :] * (Bg / (Bg - 1.0))
+    return cur, logdet, lists, bn_batch

@@ -69,18 +69,25 @@ __global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ g, 
       for (int r = 0; r < kR; ++r) {
         const int b = b0 + wave * kR + r;
         if (b < B) {
-          float cv = 0.f, u0 = 0.f, u1 = 0.f;
-          if (lane < f) {
-            const float a = eps + expf(acc[0][r]);
-            cv = c1 + acc[1][r] / a;
-            u0 = w20 * a;
-            u1 = w21 * a;
+          if (TRAIN) {
+            // raw FiLM scale / shift: sd1_bn's batch statistics are not known yet (gwtf_train_fold1 combines them)
+            float* ob = out + ((((size_t)b * C + c) * 2 + br) * 2) * FP + lane;
+            ob[0] = lane < f ? eps + expf(acc[0][r]) : 1.f;
+            ob[FP] = lane < f ? acc[1][r] : 0.f;
+          } else {
+            float cv = 0.f, u0 = 0.f, u1 = 0.f;
+            if (lane < f) {
+              const float a = eps + expf(acc[0][r]);
+              cv = c1 + acc[1][r] / a;
+              u0 = w20 * a;
+              u1 = w21 * a;
+            }
+            float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + lane;
+            ob[0] = cv;
+            ob[FP] = u0;
+            ob[2 * FP] = u1;
+            if (lane < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + lane] = w[P.b2() + lane];
           }
-          float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + lane;
-          ob[0] = cv;
-          ob[FP] = u0;
-          ob[2 * FP] = u1;
-          if (lane < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + lane] = w[P.b2() + lane];
         }
       }
     }

@@ -12,7 +12,8 @@ namespace {
 __device__ __forceinline__ float inv_std(float var) { return 1.0f / sqrtf(var + GWTF_BN_EPS); }
 
 // packed stack weights (split-f16 fragment images + sd0 parameters), see gwtf_layout.h
-__global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__ out, int C, int f, int G, int FP) {
+__global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__ out, int C, int f, int G, int FP,
+                              int training) {
   const GwtfRaw R(f, G);
   const GwtfPackW P(FP);
   const size_t per = P.coupling_size();
@@ -35,7 +36,7 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__
       const int jo = 16 * m + (lane & 15);  // output feature (row of sd1.weight)
       __half2 pk = __floats2half2_rn(0.f, 0.f);
       if (ks < KS && jo < f) {
-        const float sc = inv_std(rb[R.bn1() + f + jo]);
+        const float sc = training ? 1.0f : inv_std(rb[R.bn1() + f + jo]);   // train: sd1_bn is applied via fold1
         float e[2];
         for (int t = 0; t < 2; ++t) {
           const int ji = 32 * ks + 4 * (2 * jp + t) + (lane >> 4);  // input feature
@@ -53,7 +54,7 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__
       const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
       const int j = (int)(o % 8), e = (int)((o / 8) % 3), q = (int)((o / 24) % 4), ks = (int)(o / 96);
       const int ft = 32 * ks + 4 * j + q;
-      if (ft < f) {
+      if (ft < f && !training) {   // train: written per coupling by gwtf_train_fold0
         const float* bn = rb + R.bn0();
         const float s = bn[ft] * inv_std(bn[3 * f + ft]);
         v = e < 2 ? rb[R.sd0_w() + 2 * ft + e] * s : bn[f + ft] - bn[2 * f + ft] * s;
@@ -120,7 +121,7 @@ extern "C" int gwtf_pack_weights(const float* raw, float* packed_w, float* packe
   {
     const size_t total = GwtfPackW(FP).coupling_size() * (size_t)C;
     const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
-    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_w, C, f, G, FP);
+    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_w, C, f, G, FP, training);
   }
   {
     const size_t total = GwtfPackF(FP, G).coupling_size() * (size_t)C;

@@ -79,35 +79,15 @@ __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
   }
 }
 
-// One elementary coupling on the wave's tile.  KEEP2 = two kept coordinates / one warped (patterns 0-2),
-// otherwise one kept / two warped (patterns 3-5).  Every VALU instruction here costs the SIMD 4 cycles that
-// the matrix pipe cannot use (measured: MFMA and VALU of two waves on one SIMD do not overlap,
-// tools/diag/coissue.hip), so the body is specialised to issue as few as possible:
-//   - the f x f contraction runs at the f16 matrix rate on split operands (gwtf_layout.h): 3 MFMAs of 16 cycles
-//     per 16x16x32 block instead of 8 fp32 MFMAs of 32 cycles, at fp32-grade accuracy;
-//   - the accumulators start at c = b'/a (FiLM shift over FiLM scale, a > 0) instead of zero, so
-//     relu(a*y + b') * W2  becomes  relu(acc) * (W2*a): one v_max + one v_fma per warped coordinate;
-//   - the second sd0 input / second sd2 output only exist in the variant that needs them.
-template <int MB, int NB, int MODE, bool KEEP2>
-__device__ __forceinline__ void coupling_body(const float* __restrict__ L, int kk_steps, int lane, int q, int k0, int k1,
-                                              int w0, int w1, float eps, float s_keep, const float (&x)[NB][3],
-                                              float (&xo)[3], float (&mu_d)[3], float (&lv_d)[3]) {
+// sd0 (+ folded sd0_bn) + ReLU + f16 split in the lane that owns each MFMA k-slot, then the f x f contraction
+// acc[m][nb] = cinit[m] + W1'[16m.., :] . h0[:, points of block nb] on v_mfma_f32_16x16x32_f16 (3 products).
+template <int MB, int NB, bool KEEP2>
+__device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br, int kk_steps, int lane, int q,
+                                             const float (&xa)[NB], const float (&xb)[NB], const f32x4 (&cinit)[MB],
+                                             f32x4 (&acc)[MB][NB]) {
   using K = Cfg<MB>;
-  constexpr int FP = K::FP, KS = K::KS;
-  float xa[NB], xb[NB];
-#pragma unroll
-  for (int nb = 0; nb < NB; ++nb) {
-    xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
-    xb[nb] = KEEP2 ? sel3(x[nb][0], x[nb][1], x[nb][2], k1) : 0.f;
-  }
+  constexpr int KS = K::KS;
   const int nj_last = kk_steps - 8 * (KS - 1);   // valid k positions per lane in the last k-step (1..8)
-  float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};    // [branch][warped slot] for this lane's own point
-#pragma unroll
-  for (int br = 0; br < 2; ++br) {
-    const float* fe = L + K::PW + br * 3 * FP + 4 * q;   // c | w20a | w21a, this lane's 4 features per block
-    f32x4 acc[MB][NB], cinit[MB];   // accumulators start at c: it is the C operand of the first MFMA (no copies)
-#pragma unroll
-    for (int m = 0; m < MB; ++m) cinit[m] = *reinterpret_cast<const f32x4*>(fe + 16 * m);
     const float* aimg = L + br * K::A16 + lane * 4;
     const float* sd0 = L + 2 * K::A16 + br * K::SD0 + q * 24;
 #pragma unroll
@@ -158,6 +138,37 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
         }
       }
     }
+}
+
+// One elementary coupling on the wave's tile.  KEEP2 = two kept coordinates / one warped (patterns 0-2),
+// otherwise one kept / two warped (patterns 3-5).  Every VALU instruction here costs the SIMD 4 cycles that
+// the matrix pipe cannot use (measured: MFMA and VALU of two waves on one SIMD do not overlap,
+// tools/diag/coissue.hip), so the body is specialised to issue as few as possible:
+//   - the f x f contraction runs at the f16 matrix rate on split operands (gwtf_layout.h): 3 MFMAs of 16 cycles
+//     per 16x16x32 block instead of 8 fp32 MFMAs of 32 cycles, at fp32-grade accuracy;
+//   - the accumulators start at c = b'/a (FiLM shift over FiLM scale, a > 0) instead of zero, so
+//     relu(a*y + b') * W2  becomes  relu(acc) * (W2*a): one v_max + one v_fma per warped coordinate;
+//   - the second sd0 input / second sd2 output only exist in the variant that needs them.
+template <int MB, int NB, int MODE, bool KEEP2>
+__device__ __forceinline__ void coupling_body(const float* __restrict__ L, int kk_steps, int lane, int q, int k0, int k1,
+                                              int w0, int w1, float eps, float s_keep, const float (&x)[NB][3],
+                                              float (&xo)[3], float (&mu_d)[3], float (&lv_d)[3]) {
+  using K = Cfg<MB>;
+  constexpr int FP = K::FP;
+  float xa[NB], xb[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
+    xb[nb] = KEEP2 ? sel3(x[nb][0], x[nb][1], x[nb][2], k1) : 0.f;
+  }
+  float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};    // [branch][warped slot] for this lane's own point
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    const float* fe = L + K::PW + br * 3 * FP + 4 * q;   // c | w20a | w21a, this lane's 4 features per block
+    f32x4 acc[MB][NB], cinit[MB];   // accumulators start at c: it is the C operand of the first MFMA (no copies)
+#pragma unroll
+    for (int m = 0; m < MB; ++m) cinit[m] = *reinterpret_cast<const f32x4*>(fe + 16 * m);
+    sd1_contract<MB, NB, KEEP2>(L, br, kk_steps, lane, q, xa, xb, cinit, acc);
     // ReLU + sd2 on the accumulators (FiLM already folded in)
     float o0[NB], o1[NB];
 #pragma unroll
@@ -205,6 +216,83 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
 
 // Work list of one launch: component k applies ITS stack to points [begin[k], end[k]) of every shape.
 // Passed by value in the kernel arguments (wave-uniform, scalar loads).
+// Train-mode statistics pass of ONE coupling: per-feature sum and sum of squares of y1 = sd1(relu(sd0_bn(sd0(x))))
+// over all points, both branches (input of sd1_bn's batch statistics, reference flows.py:30,65 in train()).
+// Same tile decomposition and contraction as the forward kernel; the accumulators are reduced over the wave's
+// points (in-lane over the NB blocks, shuffles over the 16 lanes of a quarter) and added to ystats with one
+// atomic per feature and wave.   ystats: [2 branches][FP][2] = {sum y, sum y^2}
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p, const float* __restrict__ pw_c,
+                                                    float* __restrict__ ystats, int B, int N, int pat, int kk_steps) {
+  using K = Cfg<MB>;
+  constexpr int FP = K::FP;
+  __shared__ __align__(16) float lds[K::PW];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int tiles_per_shape = (N + 64 * NB - 1) / (64 * NB);
+  const int b = blockIdx.x / tiles_per_shape;
+  const int tile = blockIdx.x - b * tiles_per_shape;
+  const int n_wave0 = (tile * 4 + wave) * 16 * NB;
+#pragma unroll
+  for (int i = 0; i < (K::PW / 256 + 3) / 4; ++i) {
+    const int piece = wave + 4 * i;
+    if (piece < K::PW / 256)
+      __builtin_amdgcn_global_load_lds((glb_void*)(pw_c + piece * 256 + lane * 4), (lds_void*)&lds[piece * 256], 16, 0, 0);
+  }
+  int k0, k1, w0, w1;
+  gwtf_pattern_dims(pat, &k0, &k1, &w0, &w1);
+  float xa[NB], xb[NB];
+  bool valid[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    const int n = n_wave0 + 16 * nb + i16;
+    valid[nb] = n < N;
+    xa[nb] = valid[nb] ? p[((size_t)b * 3 + k0) * N + n] : 0.f;
+    xb[nb] = (valid[nb] && k1 >= 0) ? p[((size_t)b * 3 + k1) * N + n] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    f32x4 acc[MB][NB], cinit[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) cinit[m] = zero4;
+    if (pat < 3) sd1_contract<MB, NB, true>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
+    else sd1_contract<MB, NB, false>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float v = valid[nb] ? acc[m][nb][r] : 0.f;   // points beyond N carry sd0's bias term: exclude
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+          s1 += __shfl_xor(s1, off);
+          s2 += __shfl_xor(s2, off);
+        }
+        if (i16 == 0) {
+          const int ft = 16 * m + 4 * q + r;
+          atomicAdd(&ystats[(br * FP + ft) * 2 + 0], s1);
+          atomicAdd(&ystats[(br * FP + ft) * 2 + 1], s2);
+        }
+      }
+  }
+}
+
+// Optional per-launch extras (all zero for the plain eval forward): a sub-range of couplings, a log-det to
+// continue from, and the coordinate moments the train-mode BatchNorm of the NEXT coupling needs.
+struct Extras {
+  int c_first, c_count;          // couplings processed: c_first, c_first +/- 1, ... (c_count == 0: all C)
+  const float* logdet_in;        // [B][3][N] or null
+  float* moments_out;            // 9 floats {Sx0,Sx1,Sx2,Sx0x0,Sx0x1,Sx0x2,Sx1x1,Sx1x2,Sx2x2} or null
+};
+
 struct Jobs {
   int K;
   int tiles_cum[GWTF_MAX_COMPONENTS + 1];  // prefix sum of B * tiles(k)
@@ -217,7 +305,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
                                                     float* __restrict__ logdet, float* __restrict__ ps,
                                                     float* __restrict__ mus, float* __restrict__ lvs, int B, int N, int C,
                                                     int pattern0, float eps, int kk_steps, const Jobs jobs,
-                                                    size_t p_stride_k, size_t out_stride_k) {
+                                                    size_t p_stride_k, size_t out_stride_k, const Extras ex) {
   using K = Cfg<MB>;
   __shared__ __align__(16) float lds[2][K::LAYER];
 
@@ -263,22 +351,27 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   // this lane's own point (one per lane) and the per-quarter copies used to build the MFMA B operand
   float xo[3], ld[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-  for (int d = 0; d < 3; ++d) xo[d] = own_inrange ? p[((size_t)b * 3 + d) * N + n_own] : 0.f;
+  for (int d = 0; d < 3; ++d) {
+    xo[d] = own_inrange ? p[((size_t)b * 3 + d) * N + n_own] : 0.f;
+    if (ex.logdet_in && own_inrange) ld[d] = ex.logdet_in[((size_t)b * 3 + d) * N + n_own];
+  }
+  const int n_steps = ex.c_count > 0 ? ex.c_count : C;
+  const int c_start = ex.c_count > 0 ? ex.c_first : (MODE == GWTF_MODE_INVERSE ? C - 1 : 0);
   float x[NB][3];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[nb][d] = __shfl(xo[d], 16 * nb + i16);
 
-  stage(0, MODE == GWTF_MODE_INVERSE ? C - 1 : 0);
+  stage(0, c_start);
   const float s_keep = sqrtf(eps + 1.0f);  // scale applied to un-warped coordinates (reference quirk)
 
-  for (int step = 0; step < C; ++step) {
-    const int c = MODE == GWTF_MODE_INVERSE ? C - 1 - step : step;
+  for (int step = 0; step < n_steps; ++step) {
+    const int c = MODE == GWTF_MODE_INVERSE ? c_start - step : c_start + step;
     const int buf = step & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (step + 1 < C) stage(buf ^ 1, MODE == GWTF_MODE_INVERSE ? c - 1 : c + 1);
+    if (step + 1 < n_steps) stage(buf ^ 1, MODE == GWTF_MODE_INVERSE ? c - 1 : c + 1);
 
     const int pat = (pattern0 + c) % 6;
     int k0, k1, w0, w1;
@@ -313,12 +406,30 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
       logdet[o] = ld[d];
     }
   }
+  if (ex.moments_out) {
+    // first and second moments of the output coordinates over all points (input statistics of the next
+    // coupling's sd0_bn in train mode): wavefront shuffle reduction, 9 atomics per wave
+    float mv[9];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) mv[d] = own_valid ? xo[d] : 0.f;
+    mv[3] = mv[0] * mv[0]; mv[4] = mv[0] * mv[1]; mv[5] = mv[0] * mv[2];
+    mv[6] = mv[1] * mv[1]; mv[7] = mv[1] * mv[2]; mv[8] = mv[2] * mv[2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) mv[i] += __shfl_down(mv[i], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) atomicAdd(&ex.moments_out[i], mv[i]);
+    }
+  }
 }
 
 template <int MB, int NB>
 int launch(const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps, float* mus,
            float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps, const int* segs, int K,
-           size_t p_stride_k, size_t out_stride_k, hipStream_t st) {
+           size_t p_stride_k, size_t out_stride_k, const Extras& ex, hipStream_t st) {
   Jobs jobs;
   jobs.K = K;
   jobs.tiles_cum[0] = 0;
@@ -333,7 +444,7 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
   const bool lists = ps != nullptr;
 #define GWTF_LAUNCH(MODE_, LISTS_)                                                                                      \
   hipLaunchKernelGGL((stack_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, \
-                     B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k)
+                     B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k, ex)
   if (mode == GWTF_MODE_DIRECT) {
     if (lists) GWTF_LAUNCH(GWTF_MODE_DIRECT, true); else GWTF_LAUNCH(GWTF_MODE_DIRECT, false);
   } else {
@@ -346,11 +457,11 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
 template <int MB>
 int launch_nb(int nb, const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps,
               float* mus, float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps,
-              const int* segs, int K, size_t p_stride_k, size_t out_stride_k, hipStream_t st) {
+              const int* segs, int K, size_t p_stride_k, size_t out_stride_k, const Extras& ex, hipStream_t st) {
   switch (nb) {
-    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, st);
-    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, st);
-    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, st);
+    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
+    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
+    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
   }
 }
 
@@ -360,15 +471,16 @@ int g_force_nb = 0;  // test/tuning hook, see gwtf_debug_set_points_per_wave
 
 extern "C" void gwtf_debug_set_points_per_wave(int pts) { g_force_nb = pts / 16; }
 
-extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float* film, float* out,
-                                        float* logdet, float* ps, float* mus, float* logvars, const int* segments,
-                                        int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
-                                        size_t p_stride_k, size_t out_stride_k, void* stream) {
+static int stack_dispatch(const float* p, const float* packed_w, const float* film, float* out, float* logdet, float* ps,
+                          float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,
+                          int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, const Extras& ex,
+                          void* stream) {
   if (B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || K <= 0 || K > GWTF_MAX_COMPONENTS || !p ||
       !packed_w || !film || !out || !logdet)
     return GWTF_E_BADARG;
   if (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) return GWTF_E_BADARG;
   if (pattern0 < 0 || pattern0 > 5) return GWTF_E_BADARG;
+  if (ex.c_count < 0 || (ex.c_count > 0 && (ex.c_first < 0 || ex.c_first >= C))) return GWTF_E_BADARG;
   const bool any = ps || mus || logvars, all = ps && mus && logvars;
   if (any && !all) return GWTF_E_BADARG;
   long pts = 0;
@@ -382,7 +494,7 @@ extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, c
   int nb = g_force_nb;
   if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
   const int kk_steps = (f + 3) / 4;
-#define GWTF_ARGS nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, segments, K, p_stride_k, out_stride_k, st
+#define GWTF_ARGS nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, segments, K, p_stride_k, out_stride_k, ex, st
   switch (gwtf_padded_width(f) / 16) {
     case 1: return launch_nb<1>(GWTF_ARGS);
     case 2: return launch_nb<2>(GWTF_ARGS);
@@ -393,9 +505,63 @@ extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, c
 #undef GWTF_ARGS
 }
 
+extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float* film, float* out,
+                                        float* logdet, float* ps, float* mus, float* logvars, const int* segments,
+                                        int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                                        size_t p_stride_k, size_t out_stride_k, void* stream) {
+  const Extras ex = {0, 0, nullptr, nullptr};
+  return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, segments, K, B, N, C, f, pattern0, eps, mode,
+                        p_stride_k, out_stride_k, ex, stream);
+}
+
+// One elementary coupling of the stack (train-mode pipeline: BatchNorm statistics are only known coupling by
+// coupling): applies coupling `c` to p -> out, continues the log-det from logdet_in, optionally writes list
+// slot c and accumulates the coordinate moments of `out` for the next coupling's sd0_bn.
+extern "C" int gwtf_train_apply(const float* p, const float* packed_w, const float* film, float* out,
+                                const float* logdet_in, float* logdet, float* ps, float* mus, float* logvars,
+                                float* moments_out, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                                void* stream) {
+  const Extras ex = {c, 1, logdet_in, moments_out};
+  return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, 1, B, N, C, f, pattern0, eps, mode, 0, 0,
+                        ex, stream);
+}
+
 extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const float* film, float* out, float* logdet,
                                   float* ps, float* mus, float* logvars, int B, int N, int C, int f, int pattern0,
                                   float eps, int mode, void* stream) {
   return gwtf_stack_forward_multi(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, 1, B, N, C, f, pattern0, eps,
                                   mode, 0, 0, stream);
+}
+
+namespace {
+template <int MB>
+int launch_stats(int nb, const float* p, const float* pw_c, float* ystats, int B, int N, int pat, int kk_steps,
+                 hipStream_t st) {
+  const int pts_wg = 64 * nb;
+  const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg))), block(256);
+  switch (nb) {
+    case 1: hipLaunchKernelGGL((stats_kernel<MB, 1>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps); break;
+    case 2: hipLaunchKernelGGL((stats_kernel<MB, 2>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps); break;
+    default: hipLaunchKernelGGL((stats_kernel<MB, 4>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps); break;
+  }
+  return (int)hipGetLastError();
+}
+}  // namespace
+
+extern "C" int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats, int B, int N, int f, int pattern,
+                                void* stream) {
+  if (B <= 0 || N <= 0 || f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5 || !p || !packed_w_c || !ystats)
+    return GWTF_E_BADARG;
+  const long pts = (long)B * N;
+  int nb = g_force_nb;
+  if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
+  const int kk_steps = (f + 3) / 4;
+  hipStream_t st = (hipStream_t)stream;
+  switch (gwtf_padded_width(f) / 16) {
+    case 1: return launch_stats<1>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
+    case 2: return launch_stats<2>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
+    case 3: return launch_stats<3>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
+    case 4: return launch_stats<4>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
+    default: return GWTF_E_BADARG;
+  }
 }

@@ -224,14 +224,14 @@ class StackEngine:
             raise ValueError(f"mode must be 'direct' or 'inverse', got {mode!r}")
         self._check(p, g)
         c0 = self.couplings[0]
-        if c0.training:
-            raise NotImplementedError('train-mode BatchNorm (batch statistics) HIP path is not built yet; '
-                                      'call .eval() -- there is no torch fallback')
-        pw, pf = self.packed(False)
         pc, gc = p.contiguous().float(), g.contiguous().float()
         eps = c0._eps_value
-        film = _lib.film_forward(gc, pf, self.C, self.f, eps, False)
-        out, logdet, lists = _lib.stack_forward(pc, pw, film, self.C, self.f, self.pattern0, eps, mode, want_lists)
+        if c0.training:
+            out, logdet, lists = self._run_train(pc, gc, mode, want_lists)
+        else:
+            pw, pf = self.packed(False)
+            film = _lib.film_forward(gc, pf, self.C, self.f, eps, False)
+            out, logdet, lists = _lib.stack_forward(pc, pw, film, self.C, self.f, self.pattern0, eps, mode, want_lists)
         needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
                                                   any(t.requires_grad for t in self._tracked))
         if needs_grad:
@@ -239,6 +239,51 @@ class StackEngine:
             res = _NoBackwardYet.apply(anchor, p, g, out, logdet, *([lists] if want_lists else []))
             out, logdet = res[0], res[1]
             lists = res[2] if want_lists else None
+        return out, logdet, lists
+
+    # -- train mode: batch-statistic BatchNorm ----------------------------------------------------------
+    def _bn_modules(self):
+        """The 8 BatchNorm modules of every coupling in bn_batch order: [coupling][branch lv,mu][kind 0..3]."""
+        mods = []
+        for c in self.couplings:
+            for X in ('logvar', 'mu'):
+                t0 = getattr(c, f'T_{X}_0')
+                mods += [t0[1], t0[4], getattr(c, f'T_{X}_0_cond_w')[1], getattr(c, f'T_{X}_0_cond_b')[1]]
+        return mods
+
+    def _run_train(self, p, g, mode, want_lists):
+        """model.train() forward: statistics over all B*N points (and, when torch.distributed is initialised,
+        over all ranks -- the reference wraps the model in SyncBatchNorm, train_ae.py:152), running statistics
+        updated with the modules' momentum, unbiased variance (torch semantics)."""
+        import torch.distributed as dist
+        group_sum, g_all, row0 = None, None, 0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            def group_sum(t):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            sizes = [torch.zeros(1, dtype=torch.int64, device=p.device) for _ in range(dist.get_world_size())]
+            dist.all_gather(sizes, torch.tensor([g.shape[0]], dtype=torch.int64, device=p.device))
+            sizes = [int(x.item()) for x in sizes]
+            parts = [torch.empty(n, g.shape[1], device=g.device, dtype=g.dtype) for n in sizes]
+            dist.all_gather(parts, g)               # per-rank batches may differ by one (train_ae.py:77-78)
+            g_all, row0 = torch.cat(parts), sum(sizes[:dist.get_rank()])
+        with torch.no_grad():
+            raw = self.raw_arena()
+            out, logdet, lists, bn_batch = _lib.train_forward(p, g, raw, self.C, self.f, self.G, self.pattern0,
+                                                              self.couplings[0]._eps_value, mode, want_lists,
+                                                              group_sum, g_all, row0)
+            mods = self._bn_modules()
+            flat = bn_batch.reshape(len(mods), 2, self.f)
+            groups = {}
+            for i, m in enumerate(mods):
+                if m.track_running_stats and m.running_mean is not None:
+                    groups.setdefault(0.1 if m.momentum is None else float(m.momentum), []).append(i)
+            for mom, idx in groups.items():
+                rms, rvs = [mods[i].running_mean for i in idx], [mods[i].running_var for i in idx]
+                torch._foreach_mul_(rms, 1.0 - mom)
+                torch._foreach_add_(rms, [flat[i, 0] for i in idx], alpha=mom)
+                torch._foreach_mul_(rvs, 1.0 - mom)
+                torch._foreach_add_(rvs, [flat[i, 1] for i in idx], alpha=mom)
+            torch._foreach_add_([m.num_batches_tracked for m in mods if m.num_batches_tracked is not None], 1)
         return out, logdet, lists
 
     def capture(self, p, g, mode, want_lists=False):

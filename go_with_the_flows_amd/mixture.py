@@ -39,9 +39,11 @@ class MixtureStack:
     def forward_all(self, p, g, mode='inverse'):
         """Every component on every point -> (out, logdet), each (K,B,3,N).  Training / density path."""
         e0 = self.engines[0]
-        if e0.couplings[0].training:
-            raise NotImplementedError('train-mode BatchNorm HIP path is not built yet; call .eval()')
         e0._check(p, g)
+        if e0.couplings[0].training:
+            # batch-statistic BatchNorm: the per-coupling pipeline, component by component
+            res = [e.run(p, g, mode, False) for e in self.engines]
+            return torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res])
         pw, film, eps = self._film(g.contiguous().float())
         return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode)
 
@@ -50,7 +52,7 @@ class MixtureStack:
         (sum == N); each point goes through ONE component.  -> (out, logdet), each (B,3,N)."""
         e0 = self.engines[0]
         if e0.couplings[0].training:
-            raise NotImplementedError('train-mode BatchNorm HIP path is not built yet; call .eval()')
+            raise NotImplementedError('the sampling partition is an evaluation path (reference flow_mixture.py:146); call .eval()')
         e0._check(p, g)
         if len(counts) != self.K or sum(int(c) for c in counts) != p.shape[2]:
             raise ValueError('counts must have K entries summing to N')

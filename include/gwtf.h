@@ -92,6 +92,23 @@ int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float*
                              const int* segments, int K, int B, int N, int C, int f, int pattern0, float eps,
                              int mode, size_t p_stride_k, size_t out_stride_k, void* stream);
 
+/* ---- train-mode (batch-statistic BatchNorm) forward pipeline, reference flows.py:27,30,62,65 under model.train() ----
+ * Per coupling, in processing order (inverse: C-1..0):  fold0 -> stats -> fold1 -> apply.  See csrc/gwtf_train.hip.
+ * gwtf_pack_weights(training=1) leaves sd1 un-scaled and the sd0 records empty; gwtf_film_forward(training=1)
+ * writes RAW FiLM {a, b} as film_out[B][C][2 branches][2][FP] (NOT the eval record) and the FiLM BatchNorm
+ * batch statistics.  n_total = number of points the statistics cover (B*N; summed over ranks when sharded). */
+int gwtf_train_moments(const float* p, float* moments /*9, pre-zeroed, accumulated*/, int B, int N, void* stream);
+int gwtf_train_fold0(const float* raw_c, const float* moments, double n_total, int pattern, float* packed_w_c,
+                     float* bn_batch_c /*[2 branches][4 kinds][2][f]: kind 0 <- {mean, unbiased var} of sd0_bn*/,
+                     int f, int G, void* stream);
+int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats /*[2][FP][2] pre-zeroed, accumulated*/,
+                     int B, int N, int f, int pattern, void* stream);
+int gwtf_train_fold1(const float* raw_c, const float* ystats, double n_total, const float* film_raw, float* film_rec,
+                     float* bn_batch_c /*kind 1 <- sd1_bn*/, int c, int B, int C, int f, int G, void* stream);
+int gwtf_train_apply(const float* p, const float* packed_w, const float* film_rec, float* out, const float* logdet_in,
+                     float* logdet, float* ps, float* mus, float* logvars, float* moments_out /*9 or NULL*/,
+                     int c, int B, int N, int C, int f, int pattern0, float eps, int mode, void* stream);
+
 /* Mixture negative log-likelihood over K flow components.
  * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
  * PointFlowNLL, :11-20).

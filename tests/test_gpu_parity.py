@@ -283,3 +283,55 @@ def test_mixture_partitioned_sampling_path(counts):
             assert maxabs(host(x)[:, :, off:off + cnt], ref_x) < TOL_COORD
             assert maxabs(host(ld)[:, :, off:off + cnt], ref_ld) < TOL_LOGDET
         off += cnt
+
+
+# ---- train mode: batch-statistic BatchNorm -------------------------------------------------------------------
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+def test_g1_train_mode_single_couplings(mode):
+    G1 = golden('g1_couplings')
+    f, G, B, N = G1['dims']
+    for pi, warp in enumerate(gw.WARP_PATTERNS):
+        m, _ = coupling_and_state(f, G, warp, 100 + pi)
+        m = m.to(DEV).train()
+        with torch.no_grad():
+            po, mu, lv = m(dev(G1[f'p{pi}']), dev(G1[f'g{pi}']), mode=mode)
+        tag = f'{pi}_train_{mode}'
+        assert maxabs(host(po), G1['pout_' + tag]) < 5e-5
+        assert maxabs(host(mu), G1['mu_' + tag]) < 5e-5
+        assert maxabs(host(lv), G1['lv_' + tag]) < 5e-5
+        sd = m.state_dict()
+        for key in G1.files:
+            if key.startswith(f'rm_{tag}_'):
+                probe = key[len(f'rm_{tag}_'):]
+                assert maxabs(host(sd[probe + '.running_mean']), G1[key]) < 1e-5, probe
+                assert maxabs(host(sd[probe + '.running_var']), G1['rv' + key[2:]]) < 1e-5, probe
+                assert int(sd[probe + '.num_batches_tracked']) == 1
+
+
+@pytest.mark.parametrize('name', ['g3_decoder_4x64x128', 'g3s_decoder_lists'])
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+def test_decoder_train_mode(name, mode):
+    D = golden(name)
+    L, f, G, B, N, seed = D['dims']
+    m, st = decoder_and_state(L, f, G, seed)
+    m = m.to(DEV).train()
+    with torch.no_grad():
+        ps, mus, lvs = m(dev(D['p']), dev(D['g']), mode=mode)
+    tag = f'train_{mode}'
+    # batch statistics over B=4 latent rows amplify fp32 rounding (see tests/test_oracle_golden.py): bar = 1e-3
+    # on the 4x64x128 case, where the reference itself sits 6e-5..1.6e-4 from an fp64 evaluation
+    tol = 1e-3 if f == 64 else 5e-5
+    assert maxabs(host(ps[0]), D['first_' + tag]) < tol
+    assert maxabs(host(ps[-1]), D['last_' + tag]) < tol
+    assert maxabs(host(sum(lvs)), D['logdet_' + tag]) < tol
+    out64, ld64 = fo.decoder_fused(D['p'].astype(np.float64), D['g'].astype(np.float64), state64(st), L, mode, training=True)
+    assert maxabs(host(ps[0] if mode == 'inverse' else ps[-1]), out64) < tol
+    if 'ps_' + tag in D.files:
+        assert maxabs(host(torch.stack(ps)), D['ps_' + tag]) < tol
+        assert maxabs(host(torch.stack(lvs)), D['lvs_' + tag]) < tol
+    # eval after train uses the UPDATED running statistics: compare with the oracle's new_stats
+    new = {}
+    fo.decoder_forward(D['p'], D['g'], st, L, mode, training=True, new_stats=new)
+    sd = m.state_dict()
+    worst = max(maxabs(host(sd[k]), v) for k, v in new.items() if not k.endswith('num_batches_tracked'))
+    assert worst < (1e-3 if f == 64 else 1e-5)
