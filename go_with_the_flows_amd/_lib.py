@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'libgwtf_hip.so')
 ABI_VERSION = 1
 
 MODE_DIRECT, MODE_INVERSE = 0, 1
+STAT_REPLICAS = 64   # GWTF_STAT_REPLICAS in csrc/gwtf_layout.h
 _MODES = {'direct': MODE_DIRECT, 'inverse': MODE_INVERSE}
 
 _c_fp = ctypes.c_void_p
@@ -35,6 +36,7 @@ _SIGNATURES = {
     'gwtf_train_stats': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_train_fold1': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, _c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
     'gwtf_train_apply': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_train_forward': (ctypes.c_int, [_c_fp] * 13 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
 }
@@ -200,21 +202,31 @@ def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum
         pw, pf = pack_weights(raw, C, f, G, True)
         film_all, fstats = film_forward(gfull, pf, C, f, eps, True, want_stats=True)
         film_raw = film_all[row0:row0 + B].contiguous()
-        mom = torch.zeros(C + 1, 16, device=dev, dtype=torch.float32)
-        ystats = torch.zeros(C, 2 * FP * 2, device=dev, dtype=torch.float32)
+        mom = torch.zeros(C + 1, STAT_REPLICAS * 16, device=dev, dtype=torch.float32)
+        ystats = torch.zeros(C, STAT_REPLICAS * 2 * FP * 2, device=dev, dtype=torch.float32)
         bn_batch = torch.zeros(C, 2, 4, 2, f, device=dev, dtype=torch.float32)
         film_rec = torch.empty(B, C, FS, device=dev, dtype=torch.float32)
-        bufs = [torch.empty_like(p), torch.empty_like(p)]
+        xbuf = torch.empty(2, B, 3, N, device=dev, dtype=torch.float32)
+        bufs = [xbuf[0], xbuf[1]]
         logdet = torch.empty_like(p)
         lists = torch.empty(3, C, B, 3, N, device=dev, dtype=torch.float32) if want_lists else None
         lp = [lists[i].data_ptr() for i in range(3)] if want_lists else [None, None, None]
-        n_total = torch.tensor([float(B) * N], device=dev, dtype=torch.float64)
+        n_total = float(B) * N
         if group_sum is not None:
-            group_sum(n_total)
-        n_total = float(n_total.item())
-        check(L.gwtf_train_moments(_ptr(p, 'p'), mom[0].data_ptr(), B, N, st))
+            nt = torch.tensor([n_total], device=dev, dtype=torch.float64)
+            group_sum(nt)
+            n_total = float(nt.item())
         order = range(C) if mode == 'direct' else range(C - 1, -1, -1)
         cur = p
+        if group_sum is None:
+            # single rank: the whole pipeline is enqueued by one C call
+            check(L.gwtf_train_forward(_ptr(p, 'p'), _ptr(raw, 'raw'), pw.data_ptr(), film_raw.data_ptr(), mom.data_ptr(),
+                                       ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(), xbuf.data_ptr(),
+                                       logdet.data_ptr(), lp[0], lp[1], lp[2], B, N, C, f, G, pattern0, float(eps),
+                                       _MODES[mode], st))
+            cur, order = bufs[(C - 1) & 1], ()
+        else:
+            check(L.gwtf_train_moments(_ptr(p, 'p'), mom[0].data_ptr(), B, N, st))
         for step, c in enumerate(order):
             pat = (pattern0 + c) % 6
             if group_sum is not None:

@@ -5,8 +5,9 @@
 // RAW ARENA (input of gwtf_pack_weights): C coupling records in direct order, each made of
 // two branch records, branch 0 = logvar, branch 1 = mu.  A branch record is the reference's
 // parameters and BatchNorm buffers (lib/networks/flows.py:25-50 / 60-85) flattened row-major in
-// this order (k = kept coordinates padded to 2 columns with zeros, w = warped padded to 2 rows):
-//   sd0.weight[f][2] | sd0_bn.{weight,bias,running_mean,running_var}[f] | sd1.weight[f][f] |
+// this order (k = kept coordinates padded to 2 with zeros, w = warped padded to 2 rows; sd0.weight is stored
+// TRANSPOSED so the padding is a tail, which lets the host build the arena with one torch.cat):
+//   sd0.weight^T[2][f] | sd0_bn.{weight,bias,running_mean,running_var}[f] | sd1.weight[f][f] |
 //   sd1_bn.{running_mean,running_var}[f] |
 //   film_w0.weight[f][G] | film_w0_bn.{weight,bias,running_mean,running_var}[f] | film_w1.weight[f][f] | film_w1.bias[f] |
 //   film_b0.weight[f][G] | film_b0_bn.{...}[f] | film_b1.weight[f][f] | film_b1.bias[f] |
@@ -23,6 +24,7 @@
 #define GWTF_BN_EPS 1e-5f
 #define GWTF_MAX_FP 64
 #define GWTF_MAX_COMPONENTS 64
+#define GWTF_STAT_REPLICAS 64   // copies of every train-mode statistic accumulator (atomic contention spreading)
 
 struct GwtfRaw {  // offsets inside one branch record
   int f, G;

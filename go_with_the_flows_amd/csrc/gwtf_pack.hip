@@ -57,7 +57,7 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__
       if (ft < f && !training) {   // train: written per coupling by gwtf_train_fold0
         const float* bn = rb + R.bn0();
         const float s = bn[ft] * inv_std(bn[3 * f + ft]);
-        v = e < 2 ? rb[R.sd0_w() + 2 * ft + e] * s : bn[f + ft] - bn[2 * f + ft] * s;
+        v = e < 2 ? rb[R.sd0_w() + (size_t)e * f + ft] * s : bn[f + ft] - bn[2 * f + ft] * s;
       }
     }
     out[idx] = v;

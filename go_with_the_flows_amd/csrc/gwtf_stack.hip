@@ -220,13 +220,15 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
 // over all points, both branches (input of sd1_bn's batch statistics, reference flows.py:30,65 in train()).
 // Same tile decomposition and contraction as the forward kernel; the accumulators are reduced over the wave's
 // points (in-lane over the NB blocks, shuffles over the 16 lanes of a quarter) and added to ystats with one
-// atomic per feature and wave.   ystats: [2 branches][FP][2] = {sum y, sum y^2}
+// atomic per feature and workgroup.   ystats: [GWTF_STAT_REPLICAS][2 branches][FP][2] = {sum y, sum y^2}
 template <int MB, int NB>
 __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p, const float* __restrict__ pw_c,
                                                     float* __restrict__ ystats, int B, int N, int pat, int kk_steps) {
   using K = Cfg<MB>;
   constexpr int FP = K::FP;
   __shared__ __align__(16) float lds[K::PW];
+  __shared__ float s_stats[2 * FP * 2];
+  for (int t = threadIdx.x; t < 2 * FP * 2; t += blockDim.x) s_stats[t] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
   const int tiles_per_shape = (N + 64 * NB - 1) / (64 * NB);
@@ -278,11 +280,16 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
         }
         if (i16 == 0) {
           const int ft = 16 * m + 4 * q + r;
-          atomicAdd(&ystats[(br * FP + ft) * 2 + 0], s1);
-          atomicAdd(&ystats[(br * FP + ft) * 2 + 1], s2);
+          atomicAdd(&s_stats[(br * FP + ft) * 2 + 0], s1);   // LDS: 4 waves
+          atomicAdd(&s_stats[(br * FP + ft) * 2 + 1], s2);
         }
       }
   }
+  __syncthreads();
+  // one global atomic per value and workgroup, spread over GWTF_STAT_REPLICAS copies: thousands of adds to one
+  // address serialise (measured 580 us for this kernel with per-wave atomics on a single copy)
+  float* rep = ystats + (size_t)(blockIdx.x % GWTF_STAT_REPLICAS) * (2 * FP * 2);
+  for (int t = threadIdx.x; t < 2 * FP * 2; t += blockDim.x) atomicAdd(&rep[t], s_stats[t]);
 }
 
 // Optional per-launch extras (all zero for the plain eval forward): a sub-range of couplings, a log-det to
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
 struct Extras {
   int c_first, c_count;          // couplings processed: c_first, c_first +/- 1, ... (c_count == 0: all C)
   const float* logdet_in;        // [B][3][N] or null
-  float* moments_out;            // 9 floats {Sx0,Sx1,Sx2,Sx0x0,Sx0x1,Sx0x2,Sx1x1,Sx1x2,Sx2x2} or null
+  float* moments_out;            // [GWTF_STAT_REPLICAS][16], 9 used {Sx0,Sx1,Sx2,Sx0x0,Sx0x1,Sx0x2,Sx1x1,Sx1x2,Sx2x2}, or null
 };
 
 struct Jobs {
@@ -419,10 +426,15 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) mv[i] += __shfl_down(mv[i], off);
     }
+    __shared__ float s_mom[4][9];
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) atomicAdd(&ex.moments_out[i], mv[i]);
+      for (int i = 0; i < 9; ++i) s_mom[wave][i] = mv[i];
     }
+    __syncthreads();
+    if (threadIdx.x < 9)
+      atomicAdd(&ex.moments_out[(blockIdx.x % GWTF_STAT_REPLICAS) * 16 + threadIdx.x],
+                s_mom[0][threadIdx.x] + s_mom[1][threadIdx.x] + s_mom[2][threadIdx.x] + s_mom[3][threadIdx.x]);
   }
 }
 

@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
     for (int off = 32; off > 0; off >>= 1) mv[i] += __shfl_down(mv[i], off);
   }
   if ((threadIdx.x & 63) == 0) {
+    float* rep = mom + ((blockIdx.x + blockIdx.y) % GWTF_STAT_REPLICAS) * 16;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) atomicAdd(&mom[i], mv[i]);
+    for (int i = 0; i < 9; ++i) atomicAdd(&rep[i], mv[i]);
   }
 }
 
@@ -43,9 +44,16 @@ __device__ __forceinline__ int mom2_index(int a, int b) {  // index of S x_a x_b
 }
 
 // One workgroup, thread = (branch, feature).  bn_batch[branch][kind 0][2][f] <- {mean, unbiased var}.
-__global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom, double n_total, int pat,
+__global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
                              float* __restrict__ pw_c, float* __restrict__ bn_batch, int f, int G, int FP) {
   const int t = threadIdx.x;
+  __shared__ float mom[9];
+  if (t < 9) {
+    float sacc = 0.f;
+    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) sacc += mom_rep[r * 16 + t];
+    mom[t] = sacc;
+  }
+  __syncthreads();
   if (t >= 2 * f) return;
   const int br = t / f, j = t % f;
   const GwtfRaw R(f, G);
@@ -58,7 +66,7 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
   const double c00 = mom[mom2_index(k0, k0)] / n_total - e0 * e0;
   const double c11 = k1 >= 0 ? mom[mom2_index(k1, k1)] / n_total - e1 * e1 : 0.0;
   const double c01 = k1 >= 0 ? mom[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] / n_total - e0 * e1 : 0.0;
-  const double wa = rb[R.sd0_w() + 2 * j], wb = rb[R.sd0_w() + 2 * j + 1];
+  const double wa = rb[R.sd0_w() + j], wb = rb[R.sd0_w() + f + j];
   const double mean = wa * e0 + wb * e1;
   double var = wa * wa * c00 + 2.0 * wa * wb * c01 + wb * wb * c11;
   if (var < 0.0) var = 0.0;
@@ -88,8 +96,13 @@ __global__ void fold1_kernel(const float* __restrict__ raw_c, const float* __res
     return;
   }
   const float* rb = raw_c + (size_t)br * R.branch_size();
-  const double mean = ystats[(br * FP + j) * 2] / n_total;
-  double var = ystats[(br * FP + j) * 2 + 1] / n_total - mean * mean;
+  float ys = 0.f, yq = 0.f;
+  for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) {
+    ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
+    yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
+  }
+  const double mean = ys / n_total;
+  double var = yq / n_total - mean * mean;
   if (var < 0.0) var = 0.0;
   const float s1 = 1.0f / sqrtf((float)var + GWTF_BN_EPS);
   const float* fr = film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
@@ -132,4 +145,42 @@ extern "C" int gwtf_train_fold1(const float* raw_c, const float* ystats, double 
   hipLaunchKernelGGL(fold1_kernel, dim3(B), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, ystats, n_total, film_raw,
                      film_rec, bn_batch_c, c, C, f, G, gwtf_padded_width(f));
   return (int)hipGetLastError();
+}
+
+// Whole train-mode forward of one stack on one rank (no cross-rank statistics): enqueues moments + 4 launches per
+// coupling from C, so the host cost per coupling is four hipLaunchKernel calls instead of a Python iteration.
+// Workspace (caller-owned, pre-zeroed where stated): moments [(C+1)][64][16] zero, ystats [C][64][2*FP*2] zero,
+// bn_batch [C][2][4][2][f], film_rec [B][C][FS], xbuf [2][B][3][N].  Result coordinates end in
+// xbuf[(C-1) & 1]; packed_w is modified (sd0 records filled in).
+extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packed_w, const float* film_raw,
+                                  float* moments, float* ystats, float* bn_batch, float* film_rec, float* xbuf,
+                                  float* logdet, float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G,
+                                  int pattern0, float eps, int mode, void* stream) {
+  if (!p || !raw || !packed_w || !film_raw || !moments || !ystats || !bn_batch || !film_rec || !xbuf || !logdet)
+    return GWTF_E_BADARG;
+  if (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) return GWTF_E_BADARG;
+  const int FP = gwtf_padded_width(f);
+  const size_t R = gwtf_raw_coupling_floats(f, G), PW = gwtf_packed_w_coupling_floats(f);
+  const size_t MS = (size_t)GWTF_STAT_REPLICAS * 16, YS = (size_t)GWTF_STAT_REPLICAS * 2 * FP * 2;
+  const size_t BS = (size_t)2 * 4 * 2 * f, XS = (size_t)B * 3 * N;
+  const double n_total = (double)B * N;
+  int rc = gwtf_train_moments(p, moments, B, N, stream);
+  if (rc) return rc;
+  const float* cur = p;
+  for (int step = 0; step < C; ++step) {
+    const int c = mode == GWTF_MODE_DIRECT ? step : C - 1 - step;
+    const int pat = (pattern0 + c) % 6;
+    rc = gwtf_train_fold0(raw + c * R, moments + step * MS, n_total, pat, packed_w + c * PW, bn_batch + c * BS, f, G, stream);
+    if (rc) return rc;
+    rc = gwtf_train_stats(cur, packed_w + c * PW, ystats + c * YS, B, N, f, pat, stream);
+    if (rc) return rc;
+    rc = gwtf_train_fold1(raw + c * R, ystats + c * YS, n_total, film_raw, film_rec, bn_batch + c * BS, c, B, C, f, G, stream);
+    if (rc) return rc;
+    float* nxt = xbuf + (size_t)(step & 1) * XS;
+    rc = gwtf_train_apply(cur, packed_w, film_rec, nxt, step > 0 ? logdet : nullptr, logdet, ps, mus, logvars,
+                          step + 1 < C ? moments + (step + 1) * MS : nullptr, c, B, N, C, f, pattern0, eps, mode, stream);
+    if (rc) return rc;
+    cur = nxt;
+  }
+  return 0;
 }

@@ -74,24 +74,33 @@ class CondRealNVPFlow3D(nn.Module):
         self._stamp = 0
 
     # -- parameter gathering -------------------------------------------------------------------
-    def raw_tensors(self):
-        """This coupling's record of the raw arena, in the order fixed by csrc/gwtf_layout.h."""
+    def raw_sources(self):
+        """This coupling's record of the raw arena as (tensor, op) pairs in the order fixed by csrc/gwtf_layout.h;
+        op: None = flatten as is, 't' = transpose first, int n = n zeros (padding of the absent kept / warped slot)."""
         out = []
         k, w = len(self.keep_inds), len(self.warp_inds)
+        f = self.f_n_features
         for X in ('logvar', 'mu'):
             t0 = getattr(self, f'T_{X}_0')
             sd0, bn0, sd1, bn1 = t0[0], t0[1], t0[3], t0[4]
-            w0 = sd0.weight[0]
-            out += [F.pad(w0, (0, 2 - k)) if k < 2 else w0, bn0.weight, bn0.bias, bn0.running_mean, bn0.running_var,
-                    sd1.weight[0], bn1.running_mean, bn1.running_var]
+            out += [(sd0.weight, 't')] + ([(None, f)] if k < 2 else [])
+            out += [(bn0.weight, None), (bn0.bias, None), (bn0.running_mean, None), (bn0.running_var, None),
+                    (sd1.weight, None), (bn1.running_mean, None), (bn1.running_var, None)]
             for which in ('w', 'b'):
                 head = getattr(self, f'T_{X}_0_cond_{which}')
-                out += [head[0].weight, head[1].weight, head[1].bias, head[1].running_mean, head[1].running_var,
-                        head[3].weight, head[3].bias]
+                out += [(head[0].weight, None), (head[1].weight, None), (head[1].bias, None),
+                        (head[1].running_mean, None), (head[1].running_var, None), (head[3].weight, None),
+                        (head[3].bias, None)]
             sd2 = getattr(self, f'T_{X}_1')[1]
-            w2, b2 = sd2.weight[0], sd2.bias[0]
-            out += [F.pad(w2, (0, 0, 0, 2 - w)) if w < 2 else w2, F.pad(b2, (0, 2 - w)) if w < 2 else b2]
+            out += [(sd2.weight, None)] + ([(None, f)] if w < 2 else [])
+            out += [(sd2.bias, None)] + ([(None, 1)] if w < 2 else [])
         return out
+
+    def raw_tensors(self):
+        """Flattened tensors of this coupling's raw-arena record (see raw_sources)."""
+        dev = self.eps.device
+        return [torch.zeros(op, device=dev) if t is None else (t[0].t().reshape(-1) if op == 't' else t.reshape(-1))
+                for t, op in self.raw_sources()]
 
     def tracked_tensors(self):
         """Every tensor whose in-place modification must invalidate the packed-weight cache."""
@@ -185,11 +194,23 @@ class StackEngine:
         if self.f > 64:
             raise NotImplementedError(f'f_n_features={self.f} > 64 is not supported by the gfx950 kernels yet')
         self._tracked, self._tracked_stamp = [], None
+        self._srcs, self._src_stamp, self._zeros = None, None, None
         self._cache_key = None
         self._packed = None
 
     def raw_arena(self):
-        return torch.cat([t.reshape(-1) for c in self.couplings for t in c.raw_tensors()])
+        """Parameters + BatchNorm buffers of all couplings as one flat tensor (autograd-aware torch.cat).  The list
+        of sources is cached (module traversal costs more than the copy); it is rebuilt when .to()/.cuda()/
+        load_state_dict() re-create tensors (stamp change)."""
+        stamp = sum(c._stamp for c in self.couplings)
+        if stamp != self._src_stamp:
+            self._srcs = [so for c in self.couplings for so in c.raw_sources()]
+            dev = self.couplings[0].eps.device
+            self._zeros = {n: torch.zeros(n, device=dev) for n in {op for t, op in self._srcs if t is None}}
+            self._src_stamp = stamp
+        z = self._zeros
+        return torch.cat([z[op] if t is None else (t[0].t().reshape(-1) if op == 't' else t.view(-1))
+                          for t, op in self._srcs])
 
     def _key(self, training):
         stamp = sum(c._stamp for c in self.couplings)

@@ -97,17 +97,26 @@ int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float*
  * gwtf_pack_weights(training=1) leaves sd1 un-scaled and the sd0 records empty; gwtf_film_forward(training=1)
  * writes RAW FiLM {a, b} as film_out[B][C][2 branches][2][FP] (NOT the eval record) and the FiLM BatchNorm
  * batch statistics.  n_total = number of points the statistics cover (B*N; summed over ranks when sharded). */
-int gwtf_train_moments(const float* p, float* moments /*9, pre-zeroed, accumulated*/, int B, int N, void* stream);
+/* statistic accumulators are replicated GWTF_STAT_REPLICAS (=64) times to spread atomic contention:
+ * moments [64][16] (9 used), ystats [64][2][FP][2]; the fold kernels sum the replicas. */
+int gwtf_train_moments(const float* p, float* moments /*pre-zeroed, accumulated*/, int B, int N, void* stream);
 int gwtf_train_fold0(const float* raw_c, const float* moments, double n_total, int pattern, float* packed_w_c,
                      float* bn_batch_c /*[2 branches][4 kinds][2][f]: kind 0 <- {mean, unbiased var} of sd0_bn*/,
                      int f, int G, void* stream);
-int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats /*[2][FP][2] pre-zeroed, accumulated*/,
+int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats /*pre-zeroed, accumulated*/,
                      int B, int N, int f, int pattern, void* stream);
 int gwtf_train_fold1(const float* raw_c, const float* ystats, double n_total, const float* film_raw, float* film_rec,
                      float* bn_batch_c /*kind 1 <- sd1_bn*/, int c, int B, int C, int f, int G, void* stream);
 int gwtf_train_apply(const float* p, const float* packed_w, const float* film_rec, float* out, const float* logdet_in,
                      float* logdet, float* ps, float* mus, float* logvars, float* moments_out /*9 or NULL*/,
                      int c, int B, int N, int C, int f, int pattern0, float eps, int mode, void* stream);
+
+/* The whole single-rank train-mode forward enqueued from C (moments + 4 launches per coupling); workspace sizes
+ * are documented at the definition in csrc/gwtf_train.hip.  Result coordinates end in xbuf[(C-1) & 1]. */
+int gwtf_train_forward(const float* p, const float* raw, float* packed_w, const float* film_raw, float* moments,
+                       float* ystats, float* bn_batch, float* film_rec, float* xbuf, float* logdet,
+                       float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G, int pattern0,
+                       float eps, int mode, void* stream);
 
 /* Mixture negative log-likelihood over K flow components.
  * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
