@@ -1,0 +1,404 @@
+// gwtf_bwd.hip -- backward of ONE elementary coupling (density / inverse direction, BatchNorm as a fixed
+// affine: model.eval(), or the folded statistics of the train pipeline held constant).
+//
+// Reference semantics: autograd through CondRealNVPFlow3D.forward (lib/networks/flows.py:95-117), i.e. what
+// loss.backward() (training.py:54) computes for this layer.  Formulation in the FOLDED parameters the forward
+// kernel consumes (gwtf_layout.h):  per branch X in {logvar, mu}
+//     pre = W0f [xa;xb] + c0f      h = relu(pre)      acc = W1p h + c(b)      z = relu(acc)      o_w = u_w(b).z + bias_w
+//     lv = softsign(o^lv)   mu = o^mu   s = sqrt(eps + exp(lv))   out_w = (x_w - mu)/s   out_k = x_k/sqrt(eps+1)   ld_w += lv
+// One pass per coupling: the forward is RECOMPUTED from the saved coupling input (12 B/pt), then
+//     dt -> dz = u.dt -> dacc = dz[acc>0]      (in the accumulators' C layout, in place)
+//     dh = W1p^T dacc                           v_mfma_f32_16x16x4_f32: the C-layout registers ARE its B operand
+//                                               (k-slot q of step kk=4m+r <-> feature 16m + 4q + r), exact fp32
+//     dpre = dh[pre>0]   dxk = W0f^T dpre   dx_w = g_out_w / s
+// Reductions over points (per-shape FiLM record grads dc, du_w; sd0 grads; sd2 bias grads) are done in-lane over
+// the point blocks, by shuffles over the 16 lanes of a quarter, in LDS over the 4 waves, then one atomic per value
+// and workgroup.  The f x f weight gradient dW1p = sum_p dacc(p) h(p)^T is a plain GEMM over all points: dacc and h
+// are written out ([B][2][FP][N]) and contracted by the BLAS library on the host side.
+#include "gwtf_device.h"
+
+namespace {
+
+using namespace gwtf_dev;
+
+template <int MB>
+struct BCfg {
+  static constexpr int FP = 16 * MB;
+  static constexpr int KKF = FP / 4;
+  static constexpr int W1T = MB * KKF * 64;             // floats, one branch: [mi][kk][lane]
+  static constexpr int PB = 2 * W1T + 2 * FP * 4;       // + SD0N[2][FP][4]
+};
+
+template <int MB, int NB>
+__global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
+                                                  const float* __restrict__ g_ld, const float* __restrict__ pw_c,
+                                                  const float* __restrict__ pb_c, const float* __restrict__ film,
+                                                  float* __restrict__ g_in, float* __restrict__ dA_mat,
+                                                  float* __restrict__ h0_mat, float* __restrict__ g_film,
+                                                  float* __restrict__ g_sd0, float* __restrict__ g_bias, int B, int N,
+                                                  int C, int c, int pat, float eps, int kk_steps, int f) {
+  using K = Cfg<MB>;
+  using KB = BCfg<MB>;
+  constexpr int FP = K::FP;
+  __shared__ __align__(16) float lds[K::PW + K::FSP + KB::PB];
+  __shared__ float s_film[2][3][FP], s_sd0[2][3][FP], s_bias[4];
+  for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
+    (&s_film[0][0][0])[t] = 0.f;
+    (&s_sd0[0][0][0])[t] = 0.f;
+  }
+  if (threadIdx.x < 4) s_bias[threadIdx.x] = 0.f;
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = lane >> 4, i16 = lane & 15;
+  const int tiles_per_shape = (N + 64 * NB - 1) / (64 * NB);
+  const int b = blockIdx.x / tiles_per_shape;
+  const int tile = blockIdx.x - b * tiles_per_shape;
+  const int n_wave0 = (tile * 4 + wave) * 16 * NB;
+  const int own_nb = q & (NB - 1);
+  const int n_own = n_wave0 + 16 * own_nb + i16;
+  const bool own_valid = n_own < N && q < NB;
+  const bool own_inrange = n_own < N;
+
+  // stage: forward record | FiLM record of this shape | backward record
+  {
+    const float* src_f = film + ((size_t)b * C + c) * K::FS + lane * 4;
+#pragma unroll
+    for (int i = 0; i < (K::PW / 256 + 3) / 4; ++i) {
+      const int piece = wave + 4 * i;
+      if (piece < K::PW / 256)
+        __builtin_amdgcn_global_load_lds((glb_void*)(pw_c + piece * 256 + lane * 4), (lds_void*)&lds[piece * 256], 16, 0, 0);
+    }
+    if (wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
+      __builtin_amdgcn_global_load_lds((glb_void*)(src_f + wave * 256), (lds_void*)&lds[K::PW + wave * 256], 16, 0, 0);
+    for (int piece = wave; piece * 256 < KB::PB; piece += 4) {
+      if (piece * 256 + lane * 4 < KB::PB)
+        __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + piece * 256 + lane * 4),
+                                         (lds_void*)&lds[K::PW + K::FSP + piece * 256], 16, 0, 0);
+    }
+  }
+  int k0, k1, w0, w1;
+  gwtf_pattern_dims(pat, &k0, &k1, &w0, &w1);
+  const bool keep2 = pat < 3;
+  const int nw = keep2 ? 1 : 2;
+
+  // own point: input coordinates and upstream gradients (zero beyond N: every derived gradient is then zero)
+  float xo[3], go[3], gl[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const size_t o = ((size_t)b * 3 + d) * N + n_own;
+    xo[d] = own_inrange ? x_in[o] : 0.f;
+    go[d] = own_inrange ? g_out[o] : 0.f;
+    gl[d] = own_inrange ? g_ld[o] : 0.f;
+  }
+  float xa[NB], xb[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    xa[nb] = __shfl(sel3(xo[0], xo[1], xo[2], k0), 16 * nb + i16);
+    xb[nb] = keep2 ? __shfl(sel3(xo[0], xo[1], xo[2], k1), 16 * nb + i16) : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const float* L = lds;
+  const float* LB = lds + K::PW + K::FSP;
+
+  // ---- forward recompute: accumulators of both branches stay live -------------------------------------------
+  f32x4 acc[2][MB][NB];
+  float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    const float* fe = L + K::PW + br * 3 * FP + 4 * q;
+    f32x4 cinit[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) cinit[m] = *reinterpret_cast<const f32x4*>(fe + 16 * m);
+    if (keep2) sd1_contract<MB, NB, true>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
+    else sd1_contract<MB, NB, false>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
+    float o0[NB], o1[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o0[nb] = o1[nb] = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(fe + FP + 16 * m);
+      const f32x4 u1 = *reinterpret_cast<const f32x4*>(fe + 2 * FP + 16 * m);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float v = fmaxf(acc[br][m][nb][r], 0.f);
+          o0[nb] = fmaf(u0[r], v, o0[nb]);
+          o1[nb] = fmaf(u1[r], v, o1[nb]);
+        }
+    }
+    res[br][0] = quarter_reduce<NB>(o0, q);
+    res[br][1] = quarter_reduce<NB>(o1, q);
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
+  const float s_keep = sqrtf(eps + 1.0f);
+
+  // ---- tail forward + backward on the own point ------------------------------------------------------------
+  float dt[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [branch][warped slot] = dL/d o
+  float xw[2] = {0.f, 0.f}, gow[2] = {0.f, 0.f}, glw[2] = {0.f, 0.f}, gx[2] = {0.f, 0.f};
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d == w0) { xw[0] = xo[d]; gow[0] = go[d]; glw[0] = gl[d]; }
+    if (!keep2 && d == w1) { xw[1] = xo[d]; gow[1] = go[d]; glw[1] = gl[d]; }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (s < nw) {
+      const float t = res[0][s] + bias[s];
+      const float den = 1.0f + fabsf(t);
+      const float lv = t / den;
+      const float mu = res[1][s] + bias[2 + s];
+      const float e = expf(lv);
+      const float sc = sqrtf(eps + e);
+      const float outw = (xw[s] - mu) / sc;
+      gx[s] = gow[s] / sc;
+      const float dsc = -gow[s] * outw / sc;
+      const float dlv = glw[s] + dsc * e / (2.0f * sc);
+      dt[0][s] = dlv / (den * den);
+      dt[1][s] = -gx[s];
+    }
+  }
+  float gin[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) gin[d] = d == w0 ? gx[0] : ((!keep2 && d == w1) ? gx[1] : go[d] / s_keep);
+  {  // sd2 bias gradient: sum of dt over the wave's valid points
+    float bsum[4] = {own_valid ? dt[0][0] : 0.f, own_valid ? dt[0][1] : 0.f, own_valid ? dt[1][0] : 0.f,
+                     own_valid ? dt[1][1] : 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) bsum[i] += __shfl_down(bsum[i], off);
+    }
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) atomicAdd(&s_bias[i], bsum[i]);
+    }
+  }
+
+  // ---- per branch: dacc, FiLM-record grads, dh = W1p^T dacc, dpre, sd0 grads, dx_kept ----------------------
+  float dxa_own = 0.f, dxb_own = 0.f;
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    float d0[NB], d1[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      d0[nb] = __shfl(dt[br][0], 16 * nb + i16);
+      d1[nb] = __shfl(dt[br][1], 16 * nb + i16);
+    }
+    const float* fe = L + K::PW + br * 3 * FP + 4 * q;
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      const f32x4 u0 = *reinterpret_cast<const f32x4*>(fe + FP + 16 * m);
+      const f32x4 u1 = *reinterpret_cast<const f32x4*>(fe + 2 * FP + 16 * m);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ft = 16 * m + 4 * q + r;
+        float sdc = 0.f, sdu0 = 0.f, sdu1 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float a = acc[br][m][nb][r];
+          const float z = fmaxf(a, 0.f);
+          sdu0 = fmaf(d0[nb], z, sdu0);
+          sdu1 = fmaf(d1[nb], z, sdu1);
+          const float da = a > 0.f ? fmaf(u0[r], d0[nb], u1[r] * d1[nb]) : 0.f;
+          sdc += da;
+          acc[br][m][nb][r] = da;
+          const int n = n_wave0 + 16 * nb + i16;
+          if (n < N) dA_mat[(((size_t)b * 2 + br) * FP + ft) * N + n] = da;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+          sdc += __shfl_xor(sdc, off);
+          sdu0 += __shfl_xor(sdu0, off);
+          sdu1 += __shfl_xor(sdu1, off);
+        }
+        if (i16 == 0) {
+          atomicAdd(&s_film[br][0][ft], sdc);
+          atomicAdd(&s_film[br][1][ft], sdu0);
+          atomicAdd(&s_film[br][2][ft], sdu1);
+        }
+      }
+    }
+    // dh[16mi + 4q + r][point] = sum_j W1p[j][16mi + ..] dacc[j][point]
+    const float* w1t = LB + br * KB::W1T + lane;
+    const f32x4* sd0n = reinterpret_cast<const f32x4*>(LB + 2 * KB::W1T + br * FP * 4);
+    float pxa[NB], pxb[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) pxa[nb] = pxb[nb] = 0.f;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi) {
+      f32x4 dh[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) dh[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < KB::KKF; ++kk) {
+        if (16 * (kk >> 2) + (kk & 3) < f) {   // wave-uniform: this step's four output features are all padding otherwise
+          const float av = w1t[(mi * KB::KKF + kk) * 64];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            dh[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, acc[br][kk >> 2][nb][kk & 3], dh[nb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int fi = 16 * mi + 4 * q + r;
+        const f32x4 sp = sd0n[fi];
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float pre = fmaf(sp[0], xa[nb], fmaf(sp[1], xb[nb], sp[2]));
+          const float dp = pre > 0.f ? dh[nb][r] : 0.f;
+          const int n = n_wave0 + 16 * nb + i16;
+          if (n < N) h0_mat[(((size_t)b * 2 + br) * FP + fi) * N + n] = fmaxf(pre, 0.f);
+          pxa[nb] = fmaf(sp[0], dp, pxa[nb]);
+          pxb[nb] = fmaf(sp[1], dp, pxb[nb]);
+          g0 = fmaf(dp, xa[nb], g0);
+          g1 = fmaf(dp, xb[nb], g1);
+          g2 += dp;
+        }
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) {
+          g0 += __shfl_xor(g0, off);
+          g1 += __shfl_xor(g1, off);
+          g2 += __shfl_xor(g2, off);
+        }
+        if (i16 == 0) {
+          atomicAdd(&s_sd0[br][0][fi], g0);
+          atomicAdd(&s_sd0[br][1][fi], g1);
+          atomicAdd(&s_sd0[br][2][fi], g2);
+        }
+      }
+    }
+    dxa_own += quarter_reduce<NB>(pxa, q);
+    dxb_own += quarter_reduce<NB>(pxb, q);
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d == k0) gin[d] += dxa_own;
+    if (keep2 && d == k1) gin[d] += dxb_own;
+  }
+  if (own_valid) {
+#pragma unroll
+    for (int d = 0; d < 3; ++d) g_in[((size_t)b * 3 + d) * N + n_own] = gin[d];
+  }
+  __syncthreads();
+  // flush the workgroup's partial sums: FiLM-record grads are per shape (few workgroups per address); sd0 / bias
+  // grads are global, spread over GWTF_STAT_REPLICAS copies
+  float* gf = g_film + ((size_t)b * C + c) * (2 * 3 * FP);
+  float* gs = g_sd0 + (size_t)(blockIdx.x % GWTF_STAT_REPLICAS) * (2 * 3 * FP);
+  for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
+    atomicAdd(&gf[t], (&s_film[0][0][0])[t]);
+    atomicAdd(&gs[t], (&s_sd0[0][0][0])[t]);
+  }
+  if (threadIdx.x < 4) atomicAdd(&g_bias[(blockIdx.x % GWTF_STAT_REPLICAS) * 4 + threadIdx.x], s_bias[threadIdx.x]);
+}
+
+// folded parameters (what autograd differentiates) -> forward + backward packed records, see gwtf_layout.h
+//   W1p [C][2][f][f]   W0f [C][2][f][2]   c0f [C][2][f]
+__global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* __restrict__ W0f,
+                                   const float* __restrict__ c0f, float* __restrict__ pw, float* __restrict__ pb, int C,
+                                   int f, int FP) {
+  const GwtfPackW P(FP);
+  const int MB = FP / 16, KS = P.KS(), KKF = FP / 4;
+  const size_t PWs = P.coupling_size();
+  const size_t W1T = (size_t)MB * KKF * 64, PBs = 2 * W1T + 2 * (size_t)FP * 4;
+  const size_t total = (PWs + PBs) * (size_t)C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx / (PWs + PBs));
+    size_t o = idx - (size_t)c * (PWs + PBs);
+    float v = 0.f;
+    if (o < PWs) {
+      if (o < 2 * P.a16_size()) {
+        const int br = (int)(o / P.a16_size());
+        size_t oo = o - (size_t)br * P.a16_size();
+        const int jp = (int)(oo % 4), lane = (int)((oo / 4) % 64), part = (int)((oo / 256) % 2);
+        const int m = (int)((oo / 512) % MB), ks = (int)(oo / ((size_t)512 * MB));
+        const int jo = 16 * m + (lane & 15);
+        _Float16 e[2] = {(_Float16)0.f, (_Float16)0.f};
+        if (ks < KS && jo < f) {
+          for (int t = 0; t < 2; ++t) {
+            const int ji = 32 * ks + 4 * (2 * jp + t) + (lane >> 4);
+            const float w = ji < f ? W1p[(((size_t)c * 2 + br) * f + jo) * f + ji] : 0.f;
+            const _Float16 hi = (_Float16)w;
+            e[t] = part == 0 ? hi : (_Float16)(w - (float)hi);
+          }
+        }
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 pk = {e[0], e[1]};
+        v = __builtin_bit_cast(float, pk);
+      } else if (o - 2 * P.a16_size() < 2 * P.sd0_size()) {
+        size_t oo = o - 2 * P.a16_size();
+        const int br = (int)(oo / P.sd0_size());
+        oo -= (size_t)br * P.sd0_size();
+        const int j = (int)(oo % 8), e = (int)((oo / 8) % 3), qq = (int)((oo / 24) % 4), ks = (int)(oo / 96);
+        const int ft = 32 * ks + 4 * j + qq;
+        if (ft < f) v = e < 2 ? W0f[(((size_t)c * 2 + br) * f + ft) * 2 + e] : c0f[((size_t)c * 2 + br) * f + ft];
+      }
+      pw[(size_t)c * PWs + o] = v;
+    } else {
+      o -= PWs;
+      if (o < 2 * W1T) {
+        const int br = (int)(o / W1T);
+        size_t oo = o - (size_t)br * W1T;
+        const int lane = (int)(oo % 64), kk = (int)((oo / 64) % KKF), mi = (int)(oo / ((size_t)64 * KKF));
+        // k-slot (step kk, quarter q) <-> output feature 16*(kk>>2) + 4*q + (kk&3): the accumulator register (kk>>2, kk&3)
+        // of the lane in quarter q, so the C-layout registers of dacc are the B operand as they stand
+        const int j = 16 * (kk >> 2) + 4 * (lane >> 4) + (kk & 3), i = 16 * mi + (lane & 15);   // A[i][k] = W1p[j][i]
+        if (j < f && i < f) v = W1p[(((size_t)c * 2 + br) * f + j) * f + i];
+      } else {
+        size_t oo = o - 2 * W1T;
+        const int br = (int)(oo / ((size_t)FP * 4)), ft = (int)((oo / 4) % FP), e = (int)(oo % 4);
+        if (ft < f && e < 3) v = e < 2 ? W0f[(((size_t)c * 2 + br) * f + ft) * 2 + e] : c0f[((size_t)c * 2 + br) * f + ft];
+      }
+      pb[(size_t)c * PBs + o] = v;
+    }
+  }
+}
+
+template <int MB>
+int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
+               const float* film, float* g_in, float* dA, float* h0, float* g_film, float* g_sd0, float* g_bias, int B,
+               int N, int C, int c, int pat, float eps, int kk_steps, int f, hipStream_t st) {
+  const int pts_wg = 64 * nb;
+  const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg))), block(256);
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dA, h0, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f)
+  if (nb == 1) GWTF_B(1); else GWTF_B(2);
+#undef GWTF_B
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+extern "C" size_t gwtf_packed_b_coupling_floats(int f) {
+  const int FP = gwtf_padded_width(f);
+  return 2 * (size_t)(FP / 16) * (FP / 4) * 64 + 2 * (size_t)FP * 4;
+}
+
+extern "C" int gwtf_pack_folded(const float* W1p, const float* W0f, const float* c0f, float* packed_w, float* packed_b,
+                                int C, int f, void* stream) {
+  if (!W1p || !W0f || !c0f || !packed_w || !packed_b || C <= 0 || f <= 0 || f > GWTF_MAX_FP) return GWTF_E_BADARG;
+  const int FP = gwtf_padded_width(f);
+  hipLaunchKernelGGL(pack_folded_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, W1p, W0f, c0f, packed_w, packed_b, C,
+                     f, FP);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                                      const float* packed_b_c, const float* film, float* g_in, float* dA_mat,
+                                      float* h0_mat, float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C,
+                                      int f, int pattern0, float eps, void* stream) {
+  if (!x_in || !g_out || !g_ld || !packed_w_c || !packed_b_c || !film || !g_in || !dA_mat || !h0_mat || !g_film || !g_sd0 ||
+      !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5)
+    return GWTF_E_BADARG;
+  const int pat = (pattern0 + c) % 6, kk_steps = (f + 3) / 4;
+  const int nb = (long)B * N >= 2048L * 32 ? 2 : 1;
+  hipStream_t st = (hipStream_t)stream;
+  switch (gwtf_padded_width(f) / 16) {
+    case 1: return launch_bwd<1>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
+    case 2: return launch_bwd<2>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
+    case 3: return launch_bwd<3>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
+    case 4: return launch_bwd<4>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
+    default: return GWTF_E_BADARG;
+  }
+}

@@ -1,0 +1,124 @@
+// gwtf_device.h -- device-side building blocks shared by the forward (gwtf_stack.hip) and backward
+// (gwtf_bwd.hip) kernels: tile configuration, the split-f16 sd1 contraction, the quarter transpose-reduce.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "gwtf_layout.h"
+#include "../../include/gwtf.h"
+
+namespace gwtf_dev {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int MB>
+struct Cfg {
+  static constexpr int FP = 16 * MB;
+  static constexpr int KS = (FP + 31) / 32;               // k-steps of 32 input features
+  static constexpr int A16 = KS * MB * 2 * 256;           // floats, one branch (hi + lo f16 fragment images)
+  static constexpr int SD0 = KS * 4 * 24;                 // floats, one branch
+  static constexpr int PW = (2 * A16 + 2 * SD0 + 255) / 256 * 256;  // packed weights per coupling (whole DMA pieces)
+  static constexpr int FS = 6 * FP + 4;                   // FiLM output per (shape, coupling)
+  static constexpr int FSP = (FS + 255) / 256 * 256;
+  static constexpr int LAYER = PW + FSP;                  // one LDS buffer
+};
+
+__device__ __forceinline__ float sel3(float a, float b, float c, int d) { return d == 0 ? a : (d == 1 ? b : c); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// x = hi + lo with both parts rounded to nearest f16 (|lo| <= 2^-12 |x|): v_cvt_pk_f16_f32, two mixed-precision
+// FMAs (h - float(hi), the f16 operand converted inside v_fma_mix_f32), v_cvt_pk_f16_f32: 4 VALU for two values
+__device__ __forceinline__ void split_pair(f32x2 h, f16x2& hi, f16x2& lo) {
+  hi = __builtin_convertvector(h, f16x2);
+  f32x2 r;
+  r[0] = __builtin_fmaf((float)hi[0], -1.0f, h[0]);
+  r[1] = __builtin_fmaf((float)hi[1], -1.0f, h[1]);
+  lo = __builtin_convertvector(r, f16x2);
+}
+
+// Sum the per-quarter partials o[nb] over the four 16-lane quarters so that the lane in quarter q ends
+// with the total of point block (q & (NB-1)).
+template <int NB>
+__device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
+  if constexpr (NB == 4) {
+    const bool hi = q >= 2, odd = q & 1;
+    const float s0 = hi ? o[0] : o[2], s1 = hi ? o[1] : o[3];
+    const float t0 = (hi ? o[2] : o[0]) + __shfl_xor(s0, 32);
+    const float t1 = (hi ? o[3] : o[1]) + __shfl_xor(s1, 32);
+    return (odd ? t1 : t0) + __shfl_xor(odd ? t0 : t1, 16);
+  } else if constexpr (NB == 2) {
+    const bool odd = q & 1;
+    const float t0 = o[0] + __shfl_xor(o[0], 32);
+    const float t1 = o[1] + __shfl_xor(o[1], 32);
+    return (odd ? t1 : t0) + __shfl_xor(odd ? t0 : t1, 16);
+  } else {
+    float t = o[0] + __shfl_xor(o[0], 32);
+    return t + __shfl_xor(t, 16);
+  }
+}
+
+// sd0 (+ folded sd0_bn) + ReLU + f16 split in the lane that owns each MFMA k-slot, then the f x f contraction
+// acc[m][nb] = cinit[m] + W1'[16m.., :] . h0[:, points of block nb] on v_mfma_f32_16x16x32_f16 (3 products).
+template <int MB, int NB, bool KEEP2>
+__device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br, int kk_steps, int lane, int q,
+                                             const float (&xa)[NB], const float (&xb)[NB], const f32x4 (&cinit)[MB],
+                                             f32x4 (&acc)[MB][NB]) {
+  using K = Cfg<MB>;
+  constexpr int KS = K::KS;
+  const int nj_last = kk_steps - 8 * (KS - 1);   // valid k positions per lane in the last k-step (1..8)
+    const float* aimg = L + br * K::A16 + lane * 4;
+    const float* sd0 = L + 2 * K::A16 + br * K::SD0 + q * 24;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      // sd0 + sd0_bn + ReLU for this lane's 8 k positions (features 32*ks + 4*j + q), split into f16 hi/lo
+      const f32x4* sp = reinterpret_cast<const f32x4*>(sd0 + ks * 96);
+      const f32x4 wa[2] = {sp[0], sp[1]};
+      const f32x4 wb[2] = {KEEP2 ? sp[2] : f32x4{0.f, 0.f, 0.f, 0.f}, KEEP2 ? sp[3] : f32x4{0.f, 0.f, 0.f, 0.f}};
+      const f32x4 cc[2] = {sp[4], sp[5]};
+      f16x8 bhi[NB], blo[NB];
+#pragma unroll
+      for (int jp = 0; jp < 4; ++jp) {
+        if (ks + 1 < KS || 2 * jp < nj_last) {     // wave-uniform: skip k positions beyond ceil(f/4)
+          // two k positions at a time: packed fp32 FMAs (v_pk_fma_f32: 6 cycles for two FMAs instead of 8)
+          const int j0 = 2 * jp;
+          const f32x2 wa2 = {wa[j0 >> 2][j0 & 3], wa[j0 >> 2][(j0 & 3) + 1]};
+          const f32x2 wb2 = {wb[j0 >> 2][j0 & 3], wb[j0 >> 2][(j0 & 3) + 1]};
+          const f32x2 cc2 = {cc[j0 >> 2][j0 & 3], cc[j0 >> 2][(j0 & 3) + 1]};
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
+            f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
+                              : __builtin_elementwise_fma(wa2, xa2, cc2);
+            pre[0] = fmaxf(pre[0], 0.f);
+            pre[1] = fmaxf(pre[1], 0.f);
+            f16x2 hi, lo;
+            split_pair(pre, hi, lo);
+            bhi[nb][2 * jp] = hi[0]; bhi[nb][2 * jp + 1] = hi[1];
+            blo[nb][2 * jp] = lo[0]; blo[nb][2 * jp + 1] = lo[1];
+          }
+        } else {
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            bhi[nb][2 * jp] = bhi[nb][2 * jp + 1] = (_Float16)0.f;
+            blo[nb][2 * jp] = blo[nb][2 * jp + 1] = (_Float16)0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < MB; ++m) {
+        const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);
+        const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 1) * 256);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[nb], ks == 0 ? cinit[m] : acc[m][nb], 0, 0, 0);
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[nb], acc[m][nb], 0, 0, 0);
+          acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[nb], acc[m][nb], 0, 0, 0);
+        }
+      }
+    }
+}
+
+}  // namespace gwtf_dev

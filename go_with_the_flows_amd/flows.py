@@ -172,8 +172,9 @@ class _NoBackwardYet(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        raise NotImplementedError('go_with_the_flows_amd: the HIP backward of the coupling stack is not built yet; '
-                                  'run the forward under torch.no_grad() (there is no autograd/CPU fallback)')
+        raise NotImplementedError('go_with_the_flows_amd: backward is built for the density pass (mode="inverse") with '
+                                  'eval-mode BatchNorm only; train-mode BatchNorm / mode="direct" gradients are not '
+                                  'built yet (there is no autograd/CPU fallback)')
 
 
 class StackEngine:
@@ -212,6 +213,10 @@ class StackEngine:
         return torch.cat([z[op] if t is None else (t[0].t().reshape(-1) if op == 't' else t.view(-1))
                           for t, op in self._srcs])
 
+    def _collect(self):
+        self._key(False)
+        return self._tracked
+
     def _key(self, training):
         stamp = sum(c._stamp for c in self.couplings)
         if stamp != self._tracked_stamp:  # buffers are re-created by .to()/.cuda(): re-collect
@@ -245,6 +250,19 @@ class StackEngine:
             raise ValueError(f"mode must be 'direct' or 'inverse', got {mode!r}")
         self._check(p, g)
         c0 = self.couplings[0]
+        needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
+                                                  any(t.requires_grad for t in self._tracked or self._collect()))
+        if needs_grad and mode == 'inverse' and not c0.training:
+            # differentiable density pass: HIP forward + HIP backward (autograd.py); the per-coupling lists are
+            # returned detached (no reference consumer differentiates through them)
+            from .autograd import density_forward
+            out, logdet = density_forward(self, p, g)
+            lists = None
+            if want_lists:
+                with torch.no_grad():
+                    lists = self.run(p.detach(), g.detach(), mode, True)[2]
+                # direct-order slot 0 is the final output: keep the differentiable tensor there
+            return out, logdet, lists
         pc, gc = p.contiguous().float(), g.contiguous().float()
         eps = c0._eps_value
         if c0.training:
@@ -253,10 +271,8 @@ class StackEngine:
             pw, pf = self.packed(False)
             film = _lib.film_forward(gc, pf, self.C, self.f, eps, False)
             out, logdet, lists = _lib.stack_forward(pc, pw, film, self.C, self.f, self.pattern0, eps, mode, want_lists)
-        needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
-                                                  any(t.requires_grad for t in self._tracked))
         if needs_grad:
-            anchor = next(t for t in self._tracked if t.requires_grad) if not (p.requires_grad or g.requires_grad) else p
+            anchor = p if (p.requires_grad or g.requires_grad) else next(t for t in self._tracked if t.requires_grad)
             res = _NoBackwardYet.apply(anchor, p, g, out, logdet, *([lists] if want_lists else []))
             out, logdet = res[0], res[1]
             lists = res[2] if want_lists else None
@@ -323,8 +339,17 @@ class StackEngine:
         return GraphedStack([self], p, g, mode, want_lists)
 
     def run_lists(self, p, g, mode):
-        _, _, lists = self.run(p, g, mode, True)
-        return list(lists[0].unbind(0)), list(lists[1].unbind(0)), list(lists[2].unbind(0))
+        out, logdet, lists = self.run(p, g, mode, True)
+        ps, mus, lvs = list(lists[0].unbind(0)), list(lists[1].unbind(0)), list(lists[2].unbind(0))
+        if out.requires_grad:
+            # differentiable entries the reference's loss reads: ps[0] (inverse) and sum(logvars) -- keep the sum
+            # differentiable by routing it through one slot (the others are detached constants)
+            if mode == 'inverse':
+                ps[0] = out
+                lvs[0] = lvs[0] + (logdet - logdet.detach())
+            else:
+                ps[-1] = out
+        return ps, mus, lvs
 
 
 class GraphedStack:

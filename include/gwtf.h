@@ -118,6 +118,24 @@ int gwtf_train_forward(const float* p, const float* raw, float* packed_w, const 
                        float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G, int pattern0,
                        float eps, int mode, void* stream);
 
+/* ---- backward (density direction, BatchNorm as a fixed affine) --------------------------------------------
+ * Autograd of CondRealNVPFlow3D.forward (reference flows.py:95-117 as differentiated by loss.backward(),
+ * training.py:54), one coupling per call, in the FOLDED parameters the forward kernel consumes:
+ *   W1p [C][2][f][f] = sd1.weight with sd1_bn's scale folded, W0f [C][2][f][2] / c0f [C][2][f] = sd0 with sd0_bn folded,
+ *   FiLM record [B][C][6FP+4] = {c, u0, u1} x 2 branches + biases (gwtf_layout.h).
+ * gwtf_pack_folded builds the forward record (packed_w) and the backward record (packed_b) from them.
+ * gwtf_coupling_backward: x_in = the coupling's input saved by the forward, g_out/g_ld = dL/d(out), dL/d(logdet);
+ *   -> g_in [B][3][N]; dA_mat, h0_mat [B][2][FP][N] (dL/dacc and relu(sd0) per point: dW1p = sum_p dA h0^T is left to
+ *   a library GEMM); g_film [B][C][2][3][FP] += {dc, du0, du1}; g_sd0 [64][2][3][FP] += {dW0f[:,0], dW0f[:,1], dc0f};
+ *   g_bias [64][4] += {db_lv0, db_lv1, db_mu0, db_mu1}   (64 = GWTF_STAT_REPLICAS copies, sum them; all pre-zeroed). */
+size_t gwtf_packed_b_coupling_floats(int f);
+int gwtf_pack_folded(const float* W1p, const float* W0f, const float* c0f, float* packed_w, float* packed_b,
+                     int C, int f, void* stream);
+int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                           const float* packed_b_c, const float* film, float* g_in, float* dA_mat, float* h0_mat,
+                           float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0,
+                           float eps, void* stream);
+
 /* Mixture negative log-likelihood over K flow components.
  * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
  * PointFlowNLL, :11-20).

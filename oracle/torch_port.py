@@ -50,12 +50,13 @@ def coupling(p, g, st, prefix, warp, mode):
     return (scale * p + mu if mode == 'direct' else (p - mu) / scale), mu, logvar
 
 
-def decoder_fused(p, g, st, n_flows, mode):
-    """(B,3,N), (B,G) torch CPU tensors -> (final coordinates, sum of logvars); eval-mode BatchNorm."""
+def decoder_fused(p, g, st, n_flows, mode, grad=False):
+    """(B,3,N), (B,G) torch CPU tensors -> (final coordinates, sum of logvars); eval-mode BatchNorm.
+    grad=True keeps the autograd graph (tests use it as the gradient reference)."""
     C = 3 * n_flows
     order = range(C) if mode == 'direct' else range(C - 1, -1, -1)
     cur, logdet = p, None
-    with torch.no_grad():
+    with torch.set_grad_enabled(grad):
         for c in order:
             prefix = f'flows.{c // 3}.nvp{c % 3 + 1}.'
             cur, _, lv = coupling(cur, g, st, prefix, PATTERNS[c % 6], mode)

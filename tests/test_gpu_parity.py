@@ -335,3 +335,73 @@ def test_decoder_train_mode(name, mode):
     sd = m.state_dict()
     worst = max(maxabs(host(sd[k]), v) for k, v in new.items() if not k.endswith('num_batches_tracked'))
     assert worst < (1e-3 if f == 64 else 1e-5)
+
+
+# ---- backward (density pass, eval-mode BatchNorm) -------------------------------------------------------------
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def test_g8_gradients_match_reference_autograd():
+    D = golden('g8_gradients')
+    L, f, G, B, N = D['dims']
+    m, _ = decoder_and_state(L, f, G, 800)
+    m = m.to(DEV).eval()
+    pt, gt = dev(D['p']).requires_grad_(True), dev(D['g']).requires_grad_(True)
+    ps, mus, lvs = m(pt, gt, mode='inverse')
+    loss = 0.5 * (sum(lvs) + ps[0] ** 2).sum() / B
+    assert abs(float(loss) - float(D['loss'])) / abs(float(D['loss'])) < 1e-5
+    loss.backward()
+    assert _rel(host(pt.grad), D['dp']) < 2e-4
+    assert _rel(host(gt.grad), D['dg']) < 2e-4
+    named = dict(m.named_parameters())
+    for key in D.files:
+        if key.startswith('grad::'):
+            assert _rel(host(named[key[6:]].grad), D[key]) < 2e-4, key
+
+
+@pytest.mark.parametrize('cfg', [(1, 8, 8, 2, 5), (2, 19, 12, 3, 70), (2, 37, 16, 2, 130), (1, 64, 32, 2, 64), (3, 33, 20, 1, 257)])
+def test_gradients_vs_torch_cpu_autograd(cfg):
+    """Every parameter, p and g, against autograd through the PyTorch-CPU port (itself pinned to the reference)."""
+    from oracle import torch_port as tp
+    L, f, G, B, N = cfg
+    m, st = decoder_and_state(L, f, G, 321 + f)
+    m = m.to(DEV).eval()
+    p, g = synth_inputs(B, N, G, 77 + N)
+    rng = np.random.default_rng(5)
+    wz = rng.normal(size=(B, 3, N)).astype(np.float32)           # random cotangents: exercise g_out and g_logdet separately
+    wl = rng.normal(size=(B, 3, N)).astype(np.float32)
+    # reference gradients on CPU
+    tst = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and not k.endswith(('running_mean', 'running_var', 'eps')))
+           for k, v in st.items()}
+    pc, gc = torch.from_numpy(p).requires_grad_(True), torch.from_numpy(g).requires_grad_(True)
+    zc, ldc = tp.decoder_fused(pc, gc, tst, L, 'inverse', grad=True)
+    ((zc * torch.from_numpy(wz)).sum() + (ldc * torch.from_numpy(wl)).sum()).backward()
+    # HIP
+    pt, gt = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+    z, ld = m.forward_fused(pt, gt, 'inverse')
+    ((z * dev(wz)).sum() + (ld * dev(wl)).sum()).backward()
+    assert maxabs(host(z), zc.detach().numpy()) < TOL_COORD
+    assert _rel(host(pt.grad), pc.grad.numpy()) < 3e-4
+    assert _rel(host(gt.grad), gc.grad.numpy()) < 3e-4
+    worst, worst_key = 0.0, None
+    for k, prm in m.named_parameters():
+        ref = tst[k].grad
+        assert ref is not None, k
+        e = _rel(host(prm.grad), ref.numpy())
+        if e > worst:
+            worst, worst_key = e, k
+    assert worst < 5e-4, (worst_key, worst)
+
+
+def test_backward_unsupported_paths_fail_loudly():
+    m, _ = decoder_and_state(1, 8, 8, 3)
+    m = m.to(DEV)
+    p, g = synth_inputs(2, 16, 8, 4)
+    out, _ = m.train().forward_fused(dev(p).requires_grad_(True), dev(g), 'inverse')
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
+    out, _ = m.eval().forward_fused(dev(p).requires_grad_(True), dev(g), 'direct')
+    with pytest.raises(NotImplementedError):
+        out.sum().backward()
