@@ -40,6 +40,7 @@ _SIGNATURES = {
     'gwtf_packed_b_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_pack_folded': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 6 + [ctypes.c_float, _c_fp]),
+    'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 4 + [_c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
 }

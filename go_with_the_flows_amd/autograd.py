@@ -159,3 +159,211 @@ def density_forward(engine, p, g):
     eps = engine.couplings[0]._eps_value
     W0f, c0f, W1p, cvec, u, b2 = fold(engine, g.float(), eps)
     return StackDensityFn.apply(p.float(), W0f, c0f, W1p, cvec, u, b2, engine.C, engine.f, engine.pattern0, eps)
+
+
+# ======================================================================================================================
+# Train mode: batch-statistic BatchNorm.  The statistics make every coupling depend on global reductions of its own
+# input, so the differentiable path is a chain of small autograd nodes per coupling (reference flows.py:27,30,62,65 under
+# model.train() + loss.backward()):
+#     x --MomentsFn(HIP)--> M --fold0(torch)--> W0f,c0f --StatsFn(HIP)--> S --fold1(torch)--> c,u --ApplyFn(HIP)--> x', lv
+# Autograd sums the three contributions to dL/dx (apply, statistics of y1, moments of x) and the two contributions to the
+# sd0/sd1 weights; each HIP node's backward is one launch of csrc/gwtf_bwd.hip (+ the dW1 GEMM).
+# ======================================================================================================================
+def _pack_single(W1, W0f, c0f, f):
+    L = _lib.lib()
+    dev = W1.device
+    pw = torch.empty(L.gwtf_packed_w_coupling_floats(f), device=dev, dtype=torch.float32)
+    pb = torch.empty(L.gwtf_packed_b_coupling_floats(f), device=dev, dtype=torch.float32)
+    w1, w0, c0 = W1.detach().contiguous(), W0f.detach().contiguous(), c0f.detach().contiguous()
+    with torch.cuda.device(dev):
+        _lib.check(L.gwtf_pack_folded(w1.data_ptr(), w0.data_ptr(), c0.data_ptr(), pw.data_ptr(), pb.data_ptr(), 1, f,
+                                      torch.cuda.current_stream(dev).cuda_stream))
+    return pw, pb
+
+
+class MomentsFn(torch.autograd.Function):
+    """x (B,3,N) -> the 9 first/second moments summed over all points {Sx0..2, Sx0x0, Sx0x1, Sx0x2, Sx1x1, Sx1x2, Sx2x2}."""
+
+    @staticmethod
+    def forward(ctx, x):
+        L = _lib.lib()
+        x = x.contiguous()
+        B, _, N = x.shape
+        mom = torch.zeros(_lib.STAT_REPLICAS, 16, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(L.gwtf_train_moments(x.data_ptr(), mom.data_ptr(), B, N, _lib._stream(x)))
+        ctx.save_for_backward(x)
+        return mom.sum(0)[:9]
+
+    @staticmethod
+    def backward(ctx, gM):
+        (x,) = ctx.saved_tensors
+        Q = x.new_zeros(3, 3)
+        idx = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+        for k, (a, b) in enumerate(idx):
+            if a == b:
+                Q[a, a] = 2.0 * gM[3 + k]
+            else:
+                Q[a, b] = gM[3 + k]
+                Q[b, a] = gM[3 + k]
+        return gM[:3].view(1, 3, 1) + torch.einsum('ab,zbn->zan', Q, x)
+
+
+class StatsFn(torch.autograd.Function):
+    """S[branch][feature][{sum y1, sum y1^2}] over all points, y1 = sd1(relu(W0f x_keep + c0f))  (csrc: stats_kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, W0f, c0f, W1, pw, pb, pat, f):
+        L = _lib.lib()
+        x = x.contiguous()
+        B, _, N = x.shape
+        FP = L.gwtf_padded_width(f)
+        ys = torch.zeros(_lib.STAT_REPLICAS, 2, FP, 2, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _lib.check(L.gwtf_train_stats(x.data_ptr(), pw.data_ptr(), ys.data_ptr(), B, N, f, pat, _lib._stream(x)))
+        ctx.save_for_backward(x, pw, pb)
+        ctx.meta = (pat, f, FP)
+        return ys.sum(0)[:, :f, :]
+
+    @staticmethod
+    def backward(ctx, gS):
+        x, pw, pb = ctx.saved_tensors
+        pat, f, FP = ctx.meta
+        L = _lib.lib()
+        B, _, N = x.shape
+        dev = x.device
+        gst = torch.zeros(2, 2, FP, device=dev, dtype=torch.float32)
+        gst[:, 0, :f] = gS[:, :, 0]
+        gst[:, 1, :f] = gS[:, :, 1]
+        g_x = torch.empty_like(x)
+        dA = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
+        H0 = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
+        g_sd0 = torch.zeros(_lib.STAT_REPLICAS, 2, 3, FP, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.gwtf_stats_backward(x.data_ptr(), gst.data_ptr(), pw.data_ptr(), pb.data_ptr(), g_x.data_ptr(),
+                                             dA.data_ptr(), H0.data_ptr(), g_sd0.data_ptr(), B, N, f, pat, _lib._stream(x)))
+        gW1 = torch.einsum('bkjn,bkin->kji', dA[:, :, :f], H0[:, :, :f])
+        gs = g_sd0.sum(0)
+        return g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1, None, None, None, None
+
+
+class ApplyFn(torch.autograd.Function):
+    """One coupling with given folded parameters: x -> (x_out, logvar, mu[detached])."""
+
+    @staticmethod
+    def forward(ctx, x, W0f, c0f, W1, cvec, u, b2, pw, pb, pat, f, eps):
+        L = _lib.lib()
+        x = x.contiguous()
+        FP = L.gwtf_padded_width(f)
+        rec = film_record(cvec.unsqueeze(1), u.unsqueeze(1), b2.unsqueeze(0), FP)
+        out, lv, lists = _lib.stack_forward(x, pw, rec, 1, f, pat, eps, 'inverse', True)
+        ctx.save_for_backward(x, pw, pb, rec)
+        ctx.meta = (pat, f, FP, eps)
+        ctx.mark_non_differentiable(lists[1][0])
+        return out, lv, lists[1][0]
+
+    @staticmethod
+    def backward(ctx, g_out, g_lv, _g_mu):
+        x, pw, pb, rec = ctx.saved_tensors
+        pat, f, FP, eps = ctx.meta
+        L = _lib.lib()
+        B, _, N = x.shape
+        dev = x.device
+        R = _lib.STAT_REPLICAS
+        g_out = (g_out if g_out is not None else torch.zeros_like(x)).contiguous()
+        g_lv = (g_lv if g_lv is not None else torch.zeros_like(x)).contiguous()
+        g_x = torch.empty_like(x)
+        g_film = torch.zeros(B, 1, 2, 3, FP, device=dev, dtype=torch.float32)
+        g_sd0 = torch.zeros(R, 2, 3, FP, device=dev, dtype=torch.float32)
+        g_bias = torch.zeros(R, 4, device=dev, dtype=torch.float32)
+        dA = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
+        H0 = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.gwtf_coupling_backward(x.data_ptr(), g_out.data_ptr(), g_lv.data_ptr(), pw.data_ptr(), pb.data_ptr(),
+                                                rec.data_ptr(), g_x.data_ptr(), dA.data_ptr(), H0.data_ptr(),
+                                                g_film.data_ptr(), g_sd0.data_ptr(), g_bias.data_ptr(), 0, B, N, 1, f, pat,
+                                                float(eps), _lib._stream(x)))
+        gW1 = torch.einsum('bkjn,bkin->kji', dA[:, :, :f], H0[:, :, :f])
+        gs = g_sd0.sum(0)
+        return (g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1,
+                g_film[:, 0, :, 0, :f].contiguous(), g_film[:, 0, :, 1:3, :f].contiguous(), g_bias.sum(0).reshape(2, 2),
+                None, None, None, None, None)
+
+
+def _film_train(P, g, eps):
+    """FiLM heads with batch statistics over the B latent rows -> a, bsh (B,C,2,f) and batch {mean, unbiased var}."""
+    hg, hb, _, _ = P['hbn']
+    hraw = torch.einsum('bg,cxhfg->bcxhf', g, P['L0'])
+    Bn = hraw.shape[0]
+    mean = hraw.mean(0)
+    var = hraw.var(0, unbiased=False)
+    hbn = (hraw - mean) / torch.sqrt(var + BN_EPS) * hg + hb
+    hn = hbn * torch.sigmoid(hbn)
+    o = torch.einsum('bcxhi,cxhji->bcxhj', hn, P['L1']) + P['b1']
+    a = eps + torch.exp(o[:, :, :, 0])
+    return a, o[:, :, :, 1], mean.detach(), (var * (Bn / max(Bn - 1.0, 1.0))).detach()
+
+
+def train_density_forward(engine, p, g, group_sum=None):
+    """Differentiable train-mode density pass.  Returns out, logdet, per-coupling lists (ps, mus, lvs in direct
+    order; ps/lvs differentiable) and bn_batch (C,2,4,2,f) for the running-statistic update."""
+    from .flows import WARP_PATTERNS  # noqa: F401  (pattern table lives there)
+    C, f, eps = engine.C, engine.f, engine.couplings[0]._eps_value
+    B, _, N = p.shape
+    if B < 2:
+        raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
+    P = _gather(engine)
+    a, bsh, fmean, fvar = _film_train(P, g.float(), eps)
+    n = float(B * N)
+    bn_batch = torch.zeros(C, 2, 4, 2, f, device=p.device, dtype=torch.float32)
+    bn_batch[:, :, 2:4, 0] = fmean
+    bn_batch[:, :, 2:4, 1] = fvar
+    g0, be0, _, _ = P['bn0']
+    x = p.float().contiguous()
+    ps, mus, lvs = [None] * C, [None] * C, [None] * C
+    logdet = None
+    for c in range(C - 1, -1, -1):
+        pat = (engine.pattern0 + c) % 6
+        k0, k1 = {0: (1, 2), 1: (0, 2), 2: (0, 1), 3: (2, -1), 4: (1, -1), 5: (0, -1)}[pat]
+        M = MomentsFn.apply(x)
+        if group_sum is not None:
+            M = group_sum(M)
+        # fold0: sd0_bn statistics are analytic in the moments of the kept coordinates (double: E[xx]-E[x]E[x] cancels)
+        Md = M.double()
+        E = Md[:3] / n
+        Sxx = torch.stack([torch.stack([Md[3], Md[4], Md[5]]), torch.stack([Md[4], Md[6], Md[7]]),
+                           torch.stack([Md[5], Md[7], Md[8]])]) / n
+        Cov = Sxx - torch.outer(E, E)
+        kk = [k0] if k1 < 0 else [k0, k1]
+        Ek = torch.zeros(2, dtype=torch.float64, device=p.device)
+        Ck = torch.zeros(2, 2, dtype=torch.float64, device=p.device)
+        Ek = torch.cat([E[kk], Ek[len(kk):]])
+        Ck = torch.nn.functional.pad(Cov[kk][:, kk], (0, 2 - len(kk), 0, 2 - len(kk)))
+        W0 = P['W0'][c].double()                                   # (2,f,2)
+        mean0 = W0 @ Ek
+        var0 = torch.einsum('xfa,ab,xfb->xf', W0, Ck, W0).clamp_min(0.0)
+        s0 = (g0[c].double() / torch.sqrt(var0 + BN_EPS))
+        W0f = (W0 * s0.unsqueeze(-1)).float()
+        c0f = (be0[c].double() - mean0 * s0).float()
+        W1 = P['W1'][c]
+        pw, pb = _pack_single(W1, W0f, c0f, f)
+        S = StatsFn.apply(x, W0f, c0f, W1, pw, pb, pat, f)
+        if group_sum is not None:
+            S = group_sum(S)
+        Sd = S.double()
+        m1 = Sd[..., 0] / n
+        v1 = (Sd[..., 1] / n - m1 * m1).clamp_min(0.0)
+        s1 = (1.0 / torch.sqrt(v1 + BN_EPS)).float()
+        as1 = a[:, c] * s1
+        cvec = -m1.float() + bsh[:, c] / as1
+        u = P['W2'][c].unsqueeze(0) * as1.unsqueeze(2)
+        x, lv, mu = ApplyFn.apply(x, W0f, c0f, W1, cvec, u, P['b2'][c], pw, pb, pat, f, eps)
+        ps[c], mus[c], lvs[c] = x, mu, lv
+        logdet = lv if logdet is None else logdet + lv
+        with torch.no_grad():
+            unb = n / max(n - 1.0, 1.0)
+            bn_batch[c, :, 0, 0] = mean0.float()
+            bn_batch[c, :, 0, 1] = (var0 * unb).float()
+            bn_batch[c, :, 1, 0] = m1.float()
+            bn_batch[c, :, 1, 1] = (v1 * unb).float()
+    return x, logdet, (ps, mus, lvs), bn_batch

@@ -29,14 +29,18 @@ struct BCfg {
   static constexpr int PB = 2 * W1T + 2 * FP * 4;       // + SD0N[2][FP][4]
 };
 
-template <int MB, int NB>
+// STATS = false: backward of the coupling itself.  STATS = true: backward of the train-mode statistics pass
+// (gwtf_train_stats): the upstream is g_stats[branch][{d/dSum y, d/dSum y^2}][FP], i.e. dL/dy(p) = gS + 2 gQ y(p) for every
+// point, y = un-biased accumulator (no FiLM record, no tail); everything after dacc is shared.
+template <int MB, int NB, bool STATS>
 __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
                                                   float* __restrict__ g_in, float* __restrict__ dA_mat,
                                                   float* __restrict__ h0_mat, float* __restrict__ g_film,
-                                                  float* __restrict__ g_sd0, float* __restrict__ g_bias, int B, int N,
-                                                  int C, int c, int pat, float eps, int kk_steps, int f) {
+                                                  float* __restrict__ g_sd0, float* __restrict__ g_bias,
+                                                  const float* __restrict__ g_stats, int B, int N, int C, int c, int pat,
+                                                  float eps, int kk_steps, int f) {
   using K = Cfg<MB>;
   using KB = BCfg<MB>;
   constexpr int FP = K::FP;
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
       if (piece < K::PW / 256)
         __builtin_amdgcn_global_load_lds((glb_void*)(pw_c + piece * 256 + lane * 4), (lds_void*)&lds[piece * 256], 16, 0, 0);
     }
-    if (wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
+    if (!STATS && wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
       __builtin_amdgcn_global_load_lds((glb_void*)(src_f + wave * 256), (lds_void*)&lds[K::PW + wave * 256], 16, 0, 0);
     for (int piece = wave; piece * 256 < KB::PB; piece += 4) {
       if (piece * 256 + lane * 4 < KB::PB)
@@ -87,8 +91,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
   for (int d = 0; d < 3; ++d) {
     const size_t o = ((size_t)b * 3 + d) * N + n_own;
     xo[d] = own_inrange ? x_in[o] : 0.f;
-    go[d] = own_inrange ? g_out[o] : 0.f;
-    gl[d] = own_inrange ? g_ld[o] : 0.f;
+    go[d] = (!STATS && own_inrange) ? g_out[o] : 0.f;
+    gl[d] = (!STATS && own_inrange) ? g_ld[o] : 0.f;
   }
   float xa[NB], xb[NB];
 #pragma unroll
@@ -109,9 +113,10 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     const float* fe = L + K::PW + br * 3 * FP + 4 * q;
     f32x4 cinit[MB];
 #pragma unroll
-    for (int m = 0; m < MB; ++m) cinit[m] = *reinterpret_cast<const f32x4*>(fe + 16 * m);
+    for (int m = 0; m < MB; ++m) cinit[m] = STATS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(fe + 16 * m);
     if (keep2) sd1_contract<MB, NB, true>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
     else sd1_contract<MB, NB, false>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
+    if (STATS) continue;
     float o0[NB], o1[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) o0[nb] = o1[nb] = 0.f;
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     res[br][0] = quarter_reduce<NB>(o0, q);
     res[br][1] = quarter_reduce<NB>(o1, q);
   }
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
+  const f32x4 bias = STATS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
   const float s_keep = sqrtf(eps + 1.0f);
 
   // ---- tail forward + backward on the own point ------------------------------------------------------------
@@ -144,7 +149,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    if (s < nw) {
+    if (!STATS && s < nw) {
       const float t = res[0][s] + bias[s];
       const float den = 1.0f + fabsf(t);
       const float lv = t / den;
@@ -161,8 +166,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
   }
   float gin[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) gin[d] = d == w0 ? gx[0] : ((!keep2 && d == w1) ? gx[1] : go[d] / s_keep);
-  {  // sd2 bias gradient: sum of dt over the wave's valid points
+  for (int d = 0; d < 3; ++d) gin[d] = STATS ? 0.f : (d == w0 ? gx[0] : ((!keep2 && d == w1) ? gx[1] : go[d] / s_keep));
+  if (!STATS) {  // sd2 bias gradient: sum of dt over the wave's valid points
     float bsum[4] = {own_valid ? dt[0][0] : 0.f, own_valid ? dt[0][1] : 0.f, own_valid ? dt[1][0] : 0.f,
                      own_valid ? dt[1][1] : 0.f};
 #pragma unroll
@@ -189,11 +194,23 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     const float* fe = L + K::PW + br * 3 * FP + 4 * q;
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
-      const f32x4 u0 = *reinterpret_cast<const f32x4*>(fe + FP + 16 * m);
-      const f32x4 u1 = *reinterpret_cast<const f32x4*>(fe + 2 * FP + 16 * m);
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 u0 = STATS ? zero4 : *reinterpret_cast<const f32x4*>(fe + FP + 16 * m);
+      const f32x4 u1 = STATS ? zero4 : *reinterpret_cast<const f32x4*>(fe + 2 * FP + 16 * m);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int ft = 16 * m + 4 * q + r;
+        if (STATS) {
+          const float gs = ft < f ? g_stats[(br * 2 + 0) * FP + ft] : 0.f, gq2 = ft < f ? 2.0f * g_stats[(br * 2 + 1) * FP + ft] : 0.f;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int n = n_wave0 + 16 * nb + i16;
+            const float da = n < N ? fmaf(gq2, acc[br][m][nb][r], gs) : 0.f;
+            acc[br][m][nb][r] = da;
+            if (n < N) dA_mat[(((size_t)b * 2 + br) * FP + ft) * N + n] = da;
+          }
+          continue;
+        }
         float sdc = 0.f, sdu0 = 0.f, sdu1 = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -288,10 +305,10 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
   float* gf = g_film + ((size_t)b * C + c) * (2 * 3 * FP);
   float* gs = g_sd0 + (size_t)(blockIdx.x % GWTF_STAT_REPLICAS) * (2 * 3 * FP);
   for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
-    atomicAdd(&gf[t], (&s_film[0][0][0])[t]);
+    if (!STATS) atomicAdd(&gf[t], (&s_film[0][0][0])[t]);
     atomicAdd(&gs[t], (&s_sd0[0][0][0])[t]);
   }
-  if (threadIdx.x < 4) atomicAdd(&g_bias[(blockIdx.x % GWTF_STAT_REPLICAS) * 4 + threadIdx.x], s_bias[threadIdx.x]);
+  if (!STATS && threadIdx.x < 4) atomicAdd(&g_bias[(blockIdx.x % GWTF_STAT_REPLICAS) * 4 + threadIdx.x], s_bias[threadIdx.x]);
 }
 
 // folded parameters (what autograd differentiates) -> forward + backward packed records, see gwtf_layout.h
@@ -356,13 +373,13 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
   }
 }
 
-template <int MB>
+template <int MB, bool STATS>
 int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
-               const float* film, float* g_in, float* dA, float* h0, float* g_film, float* g_sd0, float* g_bias, int B,
-               int N, int C, int c, int pat, float eps, int kk_steps, int f, hipStream_t st) {
+               const float* film, float* g_in, float* dA, float* h0, float* g_film, float* g_sd0, float* g_bias,
+               const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg))), block(256);
-#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dA, h0, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f)
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dA, h0, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B
   return (int)hipGetLastError();
@@ -384,6 +401,24 @@ extern "C" int gwtf_pack_folded(const float* W1p, const float* W0f, const float*
   return (int)hipGetLastError();
 }
 
+static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                        const float* packed_b_c, const float* film, float* g_in, float* dA_mat, float* h0_mat,
+                        float* g_film, float* g_sd0, float* g_bias, const float* g_stats, int c, int B, int N, int C, int f,
+                        int pat, float eps, void* stream) {
+  const int kk_steps = (f + 3) / 4;
+  const int nb = (long)B * N >= 2048L * 32 ? 2 : 1;
+  hipStream_t st = (hipStream_t)stream;
+#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, st
+  switch (gwtf_padded_width(f) / 16) {
+    case 1: return stats ? launch_bwd<1, true>(nb, GWTF_A) : launch_bwd<1, false>(nb, GWTF_A);
+    case 2: return stats ? launch_bwd<2, true>(nb, GWTF_A) : launch_bwd<2, false>(nb, GWTF_A);
+    case 3: return stats ? launch_bwd<3, true>(nb, GWTF_A) : launch_bwd<3, false>(nb, GWTF_A);
+    case 4: return stats ? launch_bwd<4, true>(nb, GWTF_A) : launch_bwd<4, false>(nb, GWTF_A);
+    default: return GWTF_E_BADARG;
+  }
+#undef GWTF_A
+}
+
 extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                       const float* packed_b_c, const float* film, float* g_in, float* dA_mat,
                                       float* h0_mat, float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C,
@@ -391,14 +426,16 @@ extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, con
   if (!x_in || !g_out || !g_ld || !packed_w_c || !packed_b_c || !film || !g_in || !dA_mat || !h0_mat || !g_film || !g_sd0 ||
       !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5)
     return GWTF_E_BADARG;
-  const int pat = (pattern0 + c) % 6, kk_steps = (f + 3) / 4;
-  const int nb = (long)B * N >= 2048L * 32 ? 2 : 1;
-  hipStream_t st = (hipStream_t)stream;
-  switch (gwtf_padded_width(f) / 16) {
-    case 1: return launch_bwd<1>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
-    case 2: return launch_bwd<2>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
-    case 3: return launch_bwd<3>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
-    case 4: return launch_bwd<4>(nb, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, B, N, C, c, pat, eps, kk_steps, f, st);
-    default: return GWTF_E_BADARG;
-  }
+  return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias,
+                      nullptr, c, B, N, C, f, (pattern0 + c) % 6, eps, stream);
+}
+
+extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c,
+                                   const float* packed_b_c, float* g_in, float* dA_mat, float* h0_mat, float* g_sd0, int B,
+                                   int N, int f, int pattern, void* stream) {
+  if (!x_in || !g_stats || !packed_w_c || !packed_b_c || !g_in || !dA_mat || !h0_mat || !g_sd0 || B <= 0 || N <= 0 ||
+      f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5)
+    return GWTF_E_BADARG;
+  return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dA_mat, h0_mat,
+                      g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, stream);
 }

@@ -252,6 +252,18 @@ class StackEngine:
         c0 = self.couplings[0]
         needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
                                                   any(t.requires_grad for t in self._tracked or self._collect()))
+        if needs_grad and mode == 'inverse' and c0.training:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                raise NotImplementedError('differentiable train-mode forward across ranks (SyncBatchNorm gradients) is '
+                                          'not built yet')
+            from .autograd import train_density_forward
+            out, logdet, (ps, mus, lvs), bn_batch = train_density_forward(self, p, g)
+            self._update_running_stats(bn_batch)
+            self._last_lists = (ps, mus, lvs)
+            lists = (torch.stack([t.detach() for t in ps]), torch.stack(mus), torch.stack([t.detach() for t in lvs])) \
+                if want_lists else None
+            return out, logdet, lists
         if needs_grad and mode == 'inverse' and not c0.training:
             # differentiable density pass: HIP forward + HIP backward (autograd.py); the per-coupling lists are
             # returned detached (no reference consumer differentiates through them)
@@ -288,6 +300,23 @@ class StackEngine:
                 mods += [t0[1], t0[4], getattr(c, f'T_{X}_0_cond_w')[1], getattr(c, f'T_{X}_0_cond_b')[1]]
         return mods
 
+    def _update_running_stats(self, bn_batch):
+        """running = (1-m)*running + m*batch with the unbiased batch variance (torch.nn.BatchNorm1d semantics)."""
+        with torch.no_grad():
+            mods = self._bn_modules()
+            flat = bn_batch.reshape(len(mods), 2, self.f)
+            groups = {}
+            for i, m in enumerate(mods):
+                if m.track_running_stats and m.running_mean is not None:
+                    groups.setdefault(0.1 if m.momentum is None else float(m.momentum), []).append(i)
+            for mom, idx in groups.items():
+                rms, rvs = [mods[i].running_mean for i in idx], [mods[i].running_var for i in idx]
+                torch._foreach_mul_(rms, 1.0 - mom)
+                torch._foreach_add_(rms, [flat[i, 0] for i in idx], alpha=mom)
+                torch._foreach_mul_(rvs, 1.0 - mom)
+                torch._foreach_add_(rvs, [flat[i, 1] for i in idx], alpha=mom)
+            torch._foreach_add_([m.num_batches_tracked for m in mods if m.num_batches_tracked is not None], 1)
+
     def _run_train(self, p, g, mode, want_lists):
         """model.train() forward: statistics over all B*N points (and, when torch.distributed is initialised,
         over all ranks -- the reference wraps the model in SyncBatchNorm, train_ae.py:152), running statistics
@@ -308,19 +337,7 @@ class StackEngine:
             out, logdet, lists, bn_batch = _lib.train_forward(p, g, raw, self.C, self.f, self.G, self.pattern0,
                                                               self.couplings[0]._eps_value, mode, want_lists,
                                                               group_sum, g_all, row0)
-            mods = self._bn_modules()
-            flat = bn_batch.reshape(len(mods), 2, self.f)
-            groups = {}
-            for i, m in enumerate(mods):
-                if m.track_running_stats and m.running_mean is not None:
-                    groups.setdefault(0.1 if m.momentum is None else float(m.momentum), []).append(i)
-            for mom, idx in groups.items():
-                rms, rvs = [mods[i].running_mean for i in idx], [mods[i].running_var for i in idx]
-                torch._foreach_mul_(rms, 1.0 - mom)
-                torch._foreach_add_(rms, [flat[i, 0] for i in idx], alpha=mom)
-                torch._foreach_mul_(rvs, 1.0 - mom)
-                torch._foreach_add_(rvs, [flat[i, 1] for i in idx], alpha=mom)
-            torch._foreach_add_([m.num_batches_tracked for m in mods if m.num_batches_tracked is not None], 1)
+            self._update_running_stats(bn_batch)
         return out, logdet, lists
 
     def capture(self, p, g, mode, want_lists=False):
@@ -341,6 +358,10 @@ class StackEngine:
     def run_lists(self, p, g, mode):
         out, logdet, lists = self.run(p, g, mode, True)
         ps, mus, lvs = list(lists[0].unbind(0)), list(lists[1].unbind(0)), list(lists[2].unbind(0))
+        if out.requires_grad and self.couplings[0].training and getattr(self, '_last_lists', None) is not None:
+            dps, dmus, dlvs = self._last_lists          # train mode: every ps[j] / logvars[j] is differentiable
+            self._last_lists = None
+            return list(dps), list(dmus), list(dlvs)
         if out.requires_grad:
             # differentiable entries the reference's loss reads: ps[0] (inverse) and sum(logvars) -- keep the sum
             # differentiable by routing it through one slot (the others are detached constants)

@@ -136,6 +136,12 @@ int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g
                            float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0,
                            float eps, void* stream);
 
+/* Backward of gwtf_train_stats: g_stats [2][2][FP] = dL/d{sum y, sum y^2} per branch and feature (replicas already
+ * summed by the caller) -> g_in (kept coordinates only), dA_mat / h0_mat for the dW1 GEMM, g_sd0 [64][2][3][FP]. */
+int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
+                        float* g_in, float* dA_mat, float* h0_mat, float* g_sd0, int B, int N, int f, int pattern,
+                        void* stream);
+
 /* Mixture negative log-likelihood over K flow components.
  * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
  * PointFlowNLL, :11-20).

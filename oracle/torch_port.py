@@ -13,10 +13,13 @@ import torch.nn.functional as F
 PATTERNS = ((0,), (1,), (2,), (0, 1), (0, 2), (1, 2))
 
 
+_TRAIN = [False]   # set by decoder_fused(training=...): batch statistics (and in-place running-stat updates on `st`)
+
+
 def _bn(x, st, prefix, affine):
     return F.batch_norm(x, st[prefix + 'running_mean'], st[prefix + 'running_var'],
                         st.get(prefix + 'weight') if affine else None, st.get(prefix + 'bias') if affine else None,
-                        False, 0.1, 1e-5)
+                        _TRAIN[0], 0.1, 1e-5)
 
 
 def _film(g, st, prefix, X, which):
@@ -50,15 +53,20 @@ def coupling(p, g, st, prefix, warp, mode):
     return (scale * p + mu if mode == 'direct' else (p - mu) / scale), mu, logvar
 
 
-def decoder_fused(p, g, st, n_flows, mode, grad=False):
-    """(B,3,N), (B,G) torch CPU tensors -> (final coordinates, sum of logvars); eval-mode BatchNorm.
-    grad=True keeps the autograd graph (tests use it as the gradient reference)."""
+def decoder_fused(p, g, st, n_flows, mode, grad=False, training=False):
+    """(B,3,N), (B,G) torch CPU tensors -> (final coordinates, sum of logvars).
+    grad=True keeps the autograd graph (tests use it as the gradient reference); training=True uses batch
+    statistics and updates the running statistics in `st` in place (nn.BatchNorm1d semantics)."""
     C = 3 * n_flows
     order = range(C) if mode == 'direct' else range(C - 1, -1, -1)
     cur, logdet = p, None
-    with torch.set_grad_enabled(grad):
-        for c in order:
-            prefix = f'flows.{c // 3}.nvp{c % 3 + 1}.'
-            cur, _, lv = coupling(cur, g, st, prefix, PATTERNS[c % 6], mode)
-            logdet = lv if logdet is None else logdet + lv
+    _TRAIN[0] = training
+    try:
+        with torch.set_grad_enabled(grad):
+            for c in order:
+                prefix = f'flows.{c // 3}.nvp{c % 3 + 1}.'
+                cur, _, lv = coupling(cur, g, st, prefix, PATTERNS[c % 6], mode)
+                logdet = lv if logdet is None else logdet + lv
+    finally:
+        _TRAIN[0] = False
     return cur, logdet

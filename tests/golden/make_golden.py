@@ -256,6 +256,25 @@ def g8_gradients():
     save('g8_gradients', **out)
 
 
+def g9_train_gradients():
+    """Train-mode (batch-statistic BatchNorm) gradients of the genuine reference: loss.backward() as training.py:54."""
+    L, f, G, B, N = 1, 8, 16, 3, 40
+    ref = rdec.LocalCondRNVPDecoder(L, f, G)
+    mine = ours.LocalCondRNVPDecoder(L, f, G)
+    load_into(ref, mine, 900)
+    ref.train()
+    p, g = synth_inputs(B, N, G, 901)
+    pt, gt = T(p).requires_grad_(True), T(g).requires_grad_(True)
+    ps, mus, lvs = ref(pt, gt, mode='inverse')
+    loss = 0.5 * (sum(lvs) + ps[0] ** 2).sum() / B
+    loss.backward()
+    out = {'dims': np.array([L, f, G, B, N]), 'p': p, 'g': g, 'loss': npy(loss), 'dp': npy(pt.grad), 'dg': npy(gt.grad),
+           'z': npy(ps[0]), 'logdet': npy(sum(lvs))}
+    for k, v in ref.named_parameters():
+        out['grad::' + k] = npy(v.grad)
+    save('g9_train_gradients', **out)
+
+
 def contract():
     """Reference state_dict keys/shapes for a small decoder, as JSON (checkpoint contract)."""
     ref = rdec.LocalCondRNVPDecoder(2, 8, 16)
@@ -278,3 +297,4 @@ if __name__ == '__main__':
     g6_keep_drift()
     g7_model_training_forward()
     g8_gradients()
+    g9_train_gradients()

@@ -399,9 +399,61 @@ def test_backward_unsupported_paths_fail_loudly():
     m, _ = decoder_and_state(1, 8, 8, 3)
     m = m.to(DEV)
     p, g = synth_inputs(2, 16, 8, 4)
-    out, _ = m.train().forward_fused(dev(p).requires_grad_(True), dev(g), 'inverse')
-    with pytest.raises(NotImplementedError):
-        out.sum().backward()
     out, _ = m.eval().forward_fused(dev(p).requires_grad_(True), dev(g), 'direct')
     with pytest.raises(NotImplementedError):
         out.sum().backward()
+
+
+def test_g9_train_mode_gradients_match_reference_autograd():
+    """loss.backward() through batch-statistic BatchNorm against the genuine reference (golden g9)."""
+    D = golden('g9_train_gradients')
+    L, f, G, B, N = D['dims']
+    m, _ = decoder_and_state(L, f, G, 900)
+    m = m.to(DEV).train()
+    pt, gt = dev(D['p']).requires_grad_(True), dev(D['g']).requires_grad_(True)
+    ps, mus, lvs = m(pt, gt, mode='inverse')
+    assert maxabs(host(ps[0]), D['z']) < 5e-5 and maxabs(host(sum(lvs)), D['logdet']) < 5e-5
+    loss = 0.5 * (sum(lvs) + ps[0] ** 2).sum() / B
+    assert abs(loss.item() - float(D['loss'])) / abs(float(D['loss'])) < 1e-5
+    loss.backward()
+    assert _rel(host(pt.grad), D['dp']) < 1e-3
+    assert _rel(host(gt.grad), D['dg']) < 1e-3
+    worst, wk = 0.0, None
+    for k, prm in m.named_parameters():
+        e = _rel(host(prm.grad), D['grad::' + k])
+        if e > worst:
+            worst, wk = e, k
+    assert worst < 2e-3, (wk, worst)
+
+
+@pytest.mark.parametrize('cfg', [(1, 8, 8, 3, 33), (2, 19, 12, 4, 70), (1, 37, 16, 2, 130)])
+def test_train_mode_gradients_vs_torch_cpu_autograd(cfg):
+    from oracle import torch_port as tp
+    L, f, G, B, N = cfg
+    m, st = decoder_and_state(L, f, G, 421 + f)
+    m = m.to(DEV).train()
+    p, g = synth_inputs(B, N, G, 87 + N)
+    rng = np.random.default_rng(6)
+    wz, wl = rng.normal(size=(B, 3, N)).astype(np.float32), rng.normal(size=(B, 3, N)).astype(np.float32)
+    tst = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and not k.endswith(('running_mean', 'running_var', 'eps')))
+           for k, v in st.items()}
+    pc, gc = torch.from_numpy(p).requires_grad_(True), torch.from_numpy(g).requires_grad_(True)
+    zc, ldc = tp.decoder_fused(pc, gc, tst, L, 'inverse', grad=True, training=True)
+    ((zc * torch.from_numpy(wz)).sum() + (ldc * torch.from_numpy(wl)).sum()).backward()
+    pt, gt = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+    z, ld = m.forward_fused(pt, gt, 'inverse')
+    ((z * dev(wz)).sum() + (ld * dev(wl)).sum()).backward()
+    assert maxabs(host(z), zc.detach().numpy()) < 1e-4
+    assert _rel(host(pt.grad), pc.grad.numpy()) < 2e-3
+    assert _rel(host(gt.grad), gc.grad.numpy()) < 2e-3
+    worst, wk = 0.0, None
+    for k, prm in m.named_parameters():
+        e = _rel(host(prm.grad), tst[k].grad.numpy())
+        if e > worst:
+            worst, wk = e, k
+    assert worst < 5e-3, (wk, worst)
+    # running statistics were updated exactly once by the differentiable forward
+    sd = m.state_dict()
+    for k, v in tst.items():
+        if k.endswith('running_var'):
+            assert maxabs(host(sd[k]), v.detach().numpy()) < 1e-4, k

@@ -168,3 +168,26 @@ def test_torch_port_matches_reference(name, mode):
     tag = f'eval_{mode}'
     assert maxabs(out.numpy(), D['first_' + tag] if mode == 'inverse' else D['last_' + tag]) < 5e-6
     assert maxabs(ld.numpy(), D['logdet_' + tag]) < 5e-6
+
+
+def test_torch_port_train_mode_gradients_match_reference():
+    """The PyTorch-CPU port in train mode (used as the gradient reference of the GPU tests) reproduces the genuine
+    reference's loss.backward() through batch-statistic BatchNorm (golden g9)."""
+    import torch
+    from oracle import torch_port as tp
+    D = golden('g9_train_gradients')
+    L, f, G, B, N = D['dims']
+    _, st = decoder_and_state(L, f, G, 900)
+    tst = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and not k.endswith(('running_mean', 'running_var', 'eps')))
+           for k, v in st.items()}
+    pt, gt = torch.from_numpy(D['p']).requires_grad_(True), torch.from_numpy(D['g']).requires_grad_(True)
+    z, ld = tp.decoder_fused(pt, gt, tst, L, 'inverse', grad=True, training=True)
+    loss = 0.5 * (ld + z ** 2).sum() / B
+    loss.backward()
+    assert abs(float(loss) - float(D['loss'])) / abs(float(D['loss'])) < 1e-5
+    assert maxabs(pt.grad.numpy(), D['dp']) / np.abs(D['dp']).max() < 1e-4
+    assert maxabs(gt.grad.numpy(), D['dg']) / np.abs(D['dg']).max() < 1e-4
+    for key in D.files:
+        if key.startswith('grad::'):
+            ref = D[key]
+            assert maxabs(tst[key[6:]].grad.numpy(), ref) / (np.abs(ref).max() + 1e-12) < 2e-4, key
