@@ -40,8 +40,10 @@ class MixtureStack:
         """Every component on every point -> (out, logdet), each (K,B,3,N).  Training / density path."""
         e0 = self.engines[0]
         e0._check(p, g)
-        if e0.couplings[0].training:
-            # batch-statistic BatchNorm: the per-coupling pipeline, component by component
+        needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or any(
+            t.requires_grad for d in self.decoders for t in d.parameters()))
+        if e0.couplings[0].training or needs_grad:
+            # batch-statistic BatchNorm and/or autograd: the per-component (differentiable) path
             res = [e.run(p, g, mode, False) for e in self.engines]
             return torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res])
         pw, film, eps = self._film(g.contiguous().float())
@@ -65,12 +67,35 @@ class MixtureStack:
                                         segments=segs, shared_points=False)
 
 
+class _MixtureNLLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, logdet, mu0, lv0, logits):
+        z, logdet, mu0, lv0, logits = (t.contiguous().float() for t in (z, logdet, mu0, lv0, logits))
+        nll, plse = _lib.mixture_nll(z, logdet, mu0, lv0, logits, True)
+        ctx.save_for_backward(z, logdet, mu0, lv0, logits, plse)
+        ctx.mark_non_differentiable(plse)
+        return nll, plse
+
+    @staticmethod
+    def backward(ctx, g_nll, _g_plse):
+        z, logdet, mu0, lv0, logits, plse = ctx.saved_tensors
+        L = _lib.lib()
+        K, B, _, N = z.shape
+        g_z, g_ld = torch.empty_like(z), torch.empty_like(logdet)
+        g_mu0, g_lv0, g_logits = torch.empty_like(mu0), torch.empty_like(lv0), torch.empty_like(logits)
+        g_nll = g_nll.contiguous().float()
+        with torch.cuda.device(z.device):
+            _lib.check(L.gwtf_mixture_nll_backward(z.data_ptr(), logdet.data_ptr(), mu0.data_ptr(), lv0.data_ptr(),
+                                                   logits.data_ptr(), plse.data_ptr(), g_nll.data_ptr(), g_z.data_ptr(),
+                                                   g_ld.data_ptr(), g_mu0.data_ptr(), g_lv0.data_ptr(), g_logits.data_ptr(),
+                                                   K, B, N, _lib._stream(z)))
+        return g_z, g_ld, g_mu0, g_lv0, g_logits
+
+
 def flow_mixture_nll(z, logdet, mu0, lv0, logits, want_point_lse=False):
     """FlowMixtureNLL on fused decoder outputs (reference losses.py:88-137).
 
     z, logdet (K,B,3,N): final inverse coordinates / sum of coupling logvars per component;
     mu0, lv0 (K,B,3): base Gaussians; logits (B,K).  -> (pnll scalar = batch mean, per-shape (B,) [, per-point lse])."""
-    res = _lib.mixture_nll(z.contiguous(), logdet.contiguous(), mu0.contiguous().float(), lv0.contiguous().float(),
-                           logits.contiguous().float(), want_point_lse)
-    nll = res[0] if want_point_lse else res
-    return (nll.mean(), nll, res[1]) if want_point_lse else (nll.mean(), nll)
+    nll, plse = _MixtureNLLFn.apply(z, logdet, mu0, lv0, logits)     # differentiable w.r.t. all five inputs
+    return (nll.mean(), nll, plse) if want_point_lse else (nll.mean(), nll)

@@ -155,6 +155,13 @@ int gwtf_mixture_nll(const float* z, const float* logdet, const float* mu0, cons
                      const float* logits, float* point_lse, float* nll_shape,
                      int K, int B, int N, void* stream);
 
+/* Backward of gwtf_mixture_nll: g_nll [B] = dL/d nll_shape; point_lse as returned by the forward.
+ * Writes g_z, g_logdet [K][B][3][N]; g_mu0, g_lv0 [K][B][3]; g_logits [B][K] (the last three zeroed by the call). */
+int gwtf_mixture_nll_backward(const float* z, const float* logdet, const float* mu0, const float* lv0,
+                              const float* logits, const float* point_lse, const float* g_nll, float* g_z,
+                              float* g_logdet, float* g_mu0, float* g_lv0, float* g_logits, int K, int B, int N,
+                              void* stream);
+
 /* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
  * (16, 32 or 64; anything else restores the size-based default).  Process-wide, not thread-safe. */
 void gwtf_debug_set_points_per_wave(int points);

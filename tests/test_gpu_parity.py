@@ -457,3 +457,85 @@ def test_train_mode_gradients_vs_torch_cpu_autograd(cfg):
     for k, v in tst.items():
         if k.endswith('running_var'):
             assert maxabs(host(sd[k]), v.detach().numpy()) < 1e-4, k
+
+
+def test_three_sgd_steps_match_cpu_training():
+    """End-to-end training semantics: forward (train-mode BN) -> NLL-like loss -> backward -> SGD, three steps, against
+    the same loop run through the PyTorch-CPU port; parameters and running statistics must track each other."""
+    from oracle import torch_port as tp
+    L, f, G, B, N = 1, 8, 8, 4, 64
+    m, st = decoder_and_state(L, f, G, 2024)
+    m = m.to(DEV).train()
+    tst = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and not k.endswith(('running_mean', 'running_var', 'eps')))
+           for k, v in st.items()}
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    losses = []
+    for step in range(3):
+        p, g = synth_inputs(B, N, G, 3000 + step)
+        # CPU
+        zc, ldc = tp.decoder_fused(torch.from_numpy(p), torch.from_numpy(g), tst, L, 'inverse', grad=True, training=True)
+        lc = 0.5 * (ldc + zc ** 2).sum() / B
+        grads = torch.autograd.grad(lc, [v for v in tst.values() if v.requires_grad])
+        with torch.no_grad():
+            for v, gr in zip([v for v in tst.values() if v.requires_grad], grads):
+                v -= 0.05 * gr
+        # HIP
+        opt.zero_grad()
+        ps, mus, lvs = m(dev(p), dev(g), mode='inverse')
+        loss = 0.5 * (sum(lvs) + ps[0] ** 2).sum() / B
+        loss.backward()
+        opt.step()
+        losses.append((float(lc), float(loss.detach())))
+        assert abs(losses[-1][0] - losses[-1][1]) / abs(losses[-1][0]) < 1e-4, losses
+    sd = m.state_dict()
+    worst = max(_rel(host(sd[k]), v.detach().numpy()) for k, v in tst.items() if v.dtype == torch.float32)
+    assert worst < 1e-3, worst
+
+
+def test_mixture_nll_backward_vs_torch_autograd():
+    """d pnll / d {z, logdet, mu0, lv0, logits} against autograd through the reference's formula (losses.py:88-137)."""
+    D = golden('g5_losses')
+    L, f, G, B, N, K = D['dims']
+    leaves_c = [torch.from_numpy(D[k]).clone().requires_grad_(True) for k in ('z', 'logdet', 'mu0', 'lv0', 'logits')]
+    zc, ldc, m0c, l0c, lgc = leaves_c
+    logw = lgc - torch.logsumexp(lgc, dim=-1, keepdim=True)                                   # (B,K)
+    lp = -0.5 * ((l0c[..., None] + ldc) + (zc - m0c[..., None]) ** 2 / torch.exp(l0c[..., None])).sum(2) - 0.5 * 3 * np.log(2 * np.pi)                                                        # (K,B,N)
+    ref = (-(torch.logsumexp(lp + logw.t()[:, :, None], dim=0)).sum(-1)).mean()
+    ref.backward()
+    leaves = [dev(D[k]).requires_grad_(True) for k in ('z', 'logdet', 'mu0', 'lv0', 'logits')]
+    pnll, per_shape = gw.flow_mixture_nll(*leaves)
+    assert abs(pnll.item() - ref.item()) / abs(ref.item()) < TOL_NLL_REL
+    pnll.backward()
+    for name, a, b in zip(('z', 'logdet', 'mu0', 'lv0', 'logits'), leaves, leaves_c):
+        assert _rel(host(a.grad), b.grad.numpy()) < 1e-4, name
+
+
+def test_fused_training_path_mixture_end_to_end():
+    """MixtureStack.forward_all + flow_mixture_nll under autograd == reference-style loss
+    built from the per-component lists with torch ops; gradients agree."""
+    D = golden('g5_losses')
+    L, f, G, B, N, K = D['dims']
+    decs = [decoder_and_state(L, f, G, 510 + k)[0].to(DEV).train() for k in range(K)]
+    decs2 = [decoder_and_state(L, f, G, 510 + k)[0].to(DEV).train() for k in range(K)]
+    pd, gd = dev(D['p']), dev(D['g']).requires_grad_(True)
+    gd2 = dev(D['g']).requires_grad_(True)
+    mu0, lv0, logits = dev(D['mu0']), dev(D['lv0']), dev(D['logits'])
+    # fused path
+    z, ld = gw.MixtureStack(decs).forward_all(pd, gd, 'inverse')
+    pnll, _ = gw.flow_mixture_nll(z, ld, mu0, lv0, logits)
+    pnll.backward()
+    # list path + torch formula
+    lps = []
+    for k, dk in enumerate(decs2):
+        ps, mus, lvs = dk(pd, gd2, mode='inverse')
+        lp = -0.5 * ((lv0[k][..., None] + sum(lvs)) + (ps[0] - mu0[k][..., None]) ** 2 / torch.exp(lv0[k][..., None])).sum(1) \
+            - 0.5 * 3 * np.log(2 * np.pi)
+        lps.append(lp)
+    logw = logits - torch.logsumexp(logits, dim=-1, keepdim=True)
+    ref = (-(torch.logsumexp(torch.stack(lps) + logw.t()[:, :, None], dim=0)).sum(-1)).mean()
+    ref.backward()
+    assert abs(pnll.item() - ref.item()) / abs(ref.item()) < 1e-5
+    assert _rel(host(gd.grad), host(gd2.grad)) < 1e-4
+    for a, b in zip(decs, decs2):
+        for (k1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
+            assert _rel(host(p1.grad), host(p2.grad)) < 2e-4, k1
