@@ -304,17 +304,85 @@ def _film_train(P, g, eps):
     return a, o[:, :, :, 1], mean.detach(), (var * (Bn / max(Bn - 1.0, 1.0))).detach()
 
 
-def train_density_forward(engine, p, g, group_sum=None):
+class _AllReduceSum(torch.autograd.Function):
+    """Sum over the ranks of the data-parallel group, in both directions: forward all-reduces the statistic,
+    backward all-reduces its gradient (every rank's loss depends on every rank's points through the batch
+    statistics -- SyncBatchNorm semantics, reference train_ae.py:152)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        import torch.distributed as dist
+        t = t.clone()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        import torch.distributed as dist
+        g = g.clone().contiguous()
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        return g
+
+
+def gather_rows(g, sizes):
+    """all_gather of (B_r, G) blocks whose B_r differ (collectives need equal shapes: pad to the largest, then trim)."""
+    import torch.distributed as dist
+    bmax = max(sizes)
+    mine = g.contiguous() if g.shape[0] == bmax else torch.cat([g, g.new_zeros(bmax - g.shape[0], g.shape[1])])
+    parts = [torch.empty(bmax, g.shape[1], device=g.device, dtype=g.dtype) for _ in sizes]
+    dist.all_gather(parts, mine)
+    return torch.cat([q[:n] for q, n in zip(parts, sizes)])
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """Concatenate per-rank (B_r, G) latents (B_r may differ by one, train_ae.py:77-78); backward returns the summed
+    gradient of this rank's rows."""
+
+    @staticmethod
+    def forward(ctx, g):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(), dist.get_rank()
+        sizes = [torch.zeros(1, dtype=torch.int64, device=g.device) for _ in range(world)]
+        dist.all_gather(sizes, torch.tensor([g.shape[0]], dtype=torch.int64, device=g.device))
+        sizes = [int(x.item()) for x in sizes]
+        ctx.row0, ctx.rows = sum(sizes[:rank]), sizes[rank]
+        return gather_rows(g, sizes)
+
+    @staticmethod
+    def backward(ctx, g_all):
+        import torch.distributed as dist
+        g_all = g_all.clone().contiguous()
+        dist.all_reduce(g_all, op=dist.ReduceOp.SUM)
+        return g_all[ctx.row0:ctx.row0 + ctx.rows]
+
+
+def train_density_forward(engine, p, g, distributed=False):
     """Differentiable train-mode density pass.  Returns out, logdet, per-coupling lists (ps, mus, lvs in direct
-    order; ps/lvs differentiable) and bn_batch (C,2,4,2,f) for the running-statistic update."""
+    order; ps/lvs differentiable) and bn_batch (C,2,4,2,f) for the running-statistic update.
+    distributed=True: statistics (and their gradients) are summed over torch.distributed's default group and the
+    per-shape FiLM BatchNorm sees the latents of all ranks."""
     from .flows import WARP_PATTERNS  # noqa: F401  (pattern table lives there)
     C, f, eps = engine.C, engine.f, engine.couplings[0]._eps_value
     B, _, N = p.shape
-    if B < 2:
-        raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
     P = _gather(engine)
-    a, bsh, fmean, fvar = _film_train(P, g.float(), eps)
+    group_sum = _AllReduceSum.apply if distributed else None
     n = float(B * N)
+    g = g.float()
+    if distributed:
+        g_all = _AllGatherRows.apply(g)
+        import torch.distributed as dist
+        sizes = [torch.zeros(1, dtype=torch.int64, device=g.device) for _ in range(dist.get_world_size())]
+        dist.all_gather(sizes, torch.tensor([B], dtype=torch.int64, device=g.device))
+        row0 = sum(int(x.item()) for x in sizes[:dist.get_rank()])
+        n = float(sum(int(x.item()) for x in sizes) * N)
+        if g_all.shape[0] < 2:
+            raise ValueError('train-mode BatchNorm needs more than 1 shape per (global) batch')
+        a, bsh, fmean, fvar = _film_train(P, g_all, eps)
+        a, bsh = a[row0:row0 + B], bsh[row0:row0 + B]
+    else:
+        if B < 2:
+            raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
+        a, bsh, fmean, fvar = _film_train(P, g, eps)
     bn_batch = torch.zeros(C, 2, 4, 2, f, device=p.device, dtype=torch.float32)
     bn_batch[:, :, 2:4, 0] = fmean
     bn_batch[:, :, 2:4, 1] = fvar

@@ -254,11 +254,9 @@ class StackEngine:
                                                   any(t.requires_grad for t in self._tracked or self._collect()))
         if needs_grad and mode == 'inverse' and c0.training:
             import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                raise NotImplementedError('differentiable train-mode forward across ranks (SyncBatchNorm gradients) is '
-                                          'not built yet')
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
             from .autograd import train_density_forward
-            out, logdet, (ps, mus, lvs), bn_batch = train_density_forward(self, p, g)
+            out, logdet, (ps, mus, lvs), bn_batch = train_density_forward(self, p, g, distributed=multi)
             self._update_running_stats(bn_batch)
             self._last_lists = (ps, mus, lvs)
             lists = (torch.stack([t.detach() for t in ps]), torch.stack(mus), torch.stack([t.detach() for t in lvs])) \
@@ -329,9 +327,8 @@ class StackEngine:
             sizes = [torch.zeros(1, dtype=torch.int64, device=p.device) for _ in range(dist.get_world_size())]
             dist.all_gather(sizes, torch.tensor([g.shape[0]], dtype=torch.int64, device=p.device))
             sizes = [int(x.item()) for x in sizes]
-            parts = [torch.empty(n, g.shape[1], device=g.device, dtype=g.dtype) for n in sizes]
-            dist.all_gather(parts, g)               # per-rank batches may differ by one (train_ae.py:77-78)
-            g_all, row0 = torch.cat(parts), sum(sizes[:dist.get_rank()])
+            from .autograd import gather_rows       # per-rank batches may differ by one (train_ae.py:77-78)
+            g_all, row0 = gather_rows(g, sizes), sum(sizes[:dist.get_rank()])
         with torch.no_grad():
             raw = self.raw_arena()
             out, logdet, lists, bn_batch = _lib.train_forward(p, g, raw, self.C, self.f, self.G, self.pattern0,

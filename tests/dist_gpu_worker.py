@@ -1,0 +1,67 @@
+"""Worker for tests/test_gpu_parity.py::test_two_rank_syncbn_training_matches_single_process.
+Two ranks share cuda:0 (one-GPU box), gloo carries the small statistic tensors.  Each rank owns half of the batch;
+forward outputs, input gradients and (summed) parameter gradients must equal the single-process full-batch run."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from helpers import decoder_and_state                       # noqa: E402
+from go_with_the_flows_amd.dist import shard_bounds          # noqa: E402
+from go_with_the_flows_amd.synth import synth_inputs         # noqa: E402
+
+
+def main():
+    dist.init_process_group('gloo')
+    rank, world = dist.get_rank(), dist.get_world_size()
+    L, f, G, B, N = 1, 8, 8, 5, 48
+    p, g = synth_inputs(B, N, G, 11)
+    rng = np.random.default_rng(12)
+    wz, wl = rng.normal(size=(B, 3, N)).astype(np.float32), rng.normal(size=(B, 3, N)).astype(np.float32)
+    b0, b1 = shard_bounds(B, rank, world)
+    m, _ = decoder_and_state(L, f, G, 13)
+    m = m.cuda().train()
+    pt = torch.from_numpy(p[b0:b1]).cuda().requires_grad_(True)
+    gt = torch.from_numpy(g[b0:b1]).cuda().requires_grad_(True)
+    z, ld = m.forward_fused(pt, gt, 'inverse')
+    loss = (z * torch.from_numpy(wz[b0:b1]).cuda()).sum() + (ld * torch.from_numpy(wl[b0:b1]).cuda()).sum()
+    loss.backward()
+    from go_with_the_flows_amd.dist import all_reduce_gradients
+    n_flat = all_reduce_gradients(m, average=False)           # one flat buffer, summed (DDP would also divide by W)
+    assert n_flat == sum(q.numel() for q in m.parameters())
+    grads = torch.cat([q.grad.reshape(-1) for q in m.parameters()])
+    out = {'z': z.detach().cpu().numpy(), 'dp': pt.grad.cpu().numpy(), 'dg': gt.grad.cpu().numpy(),
+           'rv': torch.cat([v.reshape(-1) for k, v in m.state_dict().items() if k.endswith('running_var')]).cpu().numpy()}
+    np.savez(os.path.join(os.environ['GWTF_TMP'], f'rank{rank}.npz'), grads=grads.cpu().numpy(), b0=b0, b1=b1, **out)
+    dist.barrier()
+    if rank == 0:
+        dist.destroy_process_group()
+        m1, _ = decoder_and_state(L, f, G, 13)
+        m1 = m1.cuda().train()
+        pf, gf = torch.from_numpy(p).cuda().requires_grad_(True), torch.from_numpy(g).cuda().requires_grad_(True)
+        z1, ld1 = m1.forward_fused(pf, gf, 'inverse')
+        ((z1 * torch.from_numpy(wz).cuda()).sum() + (ld1 * torch.from_numpy(wl).cuda()).sum()).backward()
+        g1 = torch.cat([q.grad.reshape(-1) for q in m1.parameters()]).cpu().numpy()
+        parts = [np.load(os.path.join(os.environ['GWTF_TMP'], f'rank{r}.npz')) for r in range(world)]
+        rel = lambda a, b: float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+        res = {
+            'z': rel(np.concatenate([q['z'] for q in parts]), z1.detach().cpu().numpy()),
+            'dp': rel(np.concatenate([q['dp'] for q in parts]), pf.grad.cpu().numpy()),
+            'dg': rel(np.concatenate([q['dg'] for q in parts]), gf.grad.cpu().numpy()),
+            'param_grads': rel(parts[0]['grads'], g1),
+            'running_var': rel(parts[0]['rv'], torch.cat([v.reshape(-1) for k, v in m1.state_dict().items()
+                                                          if k.endswith('running_var')]).cpu().numpy()),
+        }
+        print('DIST2', ' '.join(f'{k}={v:.2e}' for k, v in res.items()), flush=True)
+        assert all(v < 2e-3 for v in res.values()), res
+    else:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -539,3 +539,16 @@ def test_fused_training_path_mixture_end_to_end():
     for a, b in zip(decs, decs2):
         for (k1, p1), (_, p2) in zip(a.named_parameters(), b.named_parameters()):
             assert _rel(host(p1.grad), host(p2.grad)) < 2e-4, k1
+
+
+def test_two_rank_syncbn_training_matches_single_process(tmp_path):
+    """Data-parallel training semantics (reference train_ae.py:152-153: SyncBatchNorm + DDP): two ranks, each with
+    part of the batch, statistics and their gradients summed across ranks == one process with the whole batch."""
+    import subprocess, sys, os
+    env = dict(os.environ, GWTF_TMP=str(tmp_path), MASTER_ADDR='127.0.0.1')
+    port = 29600 + os.getpid() % 1000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(os.path.dirname(__file__), 'dist_gpu_worker.py')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert 'DIST2' in r.stdout, r.stdout[-2000:]
