@@ -128,8 +128,8 @@ class StackDensityFn(torch.autograd.Function):
         g_film = torch.zeros(B, C, 2, 3, FP, device=dev, dtype=torch.float32)
         g_sd0 = torch.zeros(C, R, 2, 3, FP, device=dev, dtype=torch.float32)
         g_bias = torch.zeros(C, R, 4, device=dev, dtype=torch.float32)
-        dA = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
-        H0 = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
+        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
         gW1p = torch.empty(C, 2, f, f, device=dev, dtype=torch.float32)
         bufs = [torch.empty_like(p), torch.empty_like(p)]
         st = _lib._stream(p)
@@ -142,8 +142,8 @@ class StackDensityFn(torch.autograd.Function):
                                                     nxt.data_ptr(), dA.data_ptr(), H0.data_ptr(), g_film.data_ptr(),
                                                     g_sd0[c].data_ptr(), g_bias[c].data_ptr(), c, B, N, C, f, pattern0,
                                                     float(eps), st))
-                # dW1p[k][j][i] = sum_{b,n} dacc[b,k,j,n] h[b,k,i,n]: plain GEMM -> BLAS
-                gW1p[c] = torch.einsum('bkjn,bkin->kji', dA[:, :, :f], H0[:, :, :f])
+                # dW1p[k][j][i] = sum_{b,n} dacc[k,j,(b,n)] h[k,i,(b,n)]: one batched GEMM with K = B*N -> BLAS
+                gW1p[c] = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
                 cur = nxt
         gs = g_sd0.sum(1)                                              # (C,2,3,FP)
         g_W0f = gs[:, :, 0:2, :f].permute(0, 1, 3, 2).contiguous()    # (C,2,f,2)
@@ -236,13 +236,13 @@ class StatsFn(torch.autograd.Function):
         gst[:, 0, :f] = gS[:, :, 0]
         gst[:, 1, :f] = gS[:, :, 1]
         g_x = torch.empty_like(x)
-        dA = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
-        H0 = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
+        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
         g_sd0 = torch.zeros(_lib.STAT_REPLICAS, 2, 3, FP, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(L.gwtf_stats_backward(x.data_ptr(), gst.data_ptr(), pw.data_ptr(), pb.data_ptr(), g_x.data_ptr(),
                                              dA.data_ptr(), H0.data_ptr(), g_sd0.data_ptr(), B, N, f, pat, _lib._stream(x)))
-        gW1 = torch.einsum('bkjn,bkin->kji', dA[:, :, :f], H0[:, :, :f])
+        gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
         gs = g_sd0.sum(0)
         return g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1, None, None, None, None
 
@@ -276,14 +276,14 @@ class ApplyFn(torch.autograd.Function):
         g_film = torch.zeros(B, 1, 2, 3, FP, device=dev, dtype=torch.float32)
         g_sd0 = torch.zeros(R, 2, 3, FP, device=dev, dtype=torch.float32)
         g_bias = torch.zeros(R, 4, device=dev, dtype=torch.float32)
-        dA = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
-        H0 = torch.empty(B, 2, FP, N, device=dev, dtype=torch.float32)
+        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(L.gwtf_coupling_backward(x.data_ptr(), g_out.data_ptr(), g_lv.data_ptr(), pw.data_ptr(), pb.data_ptr(),
                                                 rec.data_ptr(), g_x.data_ptr(), dA.data_ptr(), H0.data_ptr(),
                                                 g_film.data_ptr(), g_sd0.data_ptr(), g_bias.data_ptr(), 0, B, N, 1, f, pat,
                                                 float(eps), _lib._stream(x)))
-        gW1 = torch.einsum('bkjn,bkin->kji', dA[:, :, :f], H0[:, :, :f])
+        gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
         gs = g_sd0.sum(0)
         return (g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1,
                 g_film[:, 0, :, 0, :f].contiguous(), g_film[:, 0, :, 1:3, :f].contiguous(), g_bias.sum(0).reshape(2, 2),
@@ -402,11 +402,13 @@ def train_density_forward(engine, p, g, distributed=False):
         Sxx = torch.stack([torch.stack([Md[3], Md[4], Md[5]]), torch.stack([Md[4], Md[6], Md[7]]),
                            torch.stack([Md[5], Md[7], Md[8]])]) / n
         Cov = Sxx - torch.outer(E, E)
-        kk = [k0] if k1 < 0 else [k0, k1]
-        Ek = torch.zeros(2, dtype=torch.float64, device=p.device)
-        Ck = torch.zeros(2, 2, dtype=torch.float64, device=p.device)
-        Ek = torch.cat([E[kk], Ek[len(kk):]])
-        Ck = torch.nn.functional.pad(Cov[kk][:, kk], (0, 2 - len(kk), 0, 2 - len(kk)))
+        zero = Md.new_zeros(())            # python-int indexing only: no index tensors (hipGraph-capturable)
+        if k1 < 0:
+            Ek = torch.stack([E[k0], zero])
+            Ck = torch.stack([torch.stack([Cov[k0, k0], zero]), torch.stack([zero, zero])])
+        else:
+            Ek = torch.stack([E[k0], E[k1]])
+            Ck = torch.stack([torch.stack([Cov[k0, k0], Cov[k0, k1]]), torch.stack([Cov[k1, k0], Cov[k1, k1]])])
         W0 = P['W0'][c].double()                                   # (2,f,2)
         mean0 = W0 @ Ek
         var0 = torch.einsum('xfa,ab,xfb->xf', W0, Ck, W0).clamp_min(0.0)

@@ -14,7 +14,8 @@
 // Reductions over points (per-shape FiLM record grads dc, du_w; sd0 grads; sd2 bias grads) are done in-lane over
 // the point blocks, by shuffles over the 16 lanes of a quarter, in LDS over the 4 waves, then one atomic per value
 // and workgroup.  The f x f weight gradient dW1p = sum_p dacc(p) h(p)^T is a plain GEMM over all points: dacc and h
-// are written out ([B][2][FP][N]) and contracted by the BLAS library on the host side.
+// are written out ([2][FP][B][N]: the contraction index (shape, point) is contiguous) and contracted by ONE batched
+// library GEMM with K = B*N on the host side.
 #include "gwtf_device.h"
 
 namespace {
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
             const int n = n_wave0 + 16 * nb + i16;
             const float da = n < N ? fmaf(gq2, acc[br][m][nb][r], gs) : 0.f;
             acc[br][m][nb][r] = da;
-            if (n < N) dA_mat[(((size_t)b * 2 + br) * FP + ft) * N + n] = da;
+            if (n < N) dA_mat[(((size_t)br * FP + ft) * B + b) * N + n] = da;
           }
           continue;
         }
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
           sdc += da;
           acc[br][m][nb][r] = da;
           const int n = n_wave0 + 16 * nb + i16;
-          if (n < N) dA_mat[(((size_t)b * 2 + br) * FP + ft) * N + n] = da;
+          if (n < N) dA_mat[(((size_t)br * FP + ft) * B + b) * N + n] = da;
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
           const float pre = fmaf(sp[0], xa[nb], fmaf(sp[1], xb[nb], sp[2]));
           const float dp = pre > 0.f ? dh[nb][r] : 0.f;
           const int n = n_wave0 + 16 * nb + i16;
-          if (n < N) h0_mat[(((size_t)b * 2 + br) * FP + fi) * N + n] = fmaxf(pre, 0.f);
+          if (n < N) h0_mat[(((size_t)br * FP + fi) * B + b) * N + n] = fmaxf(pre, 0.f);
           pxa[nb] = fmaf(sp[0], dp, pxa[nb]);
           pxb[nb] = fmaf(sp[1], dp, pxb[nb]);
           g0 = fmaf(dp, xa[nb], g0);

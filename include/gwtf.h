@@ -125,8 +125,8 @@ int gwtf_train_forward(const float* p, const float* raw, float* packed_w, const 
  *   FiLM record [B][C][6FP+4] = {c, u0, u1} x 2 branches + biases (gwtf_layout.h).
  * gwtf_pack_folded builds the forward record (packed_w) and the backward record (packed_b) from them.
  * gwtf_coupling_backward: x_in = the coupling's input saved by the forward, g_out/g_ld = dL/d(out), dL/d(logdet);
- *   -> g_in [B][3][N]; dA_mat, h0_mat [B][2][FP][N] (dL/dacc and relu(sd0) per point: dW1p = sum_p dA h0^T is left to
- *   a library GEMM); g_film [B][C][2][3][FP] += {dc, du0, du1}; g_sd0 [64][2][3][FP] += {dW0f[:,0], dW0f[:,1], dc0f};
+ *   -> g_in [B][3][N]; dA_mat, h0_mat [2][FP][B][N] (dL/dacc and relu(sd0) per point: dW1p = sum_p dA h0^T is left to
+ *   one batched library GEMM with K = B*N); g_film [B][C][2][3][FP] += {dc, du0, du1}; g_sd0 [64][2][3][FP] += {dW0f[:,0], dW0f[:,1], dc0f};
  *   g_bias [64][4] += {db_lv0, db_lv1, db_mu0, db_mu1}   (64 = GWTF_STAT_REPLICAS copies, sum them; all pre-zeroed). */
 size_t gwtf_packed_b_coupling_floats(int f);
 int gwtf_pack_folded(const float* W1p, const float* W0f, const float* c0f, float* packed_w, float* packed_b,

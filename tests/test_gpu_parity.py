@@ -552,3 +552,42 @@ def test_two_rank_syncbn_training_matches_single_process(tmp_path):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert 'DIST2' in r.stdout, r.stdout[-2000:]
+
+
+def test_whole_train_step_hipgraph_replay_equals_eager():
+    """forward(train BN) + backward + SGD captured in ONE hipGraph: replays continue the eager trajectory exactly."""
+    L, f, G, B, N = 1, 19, 16, 4, 128
+    p, g = synth_inputs(B, N, G, 0)
+    pd, gd = dev(p), dev(g)
+
+    def make():
+        m, _ = decoder_and_state(L, f, G, 2)
+        m = m.to(DEV).train()
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            z, ld = m.forward_fused(pd, gd, 'inverse')
+            loss = 0.5 * (ld + z * z).sum() / (B * N)
+            loss.backward()
+            opt.step()
+            return loss
+        return opt, step
+
+    _, s1 = make()
+    eager = [s1().item() for _ in range(5)]
+    o2, s2 = make()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        warm = [s2().item() for _ in range(3)]
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    o2.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        loss = s2()
+    got = list(warm)
+    for _ in range(2):
+        graph.replay()
+        got.append(loss.item())
+    assert got == eager and eager[-1] < eager[0]
