@@ -30,12 +30,17 @@ __device__ __forceinline__ float sel3(float a, float b, float c, int d) { return
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // x = hi + lo with both parts rounded to nearest f16 (|lo| <= 2^-12 |x|): v_cvt_pk_f16_f32, two mixed-precision
-// FMAs (h - float(hi), the f16 operand converted inside v_fma_mix_f32), v_cvt_pk_f16_f32: 4 VALU for two values
+// FMAs computing h - float(hi) with the f16 operand converted inside the instruction (v_fma_mix_f32; the compiler
+// does not form it by itself: it emitted 2 x v_cvt_f32_f16 + v_pk_add_f32), v_cvt_pk_f16_f32: 4 VALU for two values.
 __device__ __forceinline__ void split_pair(f32x2 h, f16x2& hi, f16x2& lo) {
   hi = __builtin_convertvector(h, f16x2);
   f32x2 r;
-  r[0] = __builtin_fmaf((float)hi[0], -1.0f, h[0]);
-  r[1] = __builtin_fmaf((float)hi[1], -1.0f, h[1]);
+  const unsigned hib = __builtin_bit_cast(unsigned, hi);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hib), "v"(h[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hib), "v"(h[1]));
+  r[0] = r0;
+  r[1] = r1;
   lo = __builtin_convertvector(r, f16x2);
 }
 
