@@ -32,11 +32,13 @@ _SIGNATURES = {
     'gwtf_stack_forward_multi': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
                                  [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_fp]),
     'gwtf_train_moments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_train_fold0': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_fold0': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_train_stats': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_train_fold1': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, _c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
     'gwtf_train_apply': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
-    'gwtf_train_forward': (ctypes.c_int, [_c_fp] * 13 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_train_forward': (ctypes.c_int, [_c_fp] * 14 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_pack_w1t': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_coupling_backward': (ctypes.c_int, [_c_fp] * 22 + [ctypes.c_int] * 7 + [ctypes.c_float, _c_fp]),
     'gwtf_packed_b_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_pack_folded': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 6 + [ctypes.c_float, _c_fp]),
@@ -225,7 +227,7 @@ def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum
         cur = p
         if group_sum is None:
             # single rank: the whole pipeline is enqueued by one C call
-            check(L.gwtf_train_forward(_ptr(p, 'p'), _ptr(raw, 'raw'), pw.data_ptr(), film_raw.data_ptr(), mom.data_ptr(),
+            check(L.gwtf_train_forward(_ptr(p, 'p'), _ptr(raw, 'raw'), pw.data_ptr(), None, film_raw.data_ptr(), mom.data_ptr(),
                                        ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(), xbuf.data_ptr(),
                                        logdet.data_ptr(), lp[0], lp[1], lp[2], B, N, C, f, G, pattern0, float(eps),
                                        _MODES[mode], st))
@@ -237,7 +239,7 @@ def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum
             if group_sum is not None:
                 group_sum(mom[step])
             raw_c, pw_c = raw[c * R:(c + 1) * R], pw[c * PW:(c + 1) * PW]
-            check(L.gwtf_train_fold0(raw_c.data_ptr(), mom[step].data_ptr(), n_total, pat, pw_c.data_ptr(),
+            check(L.gwtf_train_fold0(raw_c.data_ptr(), mom[step].data_ptr(), n_total, pat, pw_c.data_ptr(), None,
                                      bn_batch[c].data_ptr(), f, G, st))
             check(L.gwtf_train_stats(cur.data_ptr(), pw_c.data_ptr(), ystats[c].data_ptr(), B, N, f, pat, st))
             if group_sum is not None:

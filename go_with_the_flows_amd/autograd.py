@@ -236,7 +236,7 @@ class StatsFn(torch.autograd.Function):
         gst[:, 0, :f] = gS[:, :, 0]
         gst[:, 1, :f] = gS[:, :, 1]
         g_x = torch.empty_like(x)
-        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        dA = torch.zeros(2, FP, B * N, device=dev, dtype=torch.float32)     # the kernel accumulates into it
         H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
         g_sd0 = torch.zeros(_lib.STAT_REPLICAS, 2, 3, FP, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
@@ -437,3 +437,116 @@ def train_density_forward(engine, p, g, distributed=False):
             bn_batch[c, :, 1, 0] = m1.float()
             bn_batch[c, :, 1, 1] = (v1 * unb).float()
     return x, logdet, (ps, mus, lvs), bn_batch
+
+
+# ======================================================================================================================
+# Single-rank fast path of the train-mode density pass: the whole per-coupling chain of the section above inside two C
+# entry points (gwtf_train_forward / gwtf_train_coupling_backward: folds and their backward are HIP kernels), so a train
+# step costs ~6 host-level ops per coupling instead of ~300 tiny torch ops.  Only the FiLM heads (O(B f G), vectorised
+# over all couplings) stay a torch graph.  The chain of autograd nodes above remains the multi-rank implementation and
+# the cross-check of this one (tests/test_gpu_parity.py::test_train_fast_path_equals_autograd_chain).
+# ======================================================================================================================
+def _gather_film(engine):
+    cps = engine.couplings
+    head = lambda c, X, w: getattr(c, f'T_{X}_0_cond_{w}')
+
+    def st_heads(fn):
+        return torch.stack([torch.stack([torch.stack([fn(head(c, X, w)) for w in ('w', 'b')]) for X in ('logvar', 'mu')])
+                            for c in cps])
+
+    return {'L0': st_heads(lambda h: h[0].weight),
+            'hbn': [st_heads(lambda h, k=k: getattr(h[1], k)) for k in ('weight', 'bias', 'running_mean', 'running_var')],
+            'L1': st_heads(lambda h: h[3].weight), 'b1': st_heads(lambda h: h[3].bias)}
+
+
+class TrainStackFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, raw, a, bsh, C, f, G, pattern0, eps):
+        L = _lib.lib()
+        p, raw = p.contiguous(), raw.contiguous()
+        B, _, N = p.shape
+        dev = p.device
+        FP = L.gwtf_padded_width(f)
+        FS, PB = L.gwtf_film_out_floats(f), L.gwtf_packed_b_coupling_floats(f)
+        R = _lib.STAT_REPLICAS
+        film_raw = torch.zeros(B, C, 2, 2, FP, device=dev, dtype=torch.float32)
+        film_raw[:, :, :, 0, :f] = a
+        film_raw[:, :, :, 1, :f] = bsh
+        st = _lib._stream(p)
+        with torch.cuda.device(dev):
+            pw, _pf = _lib.pack_weights(raw, C, f, G, True)
+            pb = torch.zeros(C * PB, device=dev, dtype=torch.float32)
+            _lib.check(L.gwtf_pack_w1t(raw.data_ptr(), pb.data_ptr(), C, f, G, st))
+            mom = torch.zeros(C + 1, R * 16, device=dev, dtype=torch.float32)
+            ystats = torch.zeros(C, R * 2 * FP * 2, device=dev, dtype=torch.float32)
+            bn_batch = torch.zeros(C, 2, 4, 2, f, device=dev, dtype=torch.float32)
+            film_rec = torch.empty(B, C, FS, device=dev, dtype=torch.float32)
+            xbuf = torch.empty(2, B, 3, N, device=dev, dtype=torch.float32)
+            logdet = torch.empty_like(p)
+            lists = torch.empty(3, C, B, 3, N, device=dev, dtype=torch.float32)
+            _lib.check(L.gwtf_train_forward(p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr(), film_raw.data_ptr(),
+                                            mom.data_ptr(), ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(),
+                                            xbuf.data_ptr(), logdet.data_ptr(), lists[0].data_ptr(), lists[1].data_ptr(),
+                                            lists[2].data_ptr(), B, N, C, f, G, pattern0, float(eps), _lib.MODE_INVERSE, st))
+        out = xbuf[(C - 1) & 1].clone()
+        ctx.save_for_backward(p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats)
+        ctx.meta = (C, f, G, FP, pattern0, eps)
+        ctx.mark_non_differentiable(lists, bn_batch)
+        return out, logdet, lists, bn_batch
+
+    @staticmethod
+    def backward(ctx, g_out, g_logdet, _gl, _gb):
+        p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats = ctx.saved_tensors
+        C, f, G, FP, pattern0, eps = ctx.meta
+        L = _lib.lib()
+        B, _, N = p.shape
+        dev = p.device
+        R = _lib.STAT_REPLICAS
+        RC, PW, PB = L.gwtf_raw_coupling_floats(f, G), L.gwtf_packed_w_coupling_floats(f), L.gwtf_packed_b_coupling_floats(f)
+        br_size = RC // 2
+        ps = lists[0]
+        cur = (g_out if g_out is not None else torch.zeros_like(p)).contiguous().float()
+        g_ld = (g_logdet if g_logdet is not None else torch.zeros_like(p)).contiguous().float()
+        g_raw = torch.zeros_like(raw)
+        g_film_raw = torch.zeros_like(film_raw)
+        g_film = torch.zeros(B, C, 2, 3, FP, device=dev, dtype=torch.float32)
+        g_sd0 = torch.zeros(C, R * 2 * 3 * FP, device=dev, dtype=torch.float32)
+        g_bias = torch.zeros(C, R * 4, device=dev, dtype=torch.float32)
+        g_stats = torch.empty(C, 2 * 2 * FP, device=dev, dtype=torch.float32)
+        g_mom = torch.empty(C, 16, device=dev, dtype=torch.float32)
+        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        gxa, gxb = torch.empty_like(p), torch.empty_like(p)
+        bufs = [torch.empty_like(p), torch.empty_like(p)]
+        st = _lib._stream(p)
+        with torch.cuda.device(dev):
+            for c in range(C):                                   # forward processed C-1 .. 0
+                step = C - 1 - c                                 # this coupling's position in the forward order
+                x_in = ps[c + 1] if c + 1 < C else p
+                nxt = bufs[c & 1]
+                g_raw_c = g_raw[c * RC:(c + 1) * RC]
+                _lib.check(L.gwtf_train_coupling_backward(
+                    x_in.data_ptr(), cur.data_ptr(), g_ld.data_ptr(), raw[c * RC:].data_ptr(), pw[c * PW:].data_ptr(),
+                    pb[c * PB:].data_ptr(), film_rec.data_ptr(), film_raw.data_ptr(), mom[step].data_ptr(),
+                    ystats[c].data_ptr(), nxt.data_ptr(), gxa.data_ptr(), gxb.data_ptr(), dA.data_ptr(), H0.data_ptr(),
+                    g_film.data_ptr(), g_sd0[c].data_ptr(), g_bias[c].data_ptr(), g_stats[c].data_ptr(), g_mom[c].data_ptr(),
+                    g_film_raw.data_ptr(), g_raw_c.data_ptr(), c, B, N, C, f, G, pattern0, float(eps), st))
+                gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))            # (2,f,f): one GEMM, K = B*N
+                for br in range(2):
+                    off = br * br_size + 6 * f                   # GwtfRaw::sd1_w
+                    g_raw_c[off:off + f * f].copy_(gW1[br].reshape(-1))
+                cur = nxt
+        return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None
+
+
+def train_density_forward_fast(engine, p, g):
+    """Single-rank train-mode density pass through the fused C pipeline.  -> out, logdet, lists (detached), bn_batch."""
+    C, f, G, eps = engine.C, engine.f, engine.G, engine.couplings[0]._eps_value
+    if p.shape[0] < 2:
+        raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
+    a, bsh, fmean, fvar = _film_train(_gather_film(engine), g.float(), eps)
+    out, logdet, lists, bn_batch = TrainStackFn.apply(p.float(), engine.raw_arena(), a, bsh, C, f, G, engine.pattern0, eps)
+    bn_batch = bn_batch.clone()
+    bn_batch[:, :, 2:4, 0] = fmean
+    bn_batch[:, :, 2:4, 1] = fvar
+    return out, logdet, lists, bn_batch

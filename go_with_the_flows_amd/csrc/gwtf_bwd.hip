@@ -208,7 +208,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
             const int n = n_wave0 + 16 * nb + i16;
             const float da = n < N ? fmaf(gq2, acc[br][m][nb][r], gs) : 0.f;
             acc[br][m][nb][r] = da;
-            if (n < N) dA_mat[(((size_t)br * FP + ft) * B + b) * N + n] = da;
+            // the statistics path shares h with the coupling path: dW1 = (dacc_apply + dacc_stats) h^T -> accumulate
+            if (n < N) dA_mat[(((size_t)br * FP + ft) * B + b) * N + n] += da;
           }
           continue;
         }

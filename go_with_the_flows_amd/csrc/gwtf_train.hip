@@ -45,7 +45,8 @@ __device__ __forceinline__ int mom2_index(int a, int b) {  // index of S x_a x_b
 
 // One workgroup, thread = (branch, feature).  bn_batch[branch][kind 0][2][f] <- {mean, unbiased var}.
 __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
-                             float* __restrict__ pw_c, float* __restrict__ bn_batch, int f, int G, int FP) {
+                             float* __restrict__ pw_c, float* __restrict__ pb_c, float* __restrict__ bn_batch, int f, int G,
+                             int FP) {
   const int t = threadIdx.x;
   __shared__ float mom[9];
   if (t < 9) {
@@ -76,6 +77,13 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
   sd0[0] = (float)wa * s;
   sd0[8] = (float)wb * s;
   sd0[16] = bn[f + j] - (float)mean * s;
+  if (pb_c) {   // backward record: sd0 parameters in natural feature order (csrc/gwtf_bwd.hip)
+    float* n4 = pb_c + 2 * (size_t)(FP / 16) * (FP / 4) * 64 + ((size_t)br * FP + j) * 4;
+    n4[0] = sd0[0];
+    n4[1] = sd0[8];
+    n4[2] = sd0[16];
+    n4[3] = 0.f;
+  }
   float* bb = bn_batch + ((size_t)br * 4 + 0) * 2 * f;
   bb[j] = (float)mean;
   bb[f + j] = (float)(var * (n_total / (n_total > 1.0 ? n_total - 1.0 : 1.0)));
@@ -128,12 +136,12 @@ extern "C" int gwtf_train_moments(const float* p, float* moments, int B, int N, 
 }
 
 extern "C" int gwtf_train_fold0(const float* raw_c, const float* moments, double n_total, int pattern, float* packed_w_c,
-                                float* bn_batch_c, int f, int G, void* stream) {
+                                float* packed_b_c, float* bn_batch_c, int f, int G, void* stream) {
   if (!raw_c || !moments || !packed_w_c || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP || G <= 0 || pattern < 0 ||
       pattern > 5 || n_total < 1.0)
     return GWTF_E_BADARG;
   hipLaunchKernelGGL(fold0_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, moments, n_total, pattern,
-                     packed_w_c, bn_batch_c, f, G, gwtf_padded_width(f));
+                     packed_w_c, packed_b_c, bn_batch_c, f, G, gwtf_padded_width(f));
   return (int)hipGetLastError();
 }
 
@@ -151,8 +159,9 @@ extern "C" int gwtf_train_fold1(const float* raw_c, const float* ystats, double 
 // coupling from C, so the host cost per coupling is four hipLaunchKernel calls instead of a Python iteration.
 // Workspace (caller-owned, pre-zeroed where stated): moments [(C+1)][64][16] zero, ystats [C][64][2*FP*2] zero,
 // bn_batch [C][2][4][2][f], film_rec [B][C][FS], xbuf [2][B][3][N].  Result coordinates end in
-// xbuf[(C-1) & 1]; packed_w is modified (sd0 records filled in).
-extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packed_w, const float* film_raw,
+// xbuf[(C-1) & 1]; packed_w is modified (sd0 records filled in); packed_b (optional, for the backward: W1T sections
+// pre-filled by gwtf_pack_w1t) receives the sd0 parameters in natural order.
+extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float* packed_b, const float* film_raw,
                                   float* moments, float* ystats, float* bn_batch, float* film_rec, float* xbuf,
                                   float* logdet, float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G,
                                   int pattern0, float eps, int mode, void* stream) {
@@ -170,7 +179,8 @@ extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packe
   for (int step = 0; step < C; ++step) {
     const int c = mode == GWTF_MODE_DIRECT ? step : C - 1 - step;
     const int pat = (pattern0 + c) % 6;
-    rc = gwtf_train_fold0(raw + c * R, moments + step * MS, n_total, pat, packed_w + c * PW, bn_batch + c * BS, f, G, stream);
+    rc = gwtf_train_fold0(raw + c * R, moments + step * MS, n_total, pat, packed_w + c * PW,
+                          packed_b ? packed_b + c * gwtf_packed_b_coupling_floats(f) : nullptr, bn_batch + c * BS, f, G, stream);
     if (rc) return rc;
     rc = gwtf_train_stats(cur, packed_w + c * PW, ystats + c * YS, B, N, f, pat, stream);
     if (rc) return rc;
@@ -183,4 +193,209 @@ extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packe
     cur = nxt;
   }
   return 0;
+}
+
+// =====================================================================================================================
+// Backward of the folds (train mode) and the fused per-coupling train backward.  Same arithmetic as autograd through the
+// torch folds in autograd.py (which remain the multi-rank path); here each fold's backward is ONE small launch.
+// =====================================================================================================================
+namespace {
+
+// un-scaled sd1 weights -> backward records' W1T images (k-slot map of csrc/gwtf_bwd.hip); SD0N is written by fold0
+__global__ void pack_w1t_kernel(const float* __restrict__ raw, float* __restrict__ pb, int C, int f, int G, int FP) {
+  const GwtfRaw R(f, G);
+  const int MB = FP / 16, KKF = FP / 4;
+  const size_t W1T = (size_t)MB * KKF * 64, PBs = 2 * W1T + 2 * (size_t)FP * 4;
+  const size_t total = 2 * W1T * (size_t)C;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx / (2 * W1T));
+    size_t o = idx - (size_t)c * 2 * W1T;
+    const int br = (int)(o / W1T);
+    o -= (size_t)br * W1T;
+    const int lane = (int)(o % 64), kk = (int)((o / 64) % KKF), mi = (int)(o / ((size_t)64 * KKF));
+    const int j = 16 * (kk >> 2) + 4 * (lane >> 4) + (kk & 3), i = 16 * mi + (lane & 15);
+    const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
+    pb[(size_t)c * PBs + (size_t)br * W1T + o] = (j < f && i < f) ? rb[R.sd1_w() + (size_t)j * f + i] : 0.f;
+  }
+}
+
+// thread = (branch, feature); one workgroup.  Writes g_a / g_bsh rows of this coupling, dW2, db2 and gS.
+__global__ void fold1_bwd_kernel(const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total,
+                                 const float* __restrict__ film_raw, const float* __restrict__ g_film,
+                                 const float* __restrict__ g_bias, float* __restrict__ g_film_raw,
+                                 float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G,
+                                 int FP) {
+  const int t = threadIdx.x;
+  if (t >= 2 * FP) return;
+  const int br = t / FP, j = t % FP;
+  const GwtfRaw R(f, G);
+  if (j >= f) {
+    g_stats[(br * 2 + 0) * FP + j] = 0.f;
+    g_stats[(br * 2 + 1) * FP + j] = 0.f;
+    return;
+  }
+  const float* rb = raw_c + (size_t)br * R.branch_size();
+  float* grb = g_raw_c + (size_t)br * R.branch_size();
+  float ys = 0.f, yq = 0.f;
+  for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) {
+    ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
+    yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
+  }
+  const double mean = ys / n_total;
+  double var = yq / n_total - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float s1 = 1.0f / sqrtf((float)var + GWTF_BN_EPS);
+  const float w20 = rb[R.sd2_w() + j], w21 = rb[R.sd2_w() + f + j];
+  double g_m1 = 0.0, g_s1 = 0.0, gw20 = 0.0, gw21 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* fr = film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
+    const float* gf = g_film + (((size_t)b * C + c) * 2 + br) * 3 * FP;
+    float* go = g_film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
+    const float a = fr[j], bs = fr[FP + j];
+    const float gc = gf[j], gu0 = gf[FP + j], gu1 = gf[2 * FP + j];
+    const float guw = gu0 * w20 + gu1 * w21;
+    go[j] = -gc * bs / (a * a * s1) + guw * s1;   // dL/da
+    go[FP + j] = gc / (a * s1);                   // dL/dbsh
+    gw20 += (double)gu0 * a * s1;
+    gw21 += (double)gu1 * a * s1;
+    g_s1 += (double)(-gc * bs / (a * s1 * s1)) + (double)guw * a;
+    g_m1 -= gc;
+  }
+  const double g_v1 = -0.5 * g_s1 * (double)s1 * s1 * s1;
+  g_stats[(br * 2 + 0) * FP + j] = (float)((g_m1 - 2.0 * mean * g_v1) / n_total);
+  g_stats[(br * 2 + 1) * FP + j] = (float)(g_v1 / n_total);
+  grb[R.sd2_w() + j] = (float)gw20;
+  grb[R.sd2_w() + f + j] = (float)gw21;
+  if (j < 2) {
+    float bsum = 0.f;
+    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) bsum += g_bias[r * 4 + 2 * br + j];
+    grb[R.sd2_b() + j] = bsum;
+  }
+}
+
+// thread = (branch, feature); one workgroup.  g_sd0 replicas -> dW0, dgamma0, dbeta0 and the 9 moment gradients.
+__global__ void fold0_bwd_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total,
+                                 int pat, const float* __restrict__ g_sd0, float* __restrict__ g_raw_c,
+                                 float* __restrict__ g_mom, int f, int G, int FP) {
+  const int t = threadIdx.x;
+  __shared__ float mom[9];
+  __shared__ double red[5];   // gE0, gE1, gC00, gC01, gC11
+  if (t < 9) {
+    float sacc = 0.f;
+    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) sacc += mom_rep[r * 16 + t];
+    mom[t] = sacc;
+  }
+  if (t < 5) red[t] = 0.0;
+  __syncthreads();
+  int k0, k1, w0d, w1d;
+  gwtf_pattern_dims(pat, &k0, &k1, &w0d, &w1d);
+  const double e0 = mom[k0] / n_total, e1 = k1 >= 0 ? mom[k1] / n_total : 0.0;
+  const double c00 = mom[mom2_index(k0, k0)] / n_total - e0 * e0;
+  const double c11 = k1 >= 0 ? mom[mom2_index(k1, k1)] / n_total - e1 * e1 : 0.0;
+  const double c01 = k1 >= 0 ? mom[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] / n_total - e0 * e1 : 0.0;
+  if (t < 2 * f) {
+    const int br = t / f, j = t % f;
+    const GwtfRaw R(f, G);
+    const float* rb = raw_c + (size_t)br * R.branch_size();
+    float* grb = g_raw_c + (size_t)br * R.branch_size();
+    const double wa = rb[R.sd0_w() + j], wb = rb[R.sd0_w() + f + j];
+    const double gamma = rb[R.bn0() + j];
+    const double mean = wa * e0 + wb * e1;
+    double var = wa * wa * c00 + 2.0 * wa * wb * c01 + wb * wb * c11;
+    if (var < 0.0) var = 0.0;
+    const double isd = 1.0 / sqrt((double)((float)var + GWTF_BN_EPS));
+    const double s = gamma * isd;
+    double g0 = 0.0, g1 = 0.0, gc = 0.0;
+    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) {
+      const float* gs = g_sd0 + (size_t)r * (2 * 3 * FP) + (size_t)br * 3 * FP;
+      g0 += gs[j];
+      g1 += gs[FP + j];
+      gc += gs[2 * FP + j];
+    }
+    const double g_s = g0 * wa + g1 * wb - gc * mean;
+    const double g_mean = -gc * s;
+    const double g_var = g_s * gamma * (-0.5) * isd * isd * isd;
+    const double gwa = g0 * s + g_mean * e0 + g_var * 2.0 * (wa * c00 + wb * c01);
+    const double gwb = g1 * s + g_mean * e1 + g_var * 2.0 * (wa * c01 + wb * c11);
+    grb[R.sd0_w() + j] = (float)gwa;
+    grb[R.sd0_w() + f + j] = k1 >= 0 ? (float)gwb : 0.f;
+    grb[R.bn0() + j] = (float)(g_s * isd);       // d gamma
+    grb[R.bn0() + f + j] = (float)gc;            // d beta
+    atomicAdd(&red[0], g_mean * wa);
+    atomicAdd(&red[1], g_mean * wb);
+    atomicAdd(&red[2], g_var * wa * wa);
+    atomicAdd(&red[3], g_var * 2.0 * wa * wb);
+    atomicAdd(&red[4], g_var * wb * wb);
+  }
+  __syncthreads();
+  if (t == 0) {
+    for (int i = 0; i < 16; ++i) g_mom[i] = 0.f;
+    const double gC00 = red[2], gC01 = red[3], gC11 = red[4];
+    const double gE0 = red[0] - 2.0 * e0 * gC00 - e1 * gC01;
+    const double gE1 = red[1] - 2.0 * e1 * gC11 - e0 * gC01;
+    g_mom[k0] = (float)(gE0 / n_total);
+    g_mom[mom2_index(k0, k0)] = (float)(gC00 / n_total);
+    if (k1 >= 0) {
+      g_mom[k1] = (float)(gE1 / n_total);
+      g_mom[mom2_index(k1, k1)] = (float)(gC11 / n_total);
+      g_mom[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] = (float)(gC01 / n_total);
+    }
+  }
+}
+
+// g_in = g_a + g_b + d(moments)/dx:  gM_a + sum_b Q_ab x_b,  Q_aa = 2 gM_aa, Q_ab = gM_ab
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ x, const float* __restrict__ ga,
+                                                      const float* __restrict__ gb, const float* __restrict__ gm,
+                                                      float* __restrict__ g_in, int B, int N) {
+  const int b = blockIdx.y;
+  const float q00 = 2.f * gm[3], q01 = gm[4], q02 = gm[5], q11 = 2.f * gm[6], q12 = gm[7], q22 = 2.f * gm[8];
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const size_t o0 = ((size_t)b * 3 + 0) * N + n, o1 = o0 + N, o2 = o1 + N;
+    const float x0 = x[o0], x1 = x[o1], x2 = x[o2];
+    g_in[o0] = ga[o0] + gb[o0] + gm[0] + q00 * x0 + q01 * x1 + q02 * x2;
+    g_in[o1] = ga[o1] + gb[o1] + gm[1] + q01 * x0 + q11 * x1 + q12 * x2;
+    g_in[o2] = ga[o2] + gb[o2] + gm[2] + q02 * x0 + q12 * x1 + q22 * x2;
+  }
+}
+
+}  // namespace
+
+extern "C" int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, int G, void* stream) {
+  if (!raw || !packed_b || C <= 0 || f <= 0 || f > GWTF_MAX_FP || G <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(pack_w1t_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, raw, packed_b, C, f, G,
+                     gwtf_padded_width(f));
+  return (int)hipGetLastError();
+}
+
+// Backward of one coupling of the train-mode pipeline (single rank): coupling path, fold1, statistics path, fold0,
+// moments path, in five launches.  dA_mat holds dacc_apply + dacc_stats afterwards (dW1 = dA_mat h0_mat^T is the
+// caller's GEMM).  Workspaces g_sd0 [64][2][3][FP], g_bias [64][4] must be zero on entry; g_film [B][C][2][3][FP] is
+// accumulated for coupling c only (zero on entry).  g_raw_c receives dW0, dgamma0, dbeta0, dW2, db2 (other entries of the
+// record are left untouched).
+extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* raw_c,
+                                            const float* packed_w_c, const float* packed_b_c, const float* film_rec,
+                                            const float* film_raw, const float* moments_c, const float* ystats_c,
+                                            float* g_in, float* g_xa, float* g_xb, float* dA_mat, float* h0_mat,
+                                            float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom,
+                                            float* g_film_raw, float* g_raw_c, int c, int B, int N, int C, int f, int G,
+                                            int pattern0, float eps, void* stream) {
+  if (!x_in || !g_out || !g_ld || !raw_c || !packed_w_c || !packed_b_c || !film_rec || !film_raw || !moments_c ||
+      !ystats_c || !g_in || !g_xa || !g_xb || !dA_mat || !h0_mat || !g_film || !g_sd0 || !g_bias || !g_stats || !g_mom ||
+      !g_film_raw || !g_raw_c)
+    return GWTF_E_BADARG;
+  const int FP = gwtf_padded_width(f), pat = (pattern0 + c) % 6;
+  const double n_total = (double)B * N;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dA_mat, h0_mat, g_film, g_sd0,
+                                  g_bias, c, B, N, C, f, pattern0, eps, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
+                     g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP);
+  rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dA_mat, h0_mat, g_sd0, B, N, f, pat, stream);
+  if (rc) return rc;
+  hipLaunchKernelGGL(fold0_bwd_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, st, raw_c, moments_c, n_total, pat, g_sd0, g_raw_c,
+                     g_mom, f, G, FP);
+  const int bx = (N + 255) / 256;
+  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B), dim3(256), 0, st, x_in, g_xa, g_xb, g_mom, g_in, B, N);
+  return (int)hipGetLastError();
 }

@@ -255,6 +255,12 @@ class StackEngine:
         if needs_grad and mode == 'inverse' and c0.training:
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            if not multi and not getattr(self, 'force_autograd_chain', False):
+                from .autograd import train_density_forward_fast
+                out, logdet, lists, bn_batch = train_density_forward_fast(self, p, g)
+                self._update_running_stats(bn_batch)
+                self._last_lists = None
+                return out, logdet, lists
             from .autograd import train_density_forward
             out, logdet, (ps, mus, lvs), bn_batch = train_density_forward(self, p, g, distributed=multi)
             self._update_running_stats(bn_batch)

@@ -101,7 +101,7 @@ int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float*
  * moments [64][16] (9 used), ystats [64][2][FP][2]; the fold kernels sum the replicas. */
 int gwtf_train_moments(const float* p, float* moments /*pre-zeroed, accumulated*/, int B, int N, void* stream);
 int gwtf_train_fold0(const float* raw_c, const float* moments, double n_total, int pattern, float* packed_w_c,
-                     float* bn_batch_c /*[2 branches][4 kinds][2][f]: kind 0 <- {mean, unbiased var} of sd0_bn*/,
+                     float* packed_b_c /*may be NULL: backward record, sd0 section*/, float* bn_batch_c /*[2 branches][4 kinds][2][f]: kind 0 <- {mean, unbiased var} of sd0_bn*/,
                      int f, int G, void* stream);
 int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats /*pre-zeroed, accumulated*/,
                      int B, int N, int f, int pattern, void* stream);
@@ -113,7 +113,8 @@ int gwtf_train_apply(const float* p, const float* packed_w, const float* film_re
 
 /* The whole single-rank train-mode forward enqueued from C (moments + 4 launches per coupling); workspace sizes
  * are documented at the definition in csrc/gwtf_train.hip.  Result coordinates end in xbuf[(C-1) & 1]. */
-int gwtf_train_forward(const float* p, const float* raw, float* packed_w, const float* film_raw, float* moments,
+int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float* packed_b /*may be NULL*/,
+                       const float* film_raw, float* moments,
                        float* ystats, float* bn_batch, float* film_rec, float* xbuf, float* logdet,
                        float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G, int pattern0,
                        float eps, int mode, void* stream);
@@ -136,8 +137,20 @@ int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g
                            float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0,
                            float eps, void* stream);
 
+/* Backward records of the train pipeline: W1T sections from the un-scaled sd1 weights (sd0 sections: gwtf_train_fold0). */
+int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, int G, void* stream);
+/* Backward of ONE coupling of the single-rank train pipeline (coupling path + fold1 + statistics path + fold0 + moments
+ * path; csrc/gwtf_train.hip).  Workspace contract at the definition. */
+int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* raw_c,
+                                 const float* packed_w_c, const float* packed_b_c, const float* film_rec,
+                                 const float* film_raw, const float* moments_c, const float* ystats_c, float* g_in,
+                                 float* g_xa, float* g_xb, float* dA_mat, float* h0_mat, float* g_film, float* g_sd0,
+                                 float* g_bias, float* g_stats, float* g_mom, float* g_film_raw, float* g_raw_c,
+                                 int c, int B, int N, int C, int f, int G, int pattern0, float eps, void* stream);
+
 /* Backward of gwtf_train_stats: g_stats [2][2][FP] = dL/d{sum y, sum y^2} per branch and feature (replicas already
- * summed by the caller) -> g_in (kept coordinates only), dA_mat / h0_mat for the dW1 GEMM, g_sd0 [64][2][3][FP]. */
+ * summed by the caller) -> g_in (kept coordinates only); dA_mat += dL/dy (ACCUMULATED: the coupling path wrote it first,
+ * or pre-zero it), h0_mat for the dW1 GEMM; g_sd0 [64][2][3][FP] +=. */
 int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
                         float* g_in, float* dA_mat, float* h0_mat, float* g_sd0, int B, int N, int f, int pattern,
                         void* stream);

@@ -592,3 +592,29 @@ def test_whole_train_step_hipgraph_replay_equals_eager():
         got.append(loss.item())
     # statistics are accumulated with float atomics: run-to-run differences in the last bits are expected
     assert all(abs(a - b) / abs(b) < 1e-5 for a, b in zip(got, eager)) and eager[-1] < eager[0]
+
+
+def test_train_fast_path_equals_autograd_chain():
+    """The fused C train pipeline (single rank) and the chain of per-coupling autograd nodes (multi-rank path) are two
+    implementations of the same gradients."""
+    L, f, G, B, N = 2, 19, 12, 4, 90
+    p, g = synth_inputs(B, N, G, 5)
+    rng = np.random.default_rng(9)
+    wz, wl = rng.normal(size=(B, 3, N)).astype(np.float32), rng.normal(size=(B, 3, N)).astype(np.float32)
+    res = []
+    for chain in (False, True):
+        m, _ = decoder_and_state(L, f, G, 4242)
+        m = m.to(DEV).train()
+        m.engine().force_autograd_chain = chain
+        pt, gt = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+        z, ld = m.forward_fused(pt, gt, 'inverse')
+        ((z * dev(wz)).sum() + (ld * dev(wl)).sum()).backward()
+        res.append((host(z), host(pt.grad), host(gt.grad), {k: host(v.grad) for k, v in m.named_parameters()},
+                    {k: host(v) for k, v in m.state_dict().items() if 'running' in k}))
+    # batch statistics over B=4 latent rows amplify rounding (fp32 folds in C vs double-precision torch folds)
+    assert maxabs(res[0][0], res[1][0]) < 1e-4
+    assert _rel(res[0][1], res[1][1]) < 1e-3 and _rel(res[0][2], res[1][2]) < 1e-3
+    for k in res[0][3]:
+        assert _rel(res[0][3][k], res[1][3][k]) < 2e-3, k
+    for k in res[0][4]:
+        assert maxabs(res[0][4][k], res[1][4][k]) < 1e-4, k
