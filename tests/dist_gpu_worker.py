@@ -38,8 +38,21 @@ def main():
     out = {'z': z.detach().cpu().numpy(), 'dp': pt.grad.cpu().numpy(), 'dg': gt.grad.cpu().numpy(),
            'rv': torch.cat([v.reshape(-1) for k, v in m.state_dict().items() if k.endswith('running_var')]).cpu().numpy()}
     np.savez(os.path.join(os.environ['GWTF_TMP'], f'rank{rank}.npz'), grads=grads.cpu().numpy(), b0=b0, b1=b1, **out)
+    # the reference's own wrapping (train_ae.py:152-153): SyncBatchNorm conversion + DistributedDataParallel
+    m2, _ = decoder_and_state(L, f, G, 13)
+    m2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m2.cuda().train())
+    ddp = torch.nn.parallel.DistributedDataParallel(m2, find_unused_parameters=True)
+    pt2 = torch.from_numpy(p[b0:b1]).cuda().requires_grad_(True)
+    gt2 = torch.from_numpy(g[b0:b1]).cuda().requires_grad_(True)
+    ps2, mus2, lvs2 = ddp(pt2, gt2, mode='inverse')
+    loss2 = (ps2[0] * torch.from_numpy(wz[b0:b1]).cuda()).sum() + (sum(lvs2) * torch.from_numpy(wl[b0:b1]).cuda()).sum()
+    loss2.backward()
+    ddp_grads = torch.cat([q.grad.reshape(-1) for q in m2.parameters()]) * world      # DDP averages; undo for comparison
+    ddp_err = float((ddp_grads - grads).abs().max() / grads.abs().max())
+    assert ddp_err < 1e-5, ddp_err
     dist.barrier()
     if rank == 0:
+        print(f'DDP wrapped: parameter gradients == flat all-reduce path (rel {ddp_err:.1e})', flush=True)
         dist.destroy_process_group()
         m1, _ = decoder_and_state(L, f, G, 13)
         m1 = m1.cuda().train()
