@@ -38,10 +38,10 @@ _SIGNATURES = {
     'gwtf_train_apply': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_train_forward': (ctypes.c_int, [_c_fp] * 14 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_pack_w1t': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_train_coupling_backward': (ctypes.c_int, [_c_fp] * 22 + [ctypes.c_int] * 7 + [ctypes.c_float, _c_fp]),
+    'gwtf_train_coupling_backward': (ctypes.c_int, [_c_fp] * 22 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_packed_b_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_pack_folded': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 6 + [ctypes.c_float, _c_fp]),
+    'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 4 + [_c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_mixture_nll_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 3 + [_c_fp]),

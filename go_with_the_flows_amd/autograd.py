@@ -97,7 +97,7 @@ class StackDensityFn(torch.autograd.Function):
     """out, logdet = inverse pass of the whole stack, differentiable w.r.t. p and the folded tensors."""
 
     @staticmethod
-    def forward(ctx, p, W0f, c0f, W1p, cvec, u, b2, C, f, pattern0, eps):
+    def forward(ctx, p, W0f, c0f, W1p, cvec, u, b2, C, f, pattern0, eps, mode):
         L = _lib.lib()
         FP = L.gwtf_padded_width(f)
         p = p.contiguous()
@@ -109,15 +109,16 @@ class StackDensityFn(torch.autograd.Function):
                                           c0f.contiguous().data_ptr(), pw.data_ptr(), pb.data_ptr(), C, f,
                                           _lib._stream(p)))
         rec = film_record(cvec, u, b2, FP)
-        out, logdet, lists = _lib.stack_forward(p, pw, rec, C, f, pattern0, eps, 'inverse', True)
+        out, logdet, lists = _lib.stack_forward(p, pw, rec, C, f, pattern0, eps, mode, True)
         ctx.save_for_backward(p, lists[0], pw, pb, rec)
-        ctx.meta = (C, f, FP, pattern0, eps)
+        ctx.meta = (C, f, FP, pattern0, eps, mode)
         return out, logdet
 
     @staticmethod
     def backward(ctx, g_out, g_logdet):
         p, ps, pw, pb, rec = ctx.saved_tensors
-        C, f, FP, pattern0, eps = ctx.meta
+        C, f, FP, pattern0, eps, mode = ctx.meta
+        inverse = mode == 'inverse'
         L = _lib.lib()
         B, _, N = p.shape
         dev = p.device
@@ -134,14 +135,17 @@ class StackDensityFn(torch.autograd.Function):
         bufs = [torch.empty_like(p), torch.empty_like(p)]
         st = _lib._stream(p)
         with torch.cuda.device(dev):
-            for c in range(C):                       # reverse of the forward's processing order C-1 .. 0
-                x_in = ps[c + 1] if c + 1 < C else p
+            for c in (range(C) if inverse else range(C - 1, -1, -1)):   # reverse of the forward's processing order
+                if inverse:
+                    x_in = ps[c + 1] if c + 1 < C else p
+                else:
+                    x_in = ps[c - 1] if c > 0 else p
                 nxt = bufs[c & 1]
                 _lib.check(L.gwtf_coupling_backward(x_in.data_ptr(), cur.data_ptr(), g_ld.data_ptr(),
                                                     pw[c * PW:].data_ptr(), pb[c * PB:].data_ptr(), rec.data_ptr(),
                                                     nxt.data_ptr(), dA.data_ptr(), H0.data_ptr(), g_film.data_ptr(),
                                                     g_sd0[c].data_ptr(), g_bias[c].data_ptr(), c, B, N, C, f, pattern0,
-                                                    float(eps), st))
+                                                    float(eps), _lib._MODES[mode], st))
                 # dW1p[k][j][i] = sum_{b,n} dacc[k,j,(b,n)] h[k,i,(b,n)]: one batched GEMM with K = B*N -> BLAS
                 gW1p[c] = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
                 cur = nxt
@@ -151,14 +155,14 @@ class StackDensityFn(torch.autograd.Function):
         g_cvec = g_film[:, :, :, 0, :f].contiguous()
         g_u = g_film[:, :, :, 1:3, :f].contiguous()
         g_b2 = g_bias.sum(1).reshape(C, 2, 2)
-        return cur, g_W0f, g_c0f, gW1p, g_cvec, g_u, g_b2, None, None, None, None
+        return cur, g_W0f, g_c0f, gW1p, g_cvec, g_u, g_b2, None, None, None, None, None
 
 
-def density_forward(engine, p, g):
-    """Differentiable (out, logdet) of the inverse pass; eval-mode BatchNorm."""
+def density_forward(engine, p, g, mode='inverse'):
+    """Differentiable (out, logdet) of the whole stack in either direction; eval-mode BatchNorm."""
     eps = engine.couplings[0]._eps_value
     W0f, c0f, W1p, cvec, u, b2 = fold(engine, g.float(), eps)
-    return StackDensityFn.apply(p.float(), W0f, c0f, W1p, cvec, u, b2, engine.C, engine.f, engine.pattern0, eps)
+    return StackDensityFn.apply(p.float(), W0f, c0f, W1p, cvec, u, b2, engine.C, engine.f, engine.pattern0, eps, mode)
 
 
 # ======================================================================================================================
@@ -251,21 +255,21 @@ class ApplyFn(torch.autograd.Function):
     """One coupling with given folded parameters: x -> (x_out, logvar, mu[detached])."""
 
     @staticmethod
-    def forward(ctx, x, W0f, c0f, W1, cvec, u, b2, pw, pb, pat, f, eps):
+    def forward(ctx, x, W0f, c0f, W1, cvec, u, b2, pw, pb, pat, f, eps, mode):
         L = _lib.lib()
         x = x.contiguous()
         FP = L.gwtf_padded_width(f)
         rec = film_record(cvec.unsqueeze(1), u.unsqueeze(1), b2.unsqueeze(0), FP)
-        out, lv, lists = _lib.stack_forward(x, pw, rec, 1, f, pat, eps, 'inverse', True)
+        out, lv, lists = _lib.stack_forward(x, pw, rec, 1, f, pat, eps, mode, True)
         ctx.save_for_backward(x, pw, pb, rec)
-        ctx.meta = (pat, f, FP, eps)
+        ctx.meta = (pat, f, FP, eps, mode)
         ctx.mark_non_differentiable(lists[1][0])
         return out, lv, lists[1][0]
 
     @staticmethod
     def backward(ctx, g_out, g_lv, _g_mu):
         x, pw, pb, rec = ctx.saved_tensors
-        pat, f, FP, eps = ctx.meta
+        pat, f, FP, eps, mode = ctx.meta
         L = _lib.lib()
         B, _, N = x.shape
         dev = x.device
@@ -282,12 +286,12 @@ class ApplyFn(torch.autograd.Function):
             _lib.check(L.gwtf_coupling_backward(x.data_ptr(), g_out.data_ptr(), g_lv.data_ptr(), pw.data_ptr(), pb.data_ptr(),
                                                 rec.data_ptr(), g_x.data_ptr(), dA.data_ptr(), H0.data_ptr(),
                                                 g_film.data_ptr(), g_sd0.data_ptr(), g_bias.data_ptr(), 0, B, N, 1, f, pat,
-                                                float(eps), _lib._stream(x)))
+                                                float(eps), _lib._MODES[mode], _lib._stream(x)))
         gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
         gs = g_sd0.sum(0)
         return (g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1,
                 g_film[:, 0, :, 0, :f].contiguous(), g_film[:, 0, :, 1:3, :f].contiguous(), g_bias.sum(0).reshape(2, 2),
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 def _film_train(P, g, eps):
@@ -356,7 +360,7 @@ class _AllGatherRows(torch.autograd.Function):
         return g_all[ctx.row0:ctx.row0 + ctx.rows]
 
 
-def train_density_forward(engine, p, g, distributed=False):
+def train_density_forward(engine, p, g, distributed=False, mode='inverse'):
     """Differentiable train-mode density pass.  Returns out, logdet, per-coupling lists (ps, mus, lvs in direct
     order; ps/lvs differentiable) and bn_batch (C,2,4,2,f) for the running-statistic update.
     distributed=True: statistics (and their gradients) are summed over torch.distributed's default group and the
@@ -390,7 +394,7 @@ def train_density_forward(engine, p, g, distributed=False):
     x = p.float().contiguous()
     ps, mus, lvs = [None] * C, [None] * C, [None] * C
     logdet = None
-    for c in range(C - 1, -1, -1):
+    for c in (range(C - 1, -1, -1) if mode == 'inverse' else range(C)):
         pat = (engine.pattern0 + c) % 6
         k0, k1 = {0: (1, 2), 1: (0, 2), 2: (0, 1), 3: (2, -1), 4: (1, -1), 5: (0, -1)}[pat]
         M = MomentsFn.apply(x)
@@ -427,7 +431,7 @@ def train_density_forward(engine, p, g, distributed=False):
         as1 = a[:, c] * s1
         cvec = -m1.float() + bsh[:, c] / as1
         u = P['W2'][c].unsqueeze(0) * as1.unsqueeze(2)
-        x, lv, mu = ApplyFn.apply(x, W0f, c0f, W1, cvec, u, P['b2'][c], pw, pb, pat, f, eps)
+        x, lv, mu = ApplyFn.apply(x, W0f, c0f, W1, cvec, u, P['b2'][c], pw, pb, pat, f, eps, mode)
         ps[c], mus[c], lvs[c] = x, mu, lv
         logdet = lv if logdet is None else logdet + lv
         with torch.no_grad():
@@ -461,7 +465,7 @@ def _gather_film(engine):
 
 class TrainStackFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, p, raw, a, bsh, C, f, G, pattern0, eps):
+    def forward(ctx, p, raw, a, bsh, C, f, G, pattern0, eps, mode):
         L = _lib.lib()
         p, raw = p.contiguous(), raw.contiguous()
         B, _, N = p.shape
@@ -487,17 +491,18 @@ class TrainStackFn(torch.autograd.Function):
             _lib.check(L.gwtf_train_forward(p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr(), film_raw.data_ptr(),
                                             mom.data_ptr(), ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(),
                                             xbuf.data_ptr(), logdet.data_ptr(), lists[0].data_ptr(), lists[1].data_ptr(),
-                                            lists[2].data_ptr(), B, N, C, f, G, pattern0, float(eps), _lib.MODE_INVERSE, st))
-        out = xbuf[(C - 1) & 1].clone()
+                                            lists[2].data_ptr(), B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], st))
+        out = xbuf[(C - 1) & 1].clone()     # the pipeline ping-pongs between the two buffers in both directions
         ctx.save_for_backward(p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats)
-        ctx.meta = (C, f, G, FP, pattern0, eps)
+        ctx.meta = (C, f, G, FP, pattern0, eps, mode)
         ctx.mark_non_differentiable(lists, bn_batch)
         return out, logdet, lists, bn_batch
 
     @staticmethod
     def backward(ctx, g_out, g_logdet, _gl, _gb):
         p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats = ctx.saved_tensors
-        C, f, G, FP, pattern0, eps = ctx.meta
+        C, f, G, FP, pattern0, eps, mode = ctx.meta
+        inverse = mode == 'inverse'
         L = _lib.lib()
         B, _, N = p.shape
         dev = p.device
@@ -520,9 +525,12 @@ class TrainStackFn(torch.autograd.Function):
         bufs = [torch.empty_like(p), torch.empty_like(p)]
         st = _lib._stream(p)
         with torch.cuda.device(dev):
-            for c in range(C):                                   # forward processed C-1 .. 0
-                step = C - 1 - c                                 # this coupling's position in the forward order
-                x_in = ps[c + 1] if c + 1 < C else p
+            for c in (range(C) if inverse else range(C - 1, -1, -1)):   # reverse of the forward's processing order
+                step = C - 1 - c if inverse else c               # this coupling's position in the forward order
+                if inverse:
+                    x_in = ps[c + 1] if c + 1 < C else p
+                else:
+                    x_in = ps[c - 1] if c > 0 else p
                 nxt = bufs[c & 1]
                 g_raw_c = g_raw[c * RC:(c + 1) * RC]
                 _lib.check(L.gwtf_train_coupling_backward(
@@ -530,22 +538,23 @@ class TrainStackFn(torch.autograd.Function):
                     pb[c * PB:].data_ptr(), film_rec.data_ptr(), film_raw.data_ptr(), mom[step].data_ptr(),
                     ystats[c].data_ptr(), nxt.data_ptr(), gxa.data_ptr(), gxb.data_ptr(), dA.data_ptr(), H0.data_ptr(),
                     g_film.data_ptr(), g_sd0[c].data_ptr(), g_bias[c].data_ptr(), g_stats[c].data_ptr(), g_mom[c].data_ptr(),
-                    g_film_raw.data_ptr(), g_raw_c.data_ptr(), c, B, N, C, f, G, pattern0, float(eps), st))
+                    g_film_raw.data_ptr(), g_raw_c.data_ptr(), c, B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], st))
                 gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))            # (2,f,f): one GEMM, K = B*N
                 for br in range(2):
                     off = br * br_size + 6 * f                   # GwtfRaw::sd1_w
                     g_raw_c[off:off + f * f].copy_(gW1[br].reshape(-1))
                 cur = nxt
-        return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None
+        return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None, None
 
 
-def train_density_forward_fast(engine, p, g):
+def train_density_forward_fast(engine, p, g, mode='inverse'):
     """Single-rank train-mode density pass through the fused C pipeline.  -> out, logdet, lists (detached), bn_batch."""
     C, f, G, eps = engine.C, engine.f, engine.G, engine.couplings[0]._eps_value
     if p.shape[0] < 2:
         raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
     a, bsh, fmean, fvar = _film_train(_gather_film(engine), g.float(), eps)
-    out, logdet, lists, bn_batch = TrainStackFn.apply(p.float(), engine.raw_arena(), a, bsh, C, f, G, engine.pattern0, eps)
+    out, logdet, lists, bn_batch = TrainStackFn.apply(p.float(), engine.raw_arena(), a, bsh, C, f, G, engine.pattern0, eps,
+                                                      mode)
     bn_batch = bn_batch.clone()
     bn_batch[:, :, 2:4, 0] = fmean
     bn_batch[:, :, 2:4, 1] = fvar

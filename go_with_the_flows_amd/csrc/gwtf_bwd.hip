@@ -1,5 +1,5 @@
-// gwtf_bwd.hip -- backward of ONE elementary coupling (density / inverse direction, BatchNorm as a fixed
-// affine: model.eval(), or the folded statistics of the train pipeline held constant).
+// gwtf_bwd.hip -- backward of ONE elementary coupling (both directions; BatchNorm as a fixed affine: model.eval(),
+// or the folded statistics of the train pipeline held constant).
 //
 // Reference semantics: autograd through CondRealNVPFlow3D.forward (lib/networks/flows.py:95-117), i.e. what
 // loss.backward() (training.py:54) computes for this layer.  Formulation in the FOLDED parameters the forward
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
                                                   float* __restrict__ h0_mat, float* __restrict__ g_film,
                                                   float* __restrict__ g_sd0, float* __restrict__ g_bias,
                                                   const float* __restrict__ g_stats, int B, int N, int C, int c, int pat,
-                                                  float eps, int kk_steps, int f) {
+                                                  float eps, int kk_steps, int f, int mode) {
   using K = Cfg<MB>;
   using KB = BCfg<MB>;
   constexpr int FP = K::FP;
@@ -157,17 +157,25 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
       const float mu = res[1][s] + bias[2 + s];
       const float e = expf(lv);
       const float sc = sqrtf(eps + e);
-      const float outw = (xw[s] - mu) / sc;
-      gx[s] = gow[s] / sc;
-      const float dsc = -gow[s] * outw / sc;
+      float dsc;
+      if (mode == GWTF_MODE_INVERSE) {       // out = (x - mu)/s
+        const float outw = (xw[s] - mu) / sc;
+        gx[s] = gow[s] / sc;
+        dsc = -gow[s] * outw / sc;
+        dt[1][s] = -gx[s];
+      } else {                                // out = s*x + mu
+        gx[s] = gow[s] * sc;
+        dsc = gow[s] * xw[s];
+        dt[1][s] = gow[s];
+      }
       const float dlv = glw[s] + dsc * e / (2.0f * sc);
       dt[0][s] = dlv / (den * den);
-      dt[1][s] = -gx[s];
     }
   }
+  const float keep_scale = mode == GWTF_MODE_INVERSE ? 1.0f / s_keep : s_keep;
   float gin[3];
 #pragma unroll
-  for (int d = 0; d < 3; ++d) gin[d] = STATS ? 0.f : (d == w0 ? gx[0] : ((!keep2 && d == w1) ? gx[1] : go[d] / s_keep));
+  for (int d = 0; d < 3; ++d) gin[d] = STATS ? 0.f : (d == w0 ? gx[0] : ((!keep2 && d == w1) ? gx[1] : go[d] * keep_scale));
   if (!STATS) {  // sd2 bias gradient: sum of dt over the wave's valid points
     float bsum[4] = {own_valid ? dt[0][0] : 0.f, own_valid ? dt[0][1] : 0.f, own_valid ? dt[1][0] : 0.f,
                      own_valid ? dt[1][1] : 0.f};
@@ -378,10 +386,10 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
 template <int MB, bool STATS>
 int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
                const float* film, float* g_in, float* dA, float* h0, float* g_film, float* g_sd0, float* g_bias,
-               const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, hipStream_t st) {
+               const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, int mode, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg))), block(256);
-#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dA, h0, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f)
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dA, h0, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B
   return (int)hipGetLastError();
@@ -406,11 +414,11 @@ extern "C" int gwtf_pack_folded(const float* W1p, const float* W0f, const float*
 static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                         const float* packed_b_c, const float* film, float* g_in, float* dA_mat, float* h0_mat,
                         float* g_film, float* g_sd0, float* g_bias, const float* g_stats, int c, int B, int N, int C, int f,
-                        int pat, float eps, void* stream) {
+                        int pat, float eps, int mode, void* stream) {
   const int kk_steps = (f + 3) / 4;
   const int nb = (long)B * N >= 2048L * 32 ? 2 : 1;
   hipStream_t st = (hipStream_t)stream;
-#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, st
+#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, st
   switch (gwtf_padded_width(f) / 16) {
     case 1: return stats ? launch_bwd<1, true>(nb, GWTF_A) : launch_bwd<1, false>(nb, GWTF_A);
     case 2: return stats ? launch_bwd<2, true>(nb, GWTF_A) : launch_bwd<2, false>(nb, GWTF_A);
@@ -424,12 +432,13 @@ static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const
 extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                       const float* packed_b_c, const float* film, float* g_in, float* dA_mat,
                                       float* h0_mat, float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C,
-                                      int f, int pattern0, float eps, void* stream) {
+                                      int f, int pattern0, float eps, int mode, void* stream) {
   if (!x_in || !g_out || !g_ld || !packed_w_c || !packed_b_c || !film || !g_in || !dA_mat || !h0_mat || !g_film || !g_sd0 ||
-      !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5)
+      !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5 ||
+      (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE))
     return GWTF_E_BADARG;
   return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias,
-                      nullptr, c, B, N, C, f, (pattern0 + c) % 6, eps, stream);
+                      nullptr, c, B, N, C, f, (pattern0 + c) % 6, eps, mode, stream);
 }
 
 extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c,
@@ -439,5 +448,5 @@ extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, cons
       f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5)
     return GWTF_E_BADARG;
   return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dA_mat, h0_mat,
-                      g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, stream);
+                      g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, stream);
 }

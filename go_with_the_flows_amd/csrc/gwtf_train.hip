@@ -378,7 +378,7 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
                                             float* g_in, float* g_xa, float* g_xb, float* dA_mat, float* h0_mat,
                                             float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom,
                                             float* g_film_raw, float* g_raw_c, int c, int B, int N, int C, int f, int G,
-                                            int pattern0, float eps, void* stream) {
+                                            int pattern0, float eps, int mode, void* stream) {
   if (!x_in || !g_out || !g_ld || !raw_c || !packed_w_c || !packed_b_c || !film_rec || !film_raw || !moments_c ||
       !ystats_c || !g_in || !g_xa || !g_xb || !dA_mat || !h0_mat || !g_film || !g_sd0 || !g_bias || !g_stats || !g_mom ||
       !g_film_raw || !g_raw_c)
@@ -387,7 +387,7 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   const double n_total = (double)B * N;
   hipStream_t st = (hipStream_t)stream;
   int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dA_mat, h0_mat, g_film, g_sd0,
-                                  g_bias, c, B, N, C, f, pattern0, eps, stream);
+                                  g_bias, c, B, N, C, f, pattern0, eps, mode, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
                      g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP);

@@ -252,27 +252,27 @@ class StackEngine:
         c0 = self.couplings[0]
         needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
                                                   any(t.requires_grad for t in self._tracked or self._collect()))
-        if needs_grad and mode == 'inverse' and c0.training:
+        if needs_grad and c0.training:
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
             if not multi and not getattr(self, 'force_autograd_chain', False):
                 from .autograd import train_density_forward_fast
-                out, logdet, lists, bn_batch = train_density_forward_fast(self, p, g)
+                out, logdet, lists, bn_batch = train_density_forward_fast(self, p, g, mode)
                 self._update_running_stats(bn_batch)
                 self._last_lists = None
                 return out, logdet, lists
             from .autograd import train_density_forward
-            out, logdet, (ps, mus, lvs), bn_batch = train_density_forward(self, p, g, distributed=multi)
+            out, logdet, (ps, mus, lvs), bn_batch = train_density_forward(self, p, g, distributed=multi, mode=mode)
             self._update_running_stats(bn_batch)
             self._last_lists = (ps, mus, lvs)
             lists = (torch.stack([t.detach() for t in ps]), torch.stack(mus), torch.stack([t.detach() for t in lvs])) \
                 if want_lists else None
             return out, logdet, lists
-        if needs_grad and mode == 'inverse' and not c0.training:
+        if needs_grad and not c0.training:
             # differentiable density pass: HIP forward + HIP backward (autograd.py); the per-coupling lists are
             # returned detached (no reference consumer differentiates through them)
             from .autograd import density_forward
-            out, logdet = density_forward(self, p, g)
+            out, logdet = density_forward(self, p, g, mode)
             lists = None
             if want_lists:
                 with torch.no_grad():
@@ -368,11 +368,8 @@ class StackEngine:
         if out.requires_grad:
             # differentiable entries the reference's loss reads: ps[0] (inverse) and sum(logvars) -- keep the sum
             # differentiable by routing it through one slot (the others are detached constants)
-            if mode == 'inverse':
-                ps[0] = out
-                lvs[0] = lvs[0] + (logdet - logdet.detach())
-            else:
-                ps[-1] = out
+            ps[0 if mode == 'inverse' else -1] = out
+            lvs[0] = lvs[0] + (logdet - logdet.detach())
         return ps, mus, lvs
 
 

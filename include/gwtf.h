@@ -119,7 +119,7 @@ int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float*
                        float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G, int pattern0,
                        float eps, int mode, void* stream);
 
-/* ---- backward (density direction, BatchNorm as a fixed affine) --------------------------------------------
+/* ---- backward (both directions, BatchNorm as a fixed affine) --------------------------------------------------
  * Autograd of CondRealNVPFlow3D.forward (reference flows.py:95-117 as differentiated by loss.backward(),
  * training.py:54), one coupling per call, in the FOLDED parameters the forward kernel consumes:
  *   W1p [C][2][f][f] = sd1.weight with sd1_bn's scale folded, W0f [C][2][f][2] / c0f [C][2][f] = sd0 with sd0_bn folded,
@@ -135,7 +135,7 @@ int gwtf_pack_folded(const float* W1p, const float* W0f, const float* c0f, float
 int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                            const float* packed_b_c, const float* film, float* g_in, float* dA_mat, float* h0_mat,
                            float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0,
-                           float eps, void* stream);
+                           float eps, int mode, void* stream);
 
 /* Backward records of the train pipeline: W1T sections from the un-scaled sd1 weights (sd0 sections: gwtf_train_fold0). */
 int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, int G, void* stream);
@@ -146,7 +146,8 @@ int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const fl
                                  const float* film_raw, const float* moments_c, const float* ystats_c, float* g_in,
                                  float* g_xa, float* g_xb, float* dA_mat, float* h0_mat, float* g_film, float* g_sd0,
                                  float* g_bias, float* g_stats, float* g_mom, float* g_film_raw, float* g_raw_c,
-                                 int c, int B, int N, int C, int f, int G, int pattern0, float eps, void* stream);
+                                 int c, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
+                                 void* stream);
 
 /* Backward of gwtf_train_stats: g_stats [2][2][FP] = dL/d{sum y, sum y^2} per branch and feature (replicas already
  * summed by the caller) -> g_in (kept coordinates only); dA_mat += dL/dy (ACCUMULATED: the coupling path wrote it first,

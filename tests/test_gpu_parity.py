@@ -395,13 +395,34 @@ def test_gradients_vs_torch_cpu_autograd(cfg):
     assert worst < 5e-4, (worst_key, worst)
 
 
-def test_backward_unsupported_paths_fail_loudly():
-    m, _ = decoder_and_state(1, 8, 8, 3)
-    m = m.to(DEV)
-    p, g = synth_inputs(2, 16, 8, 4)
-    out, _ = m.eval().forward_fused(dev(p).requires_grad_(True), dev(g), 'direct')
-    with pytest.raises(NotImplementedError):
-        out.sum().backward()
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('cfg', [(1, 8, 8, 3, 40), (2, 37, 16, 2, 130)])
+def test_sampling_direction_gradients(cfg, training):
+    """mode='direct' (base -> data) is differentiable too: every gradient against CPU autograd, both BatchNorm modes."""
+    from oracle import torch_port as tp
+    L, f, G, B, N = cfg
+    m, st = decoder_and_state(L, f, G, 555 + f)
+    m = m.to(DEV).train(training)
+    p, g = synth_inputs(B, N, G, 66 + N)
+    rng = np.random.default_rng(8)
+    wz, wl = rng.normal(size=(B, 3, N)).astype(np.float32), rng.normal(size=(B, 3, N)).astype(np.float32)
+    tst = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and not k.endswith(('running_mean', 'running_var', 'eps')))
+           for k, v in st.items()}
+    pc, gc = torch.from_numpy(p).requires_grad_(True), torch.from_numpy(g).requires_grad_(True)
+    zc, ldc = tp.decoder_fused(pc, gc, tst, L, 'direct', grad=True, training=training)
+    ((zc * torch.from_numpy(wz)).sum() + (ldc * torch.from_numpy(wl)).sum()).backward()
+    pt, gt = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+    ps, mus, lvs = m(pt, gt, mode='direct')
+    ((ps[-1] * dev(wz)).sum() + (sum(lvs) * dev(wl)).sum()).backward()
+    tol = 3e-3 if training else 5e-4
+    assert maxabs(host(ps[-1]), zc.detach().numpy()) < (1e-4 if training else TOL_COORD)
+    assert _rel(host(pt.grad), pc.grad.numpy()) < tol and _rel(host(gt.grad), gc.grad.numpy()) < tol
+    worst, wk = 0.0, None
+    for k, prm in m.named_parameters():
+        e = _rel(host(prm.grad), tst[k].grad.numpy())
+        if e > worst:
+            worst, wk = e, k
+    assert worst < 2 * tol, (wk, worst)
 
 
 def test_g9_train_mode_gradients_match_reference_autograd():
@@ -551,7 +572,7 @@ def test_two_rank_syncbn_training_matches_single_process(tmp_path):
            '--master-port', str(port), os.path.join(os.path.dirname(__file__), 'dist_gpu_worker.py')]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert 'DIST2' in r.stdout, r.stdout[-2000:]
+    assert 'DIST2' in r.stdout and 'DDP wrapped' in r.stdout, r.stdout[-2000:]
 
 
 def test_whole_train_step_hipgraph_replay_equals_eager():
