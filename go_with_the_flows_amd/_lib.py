@@ -45,6 +45,8 @@ _SIGNATURES = {
     'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 4 + [_c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_mixture_nll_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 3 + [_c_fp]),
+    'gwtf_adam_step': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_double,
+                                       ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -176,6 +176,13 @@ int gwtf_mixture_nll_backward(const float* z, const float* logdet, const float* 
                               float* g_logdet, float* g_mu0, float* g_lv0, float* g_logits, int K, int B, int N,
                               void* stream);
 
+/* Fused step of the reference's custom Adam / AMSGrad (lib/networks/optimizers.py:15-76; un-scaled decoupled decay
+ * p -= wd*p + lr*m_hat/(sqrt(v_hat)+eps), :69-72) over many tensors per launch.  HOST arrays of n_tensors DEVICE
+ * pointers; max_exp_avg_sq may be NULL when amsgrad == 0; `step` = 1-based count including this update. */
+int gwtf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                   float* const* max_exp_avg_sq, const size_t* numel, int n_tensors, float lr, double beta1, double beta2,
+                   float eps, float weight_decay, int step, int amsgrad, void* stream);
+
 /* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
  * (16, 32 or 64; anything else restores the size-based default).  Process-wide, not thread-safe. */
 void gwtf_debug_set_points_per_wave(int points);

@@ -257,3 +257,26 @@ def to_numpy_state(state_dict) -> Dict[str, np.ndarray]:
 
 def cast_inputs(dtype, *arrays):
     return tuple(np.asarray(a).astype(dtype) for a in arrays)
+
+
+# --------------------------------------------------------------------------
+# optimiser: reference lib/networks/optimizers.py:15-76
+# --------------------------------------------------------------------------
+def adam_step(p, g, m, v, vmax, step, lr, beta1, beta2, eps, weight_decay, amsgrad):
+    """One update of the reference's Adam/AMSGrad on numpy arrays (returns new p, m, v, vmax); `step` is 1-based."""
+    dt = p.dtype.type
+    m = m * dt(beta1) + dt(1 - beta1) * g
+    v = v * dt(beta2) + dt(1 - beta2) * g * g
+    if amsgrad:
+        vmax = np.maximum(vmax, v)
+        denom = np.sqrt(vmax)
+    else:
+        denom = np.sqrt(v)
+    bc1 = dt(1 - beta1 ** step)
+    bc2 = dt(math.sqrt(1 - beta2 ** step))
+    upd = (m / bc1) / (denom / bc2 + dt(eps))
+    if weight_decay != 0:
+        p = p - (p * dt(weight_decay) + dt(lr) * upd)
+    else:
+        p = p - dt(lr) * upd
+    return p, m, v, vmax

@@ -275,6 +275,33 @@ def g9_train_gradients():
     save('g9_train_gradients', **out)
 
 
+def g10_optimizer():
+    """Three steps of the reference's Adam (both amsgrad settings, with weight decay and the LRUpdater schedule)."""
+    from lib.networks.optimizers import Adam as RefAdam, LRUpdater
+    rng = np.random.default_rng(1000)
+    shapes = [(7,), (5, 3), (1, 4, 9), (130,)]
+    out = {}
+    for ams in (0, 1):
+        ps = [torch.nn.Parameter(T(rng.normal(size=s).astype(np.float32))) for s in shapes]
+        for i, q in enumerate(ps):
+            out[f'p0_{ams}_{i}'] = npy(q).copy()
+        opt = RefAdam(ps, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-3, amsgrad=bool(ams))
+        sched = LRUpdater(10, cycle_length=4, min_lr=1e-3, max_lr=1e-2, beta1=0.9, min_beta2=0.9, max_beta2=0.99)
+        for step in range(3):
+            sched(opt, 0, step)
+            for i, q in enumerate(ps):
+                gr = rng.normal(size=shapes[i]).astype(np.float32) * (10.0 if step == 1 else 1.0)
+                out[f'g_{ams}_{step}_{i}'] = gr
+                q.grad = T(gr.copy())
+            opt.step()
+            for i, q in enumerate(ps):
+                out[f'p_{ams}_{step}_{i}'] = npy(q).copy()
+        for i, q in enumerate(ps):
+            out[f'm_{ams}_{i}'] = npy(opt.state[q]['exp_avg'])
+            out[f'v_{ams}_{i}'] = npy(opt.state[q]['max_exp_avg_sq' if ams else 'exp_avg_sq'])
+    save('g10_optimizer', **out)
+
+
 def contract():
     """Reference state_dict keys/shapes for a small decoder, as JSON (checkpoint contract)."""
     ref = rdec.LocalCondRNVPDecoder(2, 8, 16)
@@ -298,3 +325,4 @@ if __name__ == '__main__':
     g7_model_training_forward()
     g8_gradients()
     g9_train_gradients()
+    g10_optimizer()

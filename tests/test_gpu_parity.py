@@ -639,3 +639,45 @@ def test_train_fast_path_equals_autograd_chain():
         assert _rel(res[0][3][k], res[1][3][k]) < 2e-3, k
     for k in res[0][4]:
         assert maxabs(res[0][4][k], res[1][4][k]) < 1e-4, k
+
+
+@pytest.mark.parametrize('ams', [0, 1])
+def test_g10_fused_adam_matches_reference(ams):
+    """gw.optim.Adam == the reference's optimiser over three scheduled steps (state names included)."""
+    from go_with_the_flows_amd.optim import Adam
+    from test_oracle_golden import lr_updater, SCHED
+    D = golden('g10_optimizer')
+    ps = [torch.nn.Parameter(dev(D[f'p0_{ams}_{i}'])) for i in range(4)]
+    opt = Adam(ps, lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=1e-3, amsgrad=bool(ams))
+    for step in range(3):
+        lr, betas = lr_updater(10, 0, step, **SCHED)
+        for grp in opt.param_groups:
+            grp['lr'], grp['betas'] = lr, betas
+        for i, q in enumerate(ps):
+            q.grad = dev(D[f'g_{ams}_{step}_{i}'])
+        opt.step()
+        for i, q in enumerate(ps):
+            assert maxabs(host(q), D[f'p_{ams}_{step}_{i}']) < 2e-6, (step, i)
+    for i, q in enumerate(ps):
+        st = opt.state[q]
+        assert st['step'] == 3
+        assert maxabs(host(st['exp_avg']), D[f'm_{ams}_{i}']) < 1e-6
+        assert maxabs(host(st['max_exp_avg_sq' if ams else 'exp_avg_sq']), D[f'v_{ams}_{i}']) < 1e-6
+
+
+def test_fused_adam_on_a_decoder_many_tensors():
+    """More tensors than one launch carries (48), odd sizes, against the oracle formula."""
+    from go_with_the_flows_amd.optim import Adam
+    m, _ = decoder_and_state(2, 19, 12, 3)
+    m = m.to(DEV)
+    params = list(m.parameters())
+    assert len(params) > 100
+    rng = np.random.default_rng(0)
+    before = [host(q).copy() for q in params]
+    grads = [rng.normal(size=tuple(q.shape)).astype(np.float32) for q in params]
+    for q, g in zip(params, grads):
+        q.grad = dev(g)
+    Adam(params, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, amsgrad=True).step()
+    for q, b, g in zip(params, before, grads):
+        ref = fo.adam_step(b, g, np.zeros_like(b), np.zeros_like(b), np.zeros_like(b), 1, 3e-3, 0.9, 0.999, 1e-8, 1e-4, True)[0]
+        assert maxabs(host(q), ref) < 2e-6

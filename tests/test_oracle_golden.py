@@ -191,3 +191,27 @@ def test_torch_port_train_mode_gradients_match_reference():
         if key.startswith('grad::'):
             ref = D[key]
             assert maxabs(tst[key[6:]].grad.numpy(), ref) / (np.abs(ref).max() + 1e-12) < 2e-4, key
+
+
+SCHED = dict(cycle_length=4, min_lr=1e-3, max_lr=1e-2, beta1=0.9, min_beta2=0.9, max_beta2=0.99)
+
+
+def lr_updater(epoch_length, epoch, iteration, cycle_length, min_lr, max_lr, beta1, min_beta2, max_beta2):
+    """Restatement of LRUpdater.__call__ (reference optimizers.py:89-97) -> (lr, (beta1, beta2))."""
+    cur = ((epoch % cycle_length) * epoch_length + iteration) / (cycle_length * epoch_length)
+    lr = min_lr + 0.5 * (max_lr - min_lr) * (1.0 + np.cos(np.pi * cur))
+    b2 = min_beta2 + 0.5 * (max_beta2 - min_beta2) * (1.0 + np.cos(np.pi * cur))
+    return lr, (beta1, b2)
+
+
+@pytest.mark.parametrize('ams', [0, 1])
+def test_g10_adam_oracle(ams):
+    D = golden('g10_optimizer')
+    for i in range(4):
+        p = D[f'p0_{ams}_{i}']
+        m, v, vmax = np.zeros_like(p), np.zeros_like(p), np.zeros_like(p)
+        for step in range(3):
+            lr, (b1, b2) = lr_updater(10, 0, step, **SCHED)
+            p, m, v, vmax = fo.adam_step(p, D[f'g_{ams}_{step}_{i}'], m, v, vmax, step + 1, lr, b1, b2, 1e-8, 1e-3, bool(ams))
+            assert maxabs(p, D[f'p_{ams}_{step}_{i}']) < 2e-6
+        assert maxabs(m, D[f'm_{ams}_{i}']) < 1e-6 and maxabs(vmax if ams else v, D[f'v_{ams}_{i}']) < 1e-6
