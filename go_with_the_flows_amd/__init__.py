@@ -4,7 +4,8 @@ from .flows import CondRealNVPFlow3D, CondRealNVPFlow3DTriple, WARP_PATTERNS
 from .decoders import LocalCondRNVPDecoder
 from .mixture import MixtureStack, flow_mixture_nll
 from . import optim
+from . import metrics
 from ._lib import GwtfError
 
 __all__ = ['SharedDot', 'Swish', 'CondRealNVPFlow3D', 'CondRealNVPFlow3DTriple', 'LocalCondRNVPDecoder',
-           'WARP_PATTERNS', 'GwtfError', 'MixtureStack', 'flow_mixture_nll', 'optim']
+           'WARP_PATTERNS', 'GwtfError', 'MixtureStack', 'flow_mixture_nll', 'optim', 'metrics']

@@ -183,6 +183,33 @@ int gwtf_adam_step(float* const* params, const float* const* grads, float* const
                    float* const* max_exp_avg_sq, const size_t* numel, int n_tensors, float lr, double beta1, double beta2,
                    float eps, float weight_decay, int step, int amsgrad, void* stream);
 
+/* Structural losses between point sets -- the reference's only native code (CUDA extension
+ * lib/metrics/pytorch_structural_losses, bound in pybind/bind.cpp:9-15).  Point sets are [b][n][3] / [b][m][3].
+ *
+ * gwtf_nn_distance replaces nn_distance (src/structural_loss.cpp:82-104, nndistance.cu:2-124): squared distance to the
+ * nearest point of the other set and the index of the FIRST minimiser, both directions in one launch. */
+int gwtf_nn_distance(const float* xyz1, const float* xyz2, float* dist1, int* idx1, float* dist2, int* idx2,
+                     int b, int n, int m, void* stream);
+/* Replaces nn_distance_grad (structural_loss.cpp:106-123, nndistance.cu:129-169); grad_xyz1/2 are zeroed by the call. */
+int gwtf_nn_distance_grad(const float* xyz1, const float* xyz2, const float* grad_dist1, const int* idx1,
+                          const float* grad_dist2, const int* idx2, float* grad_xyz1, float* grad_xyz2, int b,
+                          int n, int m, void* stream);
+/* Replaces ApproxMatch (structural_loss.cpp:22-37, approxmatch.cu:3-182): match [b][m][n] (zeroed by the call),
+ * temp [b][2(n+m)] scratch. */
+int gwtf_approx_match(const float* xyz1, const float* xyz2, float* match, float* temp, int b, int n, int m,
+                      void* stream);
+/* ApproxMatch + MatchCost in one schedule that never materialises the (b,m,n) matching: out [b] (zeroed by the call)
+ * accumulates sum w * distance level by level.  What match_cost.py:10-23 computes when no gradient is wanted
+ * (evaluation_metrics.py:25-30 is its only caller); temp as for gwtf_approx_match. */
+int gwtf_emd_cost(const float* xyz1, const float* xyz2, float* temp, float* out, int b, int n, int m, void* stream);
+/* Replaces MatchCost (structural_loss.cpp:39-55, approxmatch.cu:184-224): out [b] = sum match * distance. */
+int gwtf_match_cost(const float* xyz1, const float* xyz2, const float* match, float* out, int b, int n, int m,
+                    void* stream);
+/* Replaces MatchCostGrad (structural_loss.cpp:57-75, approxmatch.cu:229-297): d out / d xyz1, d out / d xyz2 (un-scaled
+ * by the upstream gradient, as in the reference; match_cost.py:38-45 applies it). */
+int gwtf_match_cost_grad(const float* xyz1, const float* xyz2, const float* match, float* grad1, float* grad2,
+                         int b, int n, int m, void* stream);
+
 /* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
  * (16, 32 or 64; anything else restores the size-based default).  Process-wide, not thread-safe. */
 void gwtf_debug_set_points_per_wave(int points);

@@ -1,0 +1,124 @@
+"""HIP structural losses (csrc/gwtf_metrics.hip through the C ABI) against oracle/metrics_oracle.py.  Needs an MI355X.
+
+Bars: nearest-neighbour distances and indices BIT-EXACT (same float32 expression, no FMA contraction, first minimum wins);
+approximate matching within 2e-4 relative (the device evaluates exp through v_exp_f32 and sums in scan order, the oracle
+through libm and pairwise sums); costs 1e-4 relative; gradients 1e-4 relative to their scale.
+"""
+import numpy as np
+import pytest
+import torch
+
+from go_with_the_flows_amd import _lib, metrics
+from oracle import metrics_oracle as mo
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def clouds(seed, b, n, m, scale=0.5):
+    r = np.random.default_rng(seed)
+    return (r.standard_normal((b, n, 3)) * scale).astype(np.float32), (r.standard_normal((b, m, 3)) * scale).astype(np.float32)
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.mark.parametrize('b,n,m', [(1, 1, 1), (2, 64, 64), (3, 100, 37), (1, 5, 1300), (2, 513, 1025), (4, 2048, 2048)])
+def test_nn_distance_bit_exact(b, n, m):
+    x, y = clouds(b * 1000 + n, b, n, m)
+    d1, i1, d2, i2 = metrics.nn_distance_raw(dev(x), dev(y))
+    e1, j1, e2, j2 = mo.nn_distance(x, y)
+    assert np.array_equal(host(d1), e1) and np.array_equal(host(d2), e2)
+    assert np.array_equal(host(i1), j1) and np.array_equal(host(i2), j2)
+
+
+def test_nn_distance_ties_take_first_index():
+    x = np.zeros((1, 3, 3), np.float32)
+    y = np.tile(np.array([[1, 0, 0]], np.float32), (1, 2500, 1))      # ties inside a tile and across tiles
+    _, i1, _, i2 = metrics.nn_distance_raw(dev(x), dev(y))
+    assert (host(i1) == 0).all() and (host(i2) == 0).all()
+
+
+def test_nn_distance_rejects_host_and_malformed_inputs():
+    x, y = clouds(0, 1, 8, 8)
+    with pytest.raises(_lib.GwtfError):
+        metrics.nn_distance(torch.from_numpy(x), torch.from_numpy(y))
+    with pytest.raises(_lib.GwtfError):
+        metrics.nn_distance(dev(x).transpose(1, 2), dev(y))
+    with pytest.raises(_lib.GwtfError):
+        metrics.nn_distance(dev(x), dev(y)[:, ::2])
+
+
+@pytest.mark.parametrize('b,n,m', [(2, 40, 40), (3, 700, 333)])
+def test_nn_distance_backward(b, n, m):
+    x, y = clouds(7, b, n, m)
+    r = np.random.default_rng(8)
+    g1, g2 = r.standard_normal((b, n)).astype(np.float32), r.standard_normal((b, m)).astype(np.float32)
+    xt, yt = dev(x).requires_grad_(), dev(y).requires_grad_()
+    d1, d2 = metrics.nn_distance(xt, yt)
+    ((d1 * dev(g1)).sum() + (d2 * dev(g2)).sum()).backward()
+    _, i1, _, i2 = mo.nn_distance(x, y)
+    ga, gb = mo.nn_distance_grad(x, y, g1, i1, g2, i2)
+    assert np.abs(host(xt.grad) - ga).max() < 1e-4 * max(1, np.abs(ga).max())
+    assert np.abs(host(yt.grad) - gb).max() < 1e-4 * max(1, np.abs(gb).max())
+
+
+@pytest.mark.parametrize('b,n,m', [(2, 16, 16), (2, 200, 200), (1, 96, 32), (1, 32, 96), (2, 1030, 1030)])
+def test_approx_match_and_cost(b, n, m):
+    x, y = clouds(11 + n, b, n, m, scale=0.3)
+    match, _ = metrics.approx_match(dev(x), dev(y))
+    ref = mo.approx_match(x, y)
+    got = host(match)
+    assert got.shape == (b, m, n)
+    assert np.abs(got - ref).max() < 2e-4 * max(1.0, ref.max())
+    # marginals (what the next auction level sees) agree tightly
+    assert np.abs(got.sum(1) - ref.sum(1)).max() < 2e-4 and np.abs(got.sum(2) - ref.sum(2)).max() < 2e-4 * max(1, n // m)
+    ref_cost = mo.match_cost(x, y, ref)
+    cost = metrics.match_cost(dev(x), dev(y))                               # fused schedule (no gradient wanted)
+    np.testing.assert_allclose(host(cost), ref_cost, rtol=1e-4)
+    cost_m = metrics.match_cost(dev(x).requires_grad_(), dev(y))           # materialised matching + MatchCost
+    np.testing.assert_allclose(host(cost_m), ref_cost, rtol=1e-4)
+    np.testing.assert_allclose(host(metrics.emd_approx(dev(x), dev(y))) if n == m else ref_cost / n, ref_cost / n, rtol=1e-4)
+
+
+def test_match_cost_backward():
+    b, n = 2, 150
+    x, y = clouds(21, b, n, n, scale=0.3)
+    xt, yt = dev(x).requires_grad_(), dev(y).requires_grad_()
+    w = np.array([0.5, -2.0], np.float32)
+    (metrics.match_cost(xt, yt) * dev(w)).sum().backward()
+    match = mo.approx_match(x, y)
+    g1, g2 = mo.match_cost_grad(x, y, match)
+    g1, g2 = g1 * w[:, None, None], g2 * w[:, None, None]
+    assert np.abs(host(xt.grad) - g1).max() < 1e-4 * max(1, np.abs(g1).max())
+    assert np.abs(host(yt.grad) - g2).max() < 1e-4 * max(1, np.abs(g2).max())
+
+
+def test_full_size_properties():
+    """evaluate_ae-sized clouds (2048 points): properties that need no O(n^2) oracle pass on the host."""
+    b, n = 8, 2048
+    x, y = clouds(31, b, n, n, scale=0.3)
+    xt, yt = dev(x), dev(y)
+    d1, d2 = metrics.nn_distance(xt, xt.clone())
+    assert float(d1.abs().max()) == 0.0 and float(d2.abs().max()) == 0.0          # a cloud is at distance 0 of itself
+    d1, i1, d2, i2 = metrics.nn_distance_raw(xt, yt)
+    gathered = torch.gather(yt, 1, i1.long().unsqueeze(2).expand(-1, -1, 3))
+    assert torch.equal(((gathered - xt) ** 2).sum(2) <= d1 * (1 + 1e-6) + 1e-12, torch.ones_like(d1, dtype=torch.bool))
+    # swapping the arguments swaps the outputs
+    e1, j1, e2, j2 = metrics.nn_distance_raw(yt, xt)
+    assert torch.equal(e1, d2) and torch.equal(e2, d1) and torch.equal(j1, i2) and torch.equal(j2, i1)
+    match, _ = metrics.approx_match(xt, yt)
+    assert float(match.min()) >= 0
+    assert float(match.sum(1).max()) <= 1 + 1e-3 and float(match.sum(2).max()) <= 1 + 1e-3
+    # the nine-level auction leaves a little mass unassigned (the oracle does too): nearly all of it is placed
+    assert float(match.sum(1).mean()) > 0.99 and float(match.sum(2).mean()) > 0.99
+    assert float(match.sum(1).min()) > 0.5 and float(match.sum(2).min()) > 0.5
+    emd = metrics.emd_approx(xt, yt)
+    assert float(metrics.emd_approx(xt, xt.clone()).max()) < 1e-3 * float(emd.min())      # identical clouds cost ~0
+    perm = torch.randperm(n, device=DEV)
+    np.testing.assert_allclose(host(metrics.emd_approx(xt[:, perm].contiguous(), yt)), host(emd), rtol=2e-3)
