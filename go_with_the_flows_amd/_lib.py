@@ -53,6 +53,10 @@ _SIGNATURES = {
     'gwtf_emd_cost': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_match_cost': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_match_cost_grad': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int] * 3 + [_c_fp]),
+    'gwtf_encoder_raw_floats': (ctypes.c_size_t, [_c_fp, ctypes.c_int]),
+    'gwtf_encoder_packed_floats': (ctypes.c_size_t, [_c_fp, ctypes.c_int]),
+    'gwtf_encoder_pack': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, _c_fp]),
+    'gwtf_encoder_forward': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int, ctypes.c_int, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -31,14 +31,14 @@ def synth_state(template_state, seed):
                 v = rng.normal(0.0, 0.15, shape)
             else:  # running_var
                 v = rng.uniform(0.5, 1.5, shape)
-        elif name.endswith('sd0') or name.endswith('sd1'):
+        elif name.endswith('sd0') or name.endswith('sd1') or name == 'init_sd' or (name.startswith('mlp') and kind == 'weight'):
             fan_in = shape[-1]
             v = rng.uniform(-1.0, 1.0, shape) * np.sqrt(3.0 / fan_in)
         elif name.endswith('sd2'):
             v = rng.normal(0.0, 0.15, shape) if kind == 'weight' else rng.normal(0.0, 0.1, shape)
         elif name.endswith('film_w0') or name.endswith('film_b0'):
             v = rng.uniform(-1.0, 1.0, shape) / np.sqrt(shape[-1])
-        elif name.endswith('film_w1') or name.endswith('film_b1'):
+        elif name.endswith('film_w1') or name.endswith('film_b1') or name in ('mu_mlp0', 'logvar_mlp0'):
             v = rng.normal(0.0, 0.08, shape) if kind == 'weight' else rng.normal(0.0, 0.1, shape)
         else:
             raise KeyError(f'synth_state: unknown parameter kind {key}')

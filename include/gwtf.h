@@ -23,6 +23,7 @@ extern "C" {
 
 #define GWTF_ABI_VERSION 1
 #define GWTF_E_BADARG 10001   /* shape / mode / width outside what the kernels support */
+#define GWTF_E_UNSUPPORTED 10002   /* a layer-width list no kernel instantiation was built for */
 #define GWTF_MODE_DIRECT 0    /* sampling direction  base -> data (reference models.py:202) */
 #define GWTF_MODE_INVERSE 1   /* density direction   data -> base (reference models.py:197) */
 
@@ -209,6 +210,17 @@ int gwtf_match_cost(const float* xyz1, const float* xyz2, const float* match, fl
  * by the upstream gradient, as in the reference; match_cost.py:38-45 applies it). */
 int gwtf_match_cost_grad(const float* xyz1, const float* xyz2, const float* match, float* grad1, float* grad2,
                          int b, int n, int m, void* stream);
+
+/* PointNet cloud encoder, eval-mode BatchNorm (lib/networks/encoders.py:9-28) fused with the max-pool its caller applies
+ * (lib/networks/models.py:127-128).  widths = {3, C0, C1, ..., C_last} (n_widths entries); built instantiations:
+ * {3,64,128,256,512} (every shipped config) and {3,64,128,64,128}; others return GWTF_E_UNSUPPORTED / size 0.
+ *   raw     per layer l: weight[C_l][C_{l-1}] | bn.weight | bn.bias | bn.running_mean | bn.running_var   (C_l each)
+ *   x       [B][3][N];  features [B][C_last][N] or NULL;  pooled [B][C_last] or NULL (zeroed by the call) */
+size_t gwtf_encoder_raw_floats(const int* widths, int n_widths);
+size_t gwtf_encoder_packed_floats(const int* widths, int n_widths);
+int gwtf_encoder_pack(const float* raw, float* packed, const int* widths, int n_widths, void* stream);
+int gwtf_encoder_forward(const float* x, const float* packed, float* features, float* pooled, int B, int N,
+                         const int* widths, int n_widths, void* stream);
 
 /* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
  * (16, 32 or 64; anything else restores the size-based default).  Process-wide, not thread-safe. */

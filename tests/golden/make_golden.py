@@ -302,6 +302,49 @@ def g10_optimizer():
     save('g10_optimizer', **out)
 
 
+def g11_encoder():
+    """PointNet cloud encoder (+ max-pool, models.py:127-128) and the per-shape heads, eval and train BatchNorm."""
+    from lib.networks import encoders as renc
+    from go_with_the_flows_amd import encoders as oenc
+    out = {}
+    for tag, n_features, B, N, seed in (('big', [128, 256, 512], 3, 70, 1100), ('small', [128, 64, 128], 2, 300, 1110)):
+        ref, mine = renc.PointNetCloudEncoder(3, 64, n_features), oenc.PointNetCloudEncoder(3, 64, n_features)
+        x, _ = synth_inputs(B, N, 4, seed + 1)
+        out[f'{tag}_x'] = x
+        out[f'{tag}_dims'] = np.array([64] + n_features + [B, N])
+        for training in (False, True):
+            load_into(ref, mine, seed)
+            ref.train(training)
+            with torch.no_grad():
+                feat = ref(T(x))
+            t = 'train' if training else 'eval'
+            out[f'{tag}_{t}_pooled'] = npy(torch.max(feat, dim=2)[0])
+            out[f'{tag}_{t}_feat_head'] = npy(feat[:, :, :6])
+            if training:
+                sd = ref.state_dict()
+                out[f'{tag}_rm_last'] = npy(sd[f'features.sd{len(n_features) - 1}_bn.running_mean'])
+                out[f'{tag}_rv_last'] = npy(sd[f'features.sd{len(n_features) - 1}_bn.running_var'])
+    # per-shape heads
+    rng = np.random.default_rng(1120)
+    h = rng.standard_normal((5, 48)).astype(np.float32)
+    out['head_x'] = h
+    for tag, cls_r, cls_o, kw in (('post', renc.FeatureEncoder, oenc.FeatureEncoder, dict(deterministic=False)),
+                                  ('det', renc.FeatureEncoder, oenc.FeatureEncoder, dict(deterministic=True)),
+                                  ('wts', renc.WeightsEncoder, oenc.WeightsEncoder, dict(deterministic=True))):
+        ref, mine = cls_r(2, 48, 10, **kw), cls_o(2, 48, 10, **kw)
+        for training in (False, True):
+            load_into(ref, mine, 1130)
+            ref.train(training)
+            with torch.no_grad():
+                y = ref(T(h))
+            t = 'train' if training else 'eval'
+            if isinstance(y, tuple):
+                out[f'head_{tag}_{t}_mu'], out[f'head_{tag}_{t}_lv'] = npy(y[0]), npy(y[1])
+            else:
+                out[f'head_{tag}_{t}'] = npy(y)
+    save('g11_encoder', **out)
+
+
 def contract():
     """Reference state_dict keys/shapes for a small decoder, as JSON (checkpoint contract)."""
     ref = rdec.LocalCondRNVPDecoder(2, 8, 16)
@@ -326,3 +369,4 @@ if __name__ == '__main__':
     g8_gradients()
     g9_train_gradients()
     g10_optimizer()
+    g11_encoder()
