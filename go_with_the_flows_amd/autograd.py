@@ -146,8 +146,8 @@ class StackDensityFn(torch.autograd.Function):
                                                     nxt.data_ptr(), dA.data_ptr(), H0.data_ptr(), g_film.data_ptr(),
                                                     g_sd0[c].data_ptr(), g_bias[c].data_ptr(), c, B, N, C, f, pattern0,
                                                     float(eps), _lib._MODES[mode], st))
-                # dW1p[k][j][i] = sum_{b,n} dacc[k,j,(b,n)] h[k,i,(b,n)]: one batched GEMM with K = B*N -> BLAS
-                gW1p[c] = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
+                # dW1p[k][j][i] = sum_{b,n} dacc[k,j,(b,n)] h[k,i,(b,n)]: one skinny GEMM with K = B*N (split-K MFMA kernel)
+                _lib.dw1_gemm(dA, H0, f, out=gW1p[c])
                 cur = nxt
         gs = g_sd0.sum(1)                                              # (C,2,3,FP)
         g_W0f = gs[:, :, 0:2, :f].permute(0, 1, 3, 2).contiguous()    # (C,2,f,2)
@@ -246,7 +246,7 @@ class StatsFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             _lib.check(L.gwtf_stats_backward(x.data_ptr(), gst.data_ptr(), pw.data_ptr(), pb.data_ptr(), g_x.data_ptr(),
                                              dA.data_ptr(), H0.data_ptr(), g_sd0.data_ptr(), B, N, f, pat, _lib._stream(x)))
-        gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
+        gW1 = _lib.dw1_gemm(dA, H0, f)
         gs = g_sd0.sum(0)
         return g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1, None, None, None, None
 
@@ -287,7 +287,7 @@ class ApplyFn(torch.autograd.Function):
                                                 rec.data_ptr(), g_x.data_ptr(), dA.data_ptr(), H0.data_ptr(),
                                                 g_film.data_ptr(), g_sd0.data_ptr(), g_bias.data_ptr(), 0, B, N, 1, f, pat,
                                                 float(eps), _lib._MODES[mode], _lib._stream(x)))
-        gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))
+        gW1 = _lib.dw1_gemm(dA, H0, f)
         gs = g_sd0.sum(0)
         return (g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1,
                 g_film[:, 0, :, 0, :f].contiguous(), g_film[:, 0, :, 1:3, :f].contiguous(), g_bias.sum(0).reshape(2, 2),
@@ -539,7 +539,7 @@ class TrainStackFn(torch.autograd.Function):
                     ystats[c].data_ptr(), nxt.data_ptr(), gxa.data_ptr(), gxb.data_ptr(), dA.data_ptr(), H0.data_ptr(),
                     g_film.data_ptr(), g_sd0[c].data_ptr(), g_bias[c].data_ptr(), g_stats[c].data_ptr(), g_mom[c].data_ptr(),
                     g_film_raw.data_ptr(), g_raw_c.data_ptr(), c, B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], st))
-                gW1 = torch.bmm(dA[:, :f], H0[:, :f].transpose(1, 2))            # (2,f,f): one GEMM, K = B*N
+                gW1 = _lib.dw1_gemm(dA, H0, f)            # (2,f,f): one GEMM, K = B*N
                 for br in range(2):
                     off = br * br_size + 6 * f                   # GwtfRaw::sd1_w
                     g_raw_c[off:off + f * f].copy_(gW1[br].reshape(-1))

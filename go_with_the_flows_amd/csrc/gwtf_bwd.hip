@@ -450,3 +450,112 @@ extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, cons
   return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dA_mat, h0_mat,
                       g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, stream);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dW1[br] = dA[br] h0[br]^T : (FP x M) . (M x FP) with M = B*N points on the contraction axis -- a skinny GEMM (48 x 48
+// output, K = 131072) that library GEMMs serve badly (rocBLAS picks a 16x16x256 macro tile: 94 us).  Split-K over
+// (chunks x 2 branches) workgroups on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate); a lane's float4 of
+// four consecutive points feeds four successive MFMAs (k-slot (kq, s) <-> point p0 + 4 kq + s for BOTH operands, so the
+// sum covers every point once).  Per-workgroup partials go to a workspace and a second kernel sums them in a fixed
+// order: deterministic, no atomics.
+namespace {
+constexpr int kDw1Chunks = 128;
+
+template <int MB>
+__global__ __launch_bounds__(256) void dw1_partial_kernel(const float* __restrict__ dA, const float* __restrict__ h0,
+                                                          float* __restrict__ ws, int M) {
+  constexpr int FP = 16 * MB;
+  __shared__ float red[4][MB * MB * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, kq = lane >> 4;
+  const int br = blockIdx.y;
+  const float* A = dA + (size_t)br * FP * M;
+  const float* Hm = h0 + (size_t)br * FP * M;
+  f32x4 acc[MB][MB];
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int steps = (M + 15) / 16;
+  const int per = (steps + kDw1Chunks - 1) / kDw1Chunks;
+  const int s_begin = blockIdx.x * per, s_end = min(steps, s_begin + per);
+  const bool vec_ok = (M & 3) == 0;
+  for (int s = s_begin + wave; s < s_end; s += 4) {
+    const int p = s * 16 + 4 * kq;
+    float4 a[MB], b[MB];
+    if (vec_ok && p + 4 <= M) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        a[i] = *reinterpret_cast<const float4*>(A + (size_t)(16 * i + row) * M + p);
+        b[i] = *reinterpret_cast<const float4*>(Hm + (size_t)(16 * i + row) * M + p);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MB; ++i) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          av[e] = p + e < M ? A[(size_t)(16 * i + row) * M + p + e] : 0.f;
+          bv[e] = p + e < M ? Hm[(size_t)(16 * i + row) * M + p + e] : 0.f;
+        }
+        a[i] = make_float4(av[0], av[1], av[2], av[3]);
+        b[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+      for (int j = 0; j < MB; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+      }
+  }
+  // C layout: lane (col = row of the B operand = h0 feature j, q = kq) holds rows 4q..4q+3 (dA features) of tile (i, j)
+#pragma unroll
+  for (int i = 0; i < MB; ++i)
+#pragma unroll
+    for (int j = 0; j < MB; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][((i * MB + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+  __syncthreads();
+  float* out = ws + ((size_t)blockIdx.x * 2 + br) * FP * FP;
+  for (int t = threadIdx.x; t < MB * MB * 256; t += 256) {
+    const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
+    const int ln = t & 63, r = (t >> 6) & 3, tile = t >> 8, i = tile / MB, j = tile % MB;
+    out[(size_t)(16 * i + 4 * (ln >> 4) + r) * FP + 16 * j + (ln & 15)] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int FP, int f) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * f * f) return;
+  const int br = t / (f * f), i = (t / f) % f, j = t % f;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int c = 0; c < kDw1Chunks; c += 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += ws[((size_t)(c + u) * 2 + br) * FP * FP + (size_t)i * FP + j];
+  out[t] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+}  // namespace
+
+extern "C" size_t gwtf_dw1_workspace_floats(int f) {
+  const size_t FP = gwtf_padded_width(f);
+  return (size_t)kDw1Chunks * 2 * FP * FP;
+}
+
+extern "C" int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* workspace, float* dW1, int f, int M, void* stream) {
+  if (!dA_mat || !h0_mat || !workspace || !dW1 || f <= 0 || f > GWTF_MAX_FP || M <= 0) return GWTF_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int FP = gwtf_padded_width(f);
+  const dim3 grid(kDw1Chunks, 2), block(256);
+  switch (FP / 16) {
+    case 1: hipLaunchKernelGGL(dw1_partial_kernel<1>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
+    case 2: hipLaunchKernelGGL(dw1_partial_kernel<2>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
+    case 3: hipLaunchKernelGGL(dw1_partial_kernel<3>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
+    default: hipLaunchKernelGGL(dw1_partial_kernel<4>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
+  }
+  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 255) / 256), block, 0, st, workspace, dW1, FP, f);
+  return (int)hipGetLastError();
+}

@@ -220,46 +220,69 @@ __global__ void pack_w1t_kernel(const float* __restrict__ raw, float* __restrict
 }
 
 // thread = (branch, feature); one workgroup.  Writes g_a / g_bsh rows of this coupling, dW2, db2 and gS.
-__global__ void fold1_bwd_kernel(const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total,
-                                 const float* __restrict__ film_raw, const float* __restrict__ g_film,
-                                 const float* __restrict__ g_bias, float* __restrict__ g_film_raw,
-                                 float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G,
-                                 int FP) {
-  const int t = threadIdx.x;
-  if (t >= 2 * FP) return;
-  const int br = t / FP, j = t % FP;
+constexpr int kFoldSlices = 8;   // the single workgroup of the fold backward kernels = 8 slices x (branch, feature)
+
+__global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kernel(
+    const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total, const float* __restrict__ film_raw,
+    const float* __restrict__ g_film, const float* __restrict__ g_bias, float* __restrict__ g_film_raw,
+    float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G, int FP) {
+  constexpr int TW = 2 * GWTF_MAX_FP;
+  __shared__ float st_part[kFoldSlices][TW][2];
+  __shared__ double acc_part[kFoldSlices][TW][4];
+  const int t = threadIdx.x % TW, sl = threadIdx.x / TW;
+  const bool lane_on = t < 2 * FP;
+  const int br = lane_on ? t / FP : 0, j = lane_on ? t % FP : 0;
+  const bool on = lane_on && j < f;
   const GwtfRaw R(f, G);
-  if (j >= f) {
-    g_stats[(br * 2 + 0) * FP + j] = 0.f;
-    g_stats[(br * 2 + 1) * FP + j] = 0.f;
-    return;
+  {
+    float ys = 0.f, yq = 0.f;
+    if (on)
+      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) {
+        ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
+        yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
+      }
+    st_part[sl][t][0] = ys;
+    st_part[sl][t][1] = yq;
   }
-  const float* rb = raw_c + (size_t)br * R.branch_size();
-  float* grb = g_raw_c + (size_t)br * R.branch_size();
+  __syncthreads();
   float ys = 0.f, yq = 0.f;
-  for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) {
-    ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
-    yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
-  }
+#pragma unroll
+  for (int i = 0; i < kFoldSlices; ++i) { ys += st_part[i][t][0]; yq += st_part[i][t][1]; }
   const double mean = ys / n_total;
   double var = yq / n_total - mean * mean;
   if (var < 0.0) var = 0.0;
   const float s1 = 1.0f / sqrtf((float)var + GWTF_BN_EPS);
-  const float w20 = rb[R.sd2_w() + j], w21 = rb[R.sd2_w() + f + j];
+  const float* rb = raw_c + (size_t)br * R.branch_size();
+  float* grb = g_raw_c + (size_t)br * R.branch_size();
+  const float w20 = on ? rb[R.sd2_w() + j] : 0.f, w21 = on ? rb[R.sd2_w() + f + j] : 0.f;
   double g_m1 = 0.0, g_s1 = 0.0, gw20 = 0.0, gw21 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float* fr = film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
-    const float* gf = g_film + (((size_t)b * C + c) * 2 + br) * 3 * FP;
-    float* go = g_film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
-    const float a = fr[j], bs = fr[FP + j];
-    const float gc = gf[j], gu0 = gf[FP + j], gu1 = gf[2 * FP + j];
-    const float guw = gu0 * w20 + gu1 * w21;
-    go[j] = -gc * bs / (a * a * s1) + guw * s1;   // dL/da
-    go[FP + j] = gc / (a * s1);                   // dL/dbsh
-    gw20 += (double)gu0 * a * s1;
-    gw21 += (double)gu1 * a * s1;
-    g_s1 += (double)(-gc * bs / (a * s1 * s1)) + (double)guw * a;
-    g_m1 -= gc;
+  if (on)
+    for (int b = sl; b < B; b += kFoldSlices) {
+      const float* fr = film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
+      const float* gf = g_film + (((size_t)b * C + c) * 2 + br) * 3 * FP;
+      float* go = g_film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
+      const float a = fr[j], bs = fr[FP + j];
+      const float gc = gf[j], gu0 = gf[FP + j], gu1 = gf[2 * FP + j];
+      const float guw = gu0 * w20 + gu1 * w21;
+      go[j] = -gc * bs / (a * a * s1) + guw * s1;   // dL/da
+      go[FP + j] = gc / (a * s1);                   // dL/dbsh
+      gw20 += (double)gu0 * a * s1;
+      gw21 += (double)gu1 * a * s1;
+      g_s1 += (double)(-gc * bs / (a * s1 * s1)) + (double)guw * a;
+      g_m1 -= gc;
+    }
+  acc_part[sl][t][0] = g_m1; acc_part[sl][t][1] = g_s1; acc_part[sl][t][2] = gw20; acc_part[sl][t][3] = gw21;
+  __syncthreads();
+  if (sl != 0 || !lane_on) return;
+  if (!on) {
+    g_stats[(br * 2 + 0) * FP + j] = 0.f;
+    g_stats[(br * 2 + 1) * FP + j] = 0.f;
+    return;
+  }
+  g_m1 = g_s1 = gw20 = gw21 = 0.0;
+#pragma unroll
+  for (int i = 0; i < kFoldSlices; ++i) {
+    g_m1 += acc_part[i][t][0]; g_s1 += acc_part[i][t][1]; gw20 += acc_part[i][t][2]; gw21 += acc_part[i][t][3];
   }
   const double g_v1 = -0.5 * g_s1 * (double)s1 * s1 * s1;
   g_stats[(br * 2 + 0) * FP + j] = (float)((g_m1 - 2.0 * mean * g_v1) / n_total);
@@ -273,28 +296,57 @@ __global__ void fold1_bwd_kernel(const float* __restrict__ raw_c, const float* _
   }
 }
 
-// thread = (branch, feature); one workgroup.  g_sd0 replicas -> dW0, dgamma0, dbeta0 and the 9 moment gradients.
-__global__ void fold0_bwd_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total,
-                                 int pat, const float* __restrict__ g_sd0, float* __restrict__ g_raw_c,
-                                 float* __restrict__ g_mom, int f, int G, int FP) {
-  const int t = threadIdx.x;
-  __shared__ float mom[9];
-  __shared__ double red[5];   // gE0, gE1, gC00, gC01, gC11
+// one workgroup of 8 slices x (branch, feature).  g_sd0 replicas -> dW0, dgamma0, dbeta0 and the 9 moment gradients.
+__global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kernel(
+    const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
+    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, float* __restrict__ g_mom, int f, int G, int FP) {
+  constexpr int TW = 2 * GWTF_MAX_FP;
+  const int t = threadIdx.x % TW, sl = threadIdx.x / TW;
+  __shared__ float mom_part[kFoldSlices][9];
+  __shared__ double gs_part[kFoldSlices][TW][3];
+  __shared__ double red[TW][5];   // per (branch, feature): gE0, gE1, gC00, gC01, gC11 contributions
+  const bool on = t < 2 * f;
+  const int br = on ? t / f : 0, j = on ? t % f : 0;
   if (t < 9) {
     float sacc = 0.f;
-    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) sacc += mom_rep[r * 16 + t];
-    mom[t] = sacc;
+    for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) sacc += mom_rep[r * 16 + t];
+    mom_part[sl][t] = sacc;
   }
-  if (t < 5) red[t] = 0.0;
+  {
+    double g0 = 0.0, g1 = 0.0, gc = 0.0;
+    if (on)
+      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) {
+        const float* gs = g_sd0 + (size_t)r * (2 * 3 * FP) + (size_t)br * 3 * FP;
+        g0 += gs[j];
+        g1 += gs[FP + j];
+        gc += gs[2 * FP + j];
+      }
+    gs_part[sl][t][0] = g0; gs_part[sl][t][1] = g1; gs_part[sl][t][2] = gc;
+  }
   __syncthreads();
+  float mom[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    float v = 0.f;
+#pragma unroll
+    for (int r = 0; r < kFoldSlices; ++r) v += mom_part[r][i];
+    mom[i] = v;
+  }
   int k0, k1, w0d, w1d;
   gwtf_pattern_dims(pat, &k0, &k1, &w0d, &w1d);
-  const double e0 = mom[k0] / n_total, e1 = k1 >= 0 ? mom[k1] / n_total : 0.0;
-  const double c00 = mom[mom2_index(k0, k0)] / n_total - e0 * e0;
-  const double c11 = k1 >= 0 ? mom[mom2_index(k1, k1)] / n_total - e1 * e1 : 0.0;
-  const double c01 = k1 >= 0 ? mom[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] / n_total - e0 * e1 : 0.0;
-  if (t < 2 * f) {
-    const int br = t / f, j = t % f;
+  auto M = [&](int i) { float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) v = u == i ? mom[u] : v;
+    return v; };
+  const double e0 = M(k0) / n_total, e1 = k1 >= 0 ? M(k1) / n_total : 0.0;
+  const double c00 = M(mom2_index(k0, k0)) / n_total - e0 * e0;
+  const double c11 = k1 >= 0 ? M(mom2_index(k1, k1)) / n_total - e1 * e1 : 0.0;
+  const double c01 = k1 >= 0 ? M(mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)) / n_total - e0 * e1 : 0.0;
+  if (sl == 0) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) red[t][i] = 0.0;
+  }
+  if (on && sl == 0) {
     const GwtfRaw R(f, G);
     const float* rb = raw_c + (size_t)br * R.branch_size();
     float* grb = g_raw_c + (size_t)br * R.branch_size();
@@ -306,12 +358,8 @@ __global__ void fold0_bwd_kernel(const float* __restrict__ raw_c, const float* _
     const double isd = 1.0 / sqrt((double)((float)var + GWTF_BN_EPS));
     const double s = gamma * isd;
     double g0 = 0.0, g1 = 0.0, gc = 0.0;
-    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) {
-      const float* gs = g_sd0 + (size_t)r * (2 * 3 * FP) + (size_t)br * 3 * FP;
-      g0 += gs[j];
-      g1 += gs[FP + j];
-      gc += gs[2 * FP + j];
-    }
+#pragma unroll
+    for (int r = 0; r < kFoldSlices; ++r) { g0 += gs_part[r][t][0]; g1 += gs_part[r][t][1]; gc += gs_part[r][t][2]; }
     const double g_s = g0 * wa + g1 * wb - gc * mean;
     const double g_mean = -gc * s;
     const double g_var = g_s * gamma * (-0.5) * isd * isd * isd;
@@ -321,18 +369,22 @@ __global__ void fold0_bwd_kernel(const float* __restrict__ raw_c, const float* _
     grb[R.sd0_w() + f + j] = k1 >= 0 ? (float)gwb : 0.f;
     grb[R.bn0() + j] = (float)(g_s * isd);       // d gamma
     grb[R.bn0() + f + j] = (float)gc;            // d beta
-    atomicAdd(&red[0], g_mean * wa);
-    atomicAdd(&red[1], g_mean * wb);
-    atomicAdd(&red[2], g_var * wa * wa);
-    atomicAdd(&red[3], g_var * 2.0 * wa * wb);
-    atomicAdd(&red[4], g_var * wb * wb);
+    red[t][0] = g_mean * wa;
+    red[t][1] = g_mean * wb;
+    red[t][2] = g_var * wa * wa;
+    red[t][3] = g_var * 2.0 * wa * wb;
+    red[t][4] = g_var * wb * wb;
   }
   __syncthreads();
-  if (t == 0) {
+  if (threadIdx.x == 0) {
+    double r5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int u = 0; u < 2 * f; ++u)
+#pragma unroll
+      for (int i = 0; i < 5; ++i) r5[i] += red[u][i];
     for (int i = 0; i < 16; ++i) g_mom[i] = 0.f;
-    const double gC00 = red[2], gC01 = red[3], gC11 = red[4];
-    const double gE0 = red[0] - 2.0 * e0 * gC00 - e1 * gC01;
-    const double gE1 = red[1] - 2.0 * e1 * gC11 - e0 * gC01;
+    const double gC00 = r5[2], gC01 = r5[3], gC11 = r5[4];
+    const double gE0 = r5[0] - 2.0 * e0 * gC00 - e1 * gC01;
+    const double gE1 = r5[1] - 2.0 * e1 * gC11 - e0 * gC01;
     g_mom[k0] = (float)(gE0 / n_total);
     g_mom[mom2_index(k0, k0)] = (float)(gC00 / n_total);
     if (k1 >= 0) {
@@ -389,11 +441,11 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dA_mat, h0_mat, g_film, g_sd0,
                                   g_bias, c, B, N, C, f, pattern0, eps, mode, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
+  hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
                      g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP);
   rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dA_mat, h0_mat, g_sd0, B, N, f, pat, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(fold0_bwd_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, st, raw_c, moments_c, n_total, pat, g_sd0, g_raw_c,
+  hipLaunchKernelGGL(fold0_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, moments_c, n_total, pat, g_sd0, g_raw_c,
                      g_mom, f, G, FP);
   const int bx = (N + 255) / 256;
   hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B), dim3(256), 0, st, x_in, g_xa, g_xb, g_mom, g_in, B, N);
