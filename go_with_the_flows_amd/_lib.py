@@ -44,7 +44,7 @@ _SIGNATURES = {
     'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 4 + [_c_fp]),
     'gwtf_dw1_workspace_floats': (ctypes.c_size_t, [ctypes.c_int]),
-    'gwtf_dw1_gemm': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_dw1_gemm': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_mixture_nll_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_adam_step': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_double,
@@ -190,14 +190,16 @@ def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segment
     return out, logdet
 
 
-def dw1_gemm(dA, H0, f, out=None):
-    """(2,FP,M) x (2,FP,M)^T -> (2,f,f): the sd1 weight gradient (csrc/gwtf_bwd.hip, deterministic split-K MFMA GEMM)."""
+def dw1_gemm(dA, H0, f, out=None, branch_stride=None):
+    """(2,FP,M) x (2,FP,M)^T -> (2,f,f): the sd1 weight gradient (csrc/gwtf_bwd.hip, deterministic split-K MFMA GEMM).
+    With ``branch_stride`` the two (f,f) blocks go to out + br*branch_stride (in-place into a gradient record)."""
     L = lib()
     M = dA.shape[2]
     ws = torch.empty(L.gwtf_dw1_workspace_floats(f), device=dA.device, dtype=torch.float32)
     if out is None:
         out = torch.empty(2, f, f, device=dA.device, dtype=torch.float32)
-    check(L.gwtf_dw1_gemm(_ptr(dA, 'dA'), _ptr(H0, 'H0'), ws.data_ptr(), _ptr(out, 'dW1'), f, M, _stream(dA)))
+    check(L.gwtf_dw1_gemm(_ptr(dA, 'dA'), _ptr(H0, 'H0'), ws.data_ptr(), out.data_ptr(),
+                          f * f if branch_stride is None else branch_stride, f, M, _stream(dA)))
     return out
 
 

@@ -21,40 +21,32 @@ from . import _lib
 BN_EPS = 1e-5
 
 
-def _gather(engine):
-    """Stack the couplings' parameters / buffers into (C,2,...) tensors, branch order (logvar, mu)."""
-    cps = engine.couplings
-    f = engine.f
-
-    def st(fn):
-        return torch.stack([torch.stack([fn(c, X) for X in ('logvar', 'mu')]) for c in cps])
-
-    def pad_last(t, n):
-        return t if t.shape[-1] == n else F.pad(t, (0, n - t.shape[-1]))
-
-    def pad_rows(t, n):
-        return t if t.shape[0] == n else F.pad(t, (0, 0, 0, n - t.shape[0]))
-
-    T0 = lambda c, X: getattr(c, f'T_{X}_0')
-    head = lambda c, X, w: getattr(c, f'T_{X}_0_cond_{w}')
-    out = {
-        'W0': st(lambda c, X: pad_last(T0(c, X)[0].weight[0], 2)),            # (C,2,f,2)
-        'bn0': [st(lambda c, X, k=k: getattr(T0(c, X)[1], k)) for k in ('weight', 'bias', 'running_mean', 'running_var')],
-        'W1': st(lambda c, X: T0(c, X)[3].weight[0]),                          # (C,2,f,f)
-        'bn1': [st(lambda c, X, k=k: getattr(T0(c, X)[4], k)) for k in ('running_mean', 'running_var')],
-        'W2': st(lambda c, X: pad_rows(getattr(c, f'T_{X}_1')[1].weight[0], 2)),   # (C,2,2,f)
-        'b2': st(lambda c, X: pad_last(getattr(c, f'T_{X}_1')[1].bias[0], 2)),     # (C,2,2)
+def _gather(engine, raw=None):
+    """The couplings' parameters / buffers as (C,2,...) tensors, branch order (logvar, mu): VIEWS of the flat raw arena
+    (engine.raw_arena(): one autograd-aware torch.cat in the record order of csrc/gwtf_layout.h GwtfRaw), so gathering
+    costs no kernels and every gradient flows back through that single cat."""
+    if raw is None:
+        raw = engine.raw_arena()
+    C, f, G = engine.C, engine.f, engine.G
+    rv = raw.view(C, 2, -1)                                   # (C, branch, branch record)
+    o_bn0, o_w1, o_bn1 = 2 * f, 6 * f, 6 * f + f * f
+    o_film, FS = 8 * f + f * f, f * G + 5 * f + f * f
+    o_w2 = o_film + 2 * FS
+    films = rv[:, :, o_film:o_w2].reshape(C, 2, 2, FS)         # (C, branch, {w,b}, head record)
+    o_hbn, o_l1, o_b1 = f * G, f * G + 4 * f, f * G + 4 * f + f * f
+    return {
+        'raw': raw,
+        'W0': rv[:, :, 0:2 * f].reshape(C, 2, 2, f).transpose(2, 3),                 # (C,2,f,2)  (stored transposed)
+        'bn0': list(rv[:, :, o_bn0:o_w1].reshape(C, 2, 4, f).unbind(2)),             # weight, bias, mean, var
+        'W1': rv[:, :, o_w1:o_bn1].reshape(C, 2, f, f),
+        'bn1': list(rv[:, :, o_bn1:o_film].reshape(C, 2, 2, f).unbind(2)),           # mean, var
+        'W2': rv[:, :, o_w2:o_w2 + 2 * f].reshape(C, 2, 2, f),
+        'b2': rv[:, :, o_w2 + 2 * f:o_w2 + 2 * f + 2],
+        'L0': films[..., :o_hbn].reshape(C, 2, 2, f, G),
+        'hbn': list(films[..., o_hbn:o_l1].reshape(C, 2, 2, 4, f).unbind(3)),
+        'L1': films[..., o_l1:o_b1].reshape(C, 2, 2, f, f),
+        'b1': films[..., o_b1:],
     }
-
-    def st_heads(fn):
-        return torch.stack([torch.stack([torch.stack([fn(head(c, X, w)) for w in ('w', 'b')]) for X in ('logvar', 'mu')])
-                            for c in cps])
-
-    out['L0'] = st_heads(lambda h: h[0].weight)                                # (C,2,2,f,G)
-    out['hbn'] = [st_heads(lambda h, k=k: getattr(h[1], k)) for k in ('weight', 'bias', 'running_mean', 'running_var')]
-    out['L1'] = st_heads(lambda h: h[3].weight)                                # (C,2,2,f,f)
-    out['b1'] = st_heads(lambda h: h[3].bias)                                  # (C,2,2,f)
-    return out
 
 
 def fold(engine, g, eps):
@@ -450,19 +442,6 @@ def train_density_forward(engine, p, g, distributed=False, mode='inverse'):
 # over all couplings) stay a torch graph.  The chain of autograd nodes above remains the multi-rank implementation and
 # the cross-check of this one (tests/test_gpu_parity.py::test_train_fast_path_equals_autograd_chain).
 # ======================================================================================================================
-def _gather_film(engine):
-    cps = engine.couplings
-    head = lambda c, X, w: getattr(c, f'T_{X}_0_cond_{w}')
-
-    def st_heads(fn):
-        return torch.stack([torch.stack([torch.stack([fn(head(c, X, w)) for w in ('w', 'b')]) for X in ('logvar', 'mu')])
-                            for c in cps])
-
-    return {'L0': st_heads(lambda h: h[0].weight),
-            'hbn': [st_heads(lambda h, k=k: getattr(h[1], k)) for k in ('weight', 'bias', 'running_mean', 'running_var')],
-            'L1': st_heads(lambda h: h[3].weight), 'b1': st_heads(lambda h: h[3].bias)}
-
-
 class TrainStackFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, p, raw, a, bsh, C, f, G, pattern0, eps, mode):
@@ -539,10 +518,8 @@ class TrainStackFn(torch.autograd.Function):
                     ystats[c].data_ptr(), nxt.data_ptr(), gxa.data_ptr(), gxb.data_ptr(), dA.data_ptr(), H0.data_ptr(),
                     g_film.data_ptr(), g_sd0[c].data_ptr(), g_bias[c].data_ptr(), g_stats[c].data_ptr(), g_mom[c].data_ptr(),
                     g_film_raw.data_ptr(), g_raw_c.data_ptr(), c, B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], st))
-                gW1 = _lib.dw1_gemm(dA, H0, f)            # (2,f,f): one GEMM, K = B*N
-                for br in range(2):
-                    off = br * br_size + 6 * f                   # GwtfRaw::sd1_w
-                    g_raw_c[off:off + f * f].copy_(gW1[br].reshape(-1))
+                # dW1 (2,f,f): one skinny GEMM with K = B*N, written at GwtfRaw::sd1_w of both branch records
+                _lib.dw1_gemm(dA, H0, f, out=g_raw_c[6 * f:], branch_stride=br_size)
                 cur = nxt
         return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None, None
 
@@ -552,8 +529,9 @@ def train_density_forward_fast(engine, p, g, mode='inverse'):
     C, f, G, eps = engine.C, engine.f, engine.G, engine.couplings[0]._eps_value
     if p.shape[0] < 2:
         raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
-    a, bsh, fmean, fvar = _film_train(_gather_film(engine), g.float(), eps)
-    out, logdet, lists, bn_batch = TrainStackFn.apply(p.float(), engine.raw_arena(), a, bsh, C, f, G, engine.pattern0, eps,
+    P = _gather(engine)
+    a, bsh, fmean, fvar = _film_train(P, g.float(), eps)
+    out, logdet, lists, bn_batch = TrainStackFn.apply(p.float(), P['raw'], a, bsh, C, f, G, engine.pattern0, eps,
                                                       mode)
     bn_batch = bn_batch.clone()
     bn_batch[:, :, 2:4, 0] = fmean

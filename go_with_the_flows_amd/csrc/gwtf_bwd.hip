@@ -8,8 +8,8 @@
 //     lv = softsign(o^lv)   mu = o^mu   s = sqrt(eps + exp(lv))   out_w = (x_w - mu)/s   out_k = x_k/sqrt(eps+1)   ld_w += lv
 // One pass per coupling: the forward is RECOMPUTED from the saved coupling input (12 B/pt), then
 //     dt -> dz = u.dt -> dacc = dz[acc>0]      (in the accumulators' C layout, in place)
-//     dh = W1p^T dacc                           v_mfma_f32_16x16x4_f32: the C-layout registers ARE its B operand
-//                                               (k-slot q of step kk=4m+r <-> feature 16m + 4q + r), exact fp32
+//     dh = W1p^T dacc                           v_mfma_f32_16x16x32_f16, three-product split: the C-layout registers of
+//                                               dacc, split into f16 hi/lo, ARE its B operand (k-slot map: GwtfPackB)
 //     dpre = dh[pre>0]   dxk = W0f^T dpre   dx_w = g_out_w / s
 // Reductions over points (per-shape FiLM record grads dc, du_w; sd0 grads; sd2 bias grads) are done in-lane over
 // the point blocks, by shuffles over the 16 lanes of a quarter, in LDS over the 4 waves, then one atomic per value
@@ -25,8 +25,8 @@ using namespace gwtf_dev;
 template <int MB>
 struct BCfg {
   static constexpr int FP = 16 * MB;
-  static constexpr int KKF = FP / 4;
-  static constexpr int W1T = MB * KKF * 64;             // floats, one branch: [mi][kk][lane]
+  static constexpr int KS = (FP + 31) / 32;
+  static constexpr int W1T = MB * KS * 2 * 256;         // floats, one branch: [mi][ks][part][lane][8 f16] (GwtfPackB)
   static constexpr int PB = 2 * W1T + 2 * FP * 4;       // + SD0N[2][FP][4]
 };
 
@@ -247,8 +247,42 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
         }
       }
     }
-    // dh[16mi + 4q + r][point] = sum_j W1p[j][16mi + ..] dacc[j][point]
-    const float* w1t = LB + br * KB::W1T + lane;
+    // dh[16mi + 4q + r][point] = sum_j W1p[j][16mi + ..] dacc[j][point] on the f16 MFMA with the three-product split.
+    // Gradients have no natural scale (a 1/(B N) loss normalisation puts them near the f16 subnormals), so the wave
+    // rescales dacc by a power of two that brings its largest magnitude to [2^8, 2^9) and undoes it on dh: exact.
+    float amax = 0.f;
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(acc[br][m][nb][r]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    const int ebits = (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, amax)) >> 23) & 0xff;
+    const bool rescale = ebits >= 16 && ebits <= 240;
+    const float up = rescale ? __builtin_bit_cast(float, (262 - ebits) << 23) : 1.0f;     // 2^(8 - (ebits - 127))
+    const float down = rescale ? __builtin_bit_cast(float, (ebits - 8) << 23) : 1.0f;     // 2^((ebits - 127) - 8)
+    f16x8 dhi[KB::KS][NB], dlo[KB::KS][NB];
+#pragma unroll
+    for (int ks = 0; ks < KB::KS; ++ks)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int m = 2 * ks + half;
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            f16x2 h = {(_Float16)0.f, (_Float16)0.f}, l = {(_Float16)0.f, (_Float16)0.f};
+            if (m < MB) {
+              const f32x2 v = {acc[br][m < MB ? m : 0][nb][2 * pr] * up, acc[br][m < MB ? m : 0][nb][2 * pr + 1] * up};
+              split_pair(v, h, l);
+            }
+            dhi[ks][nb][4 * half + 2 * pr] = h[0]; dhi[ks][nb][4 * half + 2 * pr + 1] = h[1];
+            dlo[ks][nb][4 * half + 2 * pr] = l[0]; dlo[ks][nb][4 * half + 2 * pr + 1] = l[1];
+          }
+        }
+    const float* w1t = LB + br * KB::W1T + lane * 4;
     const f32x4* sd0n = reinterpret_cast<const f32x4*>(LB + 2 * KB::W1T + br * FP * 4);
     float pxa[NB], pxb[NB];
 #pragma unroll
@@ -259,14 +293,18 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) dh[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int kk = 0; kk < KB::KKF; ++kk) {
-        if (16 * (kk >> 2) + (kk & 3) < f) {   // wave-uniform: this step's four output features are all padding otherwise
-          const float av = w1t[(mi * KB::KKF + kk) * 64];
+      for (int ks = 0; ks < KB::KS; ++ks) {
+        const f16x8 ahi = *reinterpret_cast<const f16x8*>(w1t + ((mi * KB::KS + ks) * 2 + 0) * 256);
+        const f16x8 alo = *reinterpret_cast<const f16x8*>(w1t + ((mi * KB::KS + ks) * 2 + 1) * 256);
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            dh[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, acc[br][kk >> 2][nb][kk & 3], dh[nb], 0, 0, 0);
+        for (int nb = 0; nb < NB; ++nb) {
+          dh[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, dhi[ks][nb], dh[nb], 0, 0, 0);
+          dh[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, dlo[ks][nb], dh[nb], 0, 0, 0);
+          dh[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, dhi[ks][nb], dh[nb], 0, 0, 0);
         }
       }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) dh[nb] *= down;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int fi = 16 * mi + 4 * q + r;
@@ -327,9 +365,10 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
                                    const float* __restrict__ c0f, float* __restrict__ pw, float* __restrict__ pb, int C,
                                    int f, int FP) {
   const GwtfPackW P(FP);
-  const int MB = FP / 16, KS = P.KS(), KKF = FP / 4;
+  const GwtfPackB PBk(FP);
+  const int MB = FP / 16, KS = P.KS();
   const size_t PWs = P.coupling_size();
-  const size_t W1T = (size_t)MB * KKF * 64, PBs = 2 * W1T + 2 * (size_t)FP * 4;
+  const size_t W1T = PBk.w1t_size(), PBs = PBk.coupling_size();
   const size_t total = (PWs + PBs) * (size_t)C;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx / (PWs + PBs));
@@ -368,11 +407,8 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
       if (o < 2 * W1T) {
         const int br = (int)(o / W1T);
         size_t oo = o - (size_t)br * W1T;
-        const int lane = (int)(oo % 64), kk = (int)((oo / 64) % KKF), mi = (int)(oo / ((size_t)64 * KKF));
-        // k-slot (step kk, quarter q) <-> output feature 16*(kk>>2) + 4*q + (kk&3): the accumulator register (kk>>2, kk&3)
-        // of the lane in quarter q, so the C-layout registers of dacc are the B operand as they stand
-        const int j = 16 * (kk >> 2) + 4 * (lane >> 4) + (kk & 3), i = 16 * mi + (lane & 15);   // A[i][k] = W1p[j][i]
-        if (j < f && i < f) v = W1p[(((size_t)c * 2 + br) * f + j) * f + i];
+        const float* Wb = W1p + ((size_t)c * 2 + br) * f * f;
+        v = gwtf_w1t_slot(PBk, oo, [&](int j, int i) { return (j < f && i < f) ? Wb[(size_t)j * f + i] : 0.f; });
       } else {
         size_t oo = o - 2 * W1T;
         const int br = (int)(oo / ((size_t)FP * 4)), ft = (int)((oo / 4) % FP), e = (int)(oo % 4);
@@ -398,8 +434,7 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
 }  // namespace
 
 extern "C" size_t gwtf_packed_b_coupling_floats(int f) {
-  const int FP = gwtf_padded_width(f);
-  return 2 * (size_t)(FP / 16) * (FP / 4) * 64 + 2 * (size_t)FP * 4;
+  return GwtfPackB(gwtf_padded_width(f)).coupling_size();
 }
 
 extern "C" int gwtf_pack_folded(const float* W1p, const float* W0f, const float* c0f, float* packed_w, float* packed_b,
@@ -527,16 +562,24 @@ __global__ __launch_bounds__(256) void dw1_partial_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int FP, int f) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 2 * f * f) return;
-  const int br = t / (f * f), i = (t / f) % f, j = t % f;
+// 64 outputs per workgroup x 4 slices of the chunk axis, LDS-combined: fixed summation order
+__global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int FP, int f,
+                                                         size_t branch_stride) {
+  __shared__ float part[4][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + e;
+  const bool on = t < 2 * f * f;
+  const int br = on ? t / (f * f) : 0, i = on ? (t / f) % f : 0, j = on ? t % f : 0;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int c = 0; c < kDw1Chunks; c += 4)
+  if (on) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] += ws[((size_t)(c + u) * 2 + br) * FP * FP + (size_t)i * FP + j];
-  out[t] = (s[0] + s[1]) + (s[2] + s[3]);
+    for (int c = sl * (kDw1Chunks / 4); c < (sl + 1) * (kDw1Chunks / 4); c += 4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += ws[((size_t)(c + u) * 2 + br) * FP * FP + (size_t)i * FP + j];
+  }
+  part[sl][e] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (sl == 0 && on) out[(size_t)br * branch_stride + (size_t)i * f + j] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 }  // namespace
 
@@ -545,8 +588,10 @@ extern "C" size_t gwtf_dw1_workspace_floats(int f) {
   return (size_t)kDw1Chunks * 2 * FP * FP;
 }
 
-extern "C" int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* workspace, float* dW1, int f, int M, void* stream) {
-  if (!dA_mat || !h0_mat || !workspace || !dW1 || f <= 0 || f > GWTF_MAX_FP || M <= 0) return GWTF_E_BADARG;
+extern "C" int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* workspace, float* dW1, size_t branch_stride, int f,
+                             int M, void* stream) {
+  if (!dA_mat || !h0_mat || !workspace || !dW1 || f <= 0 || f > GWTF_MAX_FP || M <= 0 || branch_stride < (size_t)f * f)
+    return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int FP = gwtf_padded_width(f);
   const dim3 grid(kDw1Chunks, 2), block(256);
@@ -556,6 +601,6 @@ extern "C" int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* wo
     case 3: hipLaunchKernelGGL(dw1_partial_kernel<3>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
     default: hipLaunchKernelGGL(dw1_partial_kernel<4>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
   }
-  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 255) / 256), block, 0, st, workspace, dW1, FP, f);
+  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 63) / 64), block, 0, st, workspace, dW1, FP, f, branch_stride);
   return (int)hipGetLastError();
 }

@@ -71,6 +71,42 @@ struct GwtfPackW {
   GWTF_HD size_t coupling_size() const { return (used_size() + 255) / 256 * 256; }
 };
 
+// BACKWARD RECORD (read by the backward kernels through LDS), per coupling:
+//   W1T[branch][mi][ks][part][lane][8] f16 : hi / lo of W1[j][i], the TRANSPOSED sd1 weight as the A operand of
+//       dh = W1^T dacc on v_mfma_f32_16x16x32_f16: row i = 16*mi + (lane&15) (input feature of sd1), k-slot (ks, q = lane>>4, e)
+//       <-> output feature j = 32*ks + 16*(e>>2) + 4*q + (e&3), i.e. accumulator tile 2*ks + (e>>2), row 4*q + (e&3): the
+//       C-layout registers of dacc become the B operand with no data movement
+//   SD0N[branch][FP][4] f32 : {w0a, w0b, c0, 0} of the folded sd0 in natural feature order
+struct GwtfPackB {
+  int FP;
+  GWTF_HD GwtfPackB(int FP_) : FP(FP_) {}
+  GWTF_HD int MB() const { return FP / 16; }
+  GWTF_HD int KS() const { return (FP + 31) / 32; }
+  GWTF_HD size_t w1t_size() const { return (size_t)MB() * KS() * 2 * 256; }   // floats (2 f16 each), one branch
+  GWTF_HD size_t w1t(int branch) const { return branch * w1t_size(); }
+  GWTF_HD size_t sd0n(int branch) const { return 2 * w1t_size() + (size_t)branch * FP * 4; }
+  GWTF_HD size_t coupling_size() const { return 2 * w1t_size() + 2 * (size_t)FP * 4; }
+};
+
+// value of one float slot (= two f16) of a W1T image; W(j, i) returns the sd1 weight (0 outside the natural width)
+template <typename WFn>
+GWTF_HD float gwtf_w1t_slot(const GwtfPackB& P, size_t o /* offset inside one branch's image */, WFn W) {
+  const int jp = (int)(o % 4), lane = (int)((o / 4) % 64), part = (int)((o / 256) % 2);
+  const int ks = (int)((o / 512) % P.KS()), mi = (int)(o / ((size_t)512 * P.KS()));
+  const int i = 16 * mi + (lane & 15), q = lane >> 4;
+  _Float16 h[2];
+  for (int t = 0; t < 2; ++t) {
+    const int e = 2 * jp + t;
+    const int j = 32 * ks + 16 * (e >> 2) + 4 * q + (e & 3);
+    const float w = W(j, i);
+    const _Float16 hi = (_Float16)w;
+    h[t] = part == 0 ? hi : (_Float16)(w - (float)hi);
+  }
+  typedef _Float16 gwtf_h2 __attribute__((ext_vector_type(2)));
+  const gwtf_h2 pk = {h[0], h[1]};
+  return __builtin_bit_cast(float, pk);
+}
+
 // PACKED FILM WEIGHTS (read by gwtf_film_forward), per coupling, per branch:
 //   for which in {w,b}: L0T[GP][FP] (GP = G rounded up to 16, zero rows beyond G) | S[FP] | T[FP] | L1T[FP][FP] | L1B[FP]
 //   C1[FP] (sd1_bn shift: -mean/sqrt(var+eps)) | W2[2][FP] | B2[4] (sd2 bias, 2 used)

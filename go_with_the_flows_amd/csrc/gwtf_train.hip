@@ -78,7 +78,7 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
   sd0[8] = (float)wb * s;
   sd0[16] = bn[f + j] - (float)mean * s;
   if (pb_c) {   // backward record: sd0 parameters in natural feature order (csrc/gwtf_bwd.hip)
-    float* n4 = pb_c + 2 * (size_t)(FP / 16) * (FP / 4) * 64 + ((size_t)br * FP + j) * 4;
+    float* n4 = pb_c + GwtfPackB(FP).sd0n(br) + (size_t)j * 4;
     n4[0] = sd0[0];
     n4[1] = sd0[8];
     n4[2] = sd0[16];
@@ -204,18 +204,17 @@ namespace {
 // un-scaled sd1 weights -> backward records' W1T images (k-slot map of csrc/gwtf_bwd.hip); SD0N is written by fold0
 __global__ void pack_w1t_kernel(const float* __restrict__ raw, float* __restrict__ pb, int C, int f, int G, int FP) {
   const GwtfRaw R(f, G);
-  const int MB = FP / 16, KKF = FP / 4;
-  const size_t W1T = (size_t)MB * KKF * 64, PBs = 2 * W1T + 2 * (size_t)FP * 4;
+  const GwtfPackB P(FP);
+  const size_t W1T = P.w1t_size(), PBs = P.coupling_size();
   const size_t total = 2 * W1T * (size_t)C;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int c = (int)(idx / (2 * W1T));
     size_t o = idx - (size_t)c * 2 * W1T;
     const int br = (int)(o / W1T);
     o -= (size_t)br * W1T;
-    const int lane = (int)(o % 64), kk = (int)((o / 64) % KKF), mi = (int)(o / ((size_t)64 * KKF));
-    const int j = 16 * (kk >> 2) + 4 * (lane >> 4) + (kk & 3), i = 16 * mi + (lane & 15);
-    const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
-    pb[(size_t)c * PBs + (size_t)br * W1T + o] = (j < f && i < f) ? rb[R.sd1_w() + (size_t)j * f + i] : 0.f;
+    const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size() + R.sd1_w();
+    pb[(size_t)c * PBs + (size_t)br * W1T + o] =
+        gwtf_w1t_slot(P, o, [&](int j, int i) { return (j < f && i < f) ? rb[(size_t)j * f + i] : 0.f; });
   }
 }
 

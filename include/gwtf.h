@@ -159,9 +159,12 @@ int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* pa
 
 /* dW1[br][i][j] = sum_p dA_mat[br][i][p] * h0_mat[br][j][p]  (i, j < f; p < M = B*N): the sd1 weight gradient from the two
  * matrices the backward kernels leave behind ([2][FP][M] each, FP = gwtf_padded_width(f)).  Deterministic split-K on the
- * fp32 MFMA; workspace: gwtf_dw1_workspace_floats(f) floats.  dW1 [2][f][f] is overwritten. */
+ * fp32 MFMA; workspace: gwtf_dw1_workspace_floats(f) floats.  Branch br is written as an [f][f] block at
+ * dW1 + br * branch_stride (branch_stride = f*f for a dense [2][f][f]; the raw-arena branch size to write gradient records
+ * in place). */
 size_t gwtf_dw1_workspace_floats(int f);
-int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* workspace, float* dW1, int f, int M, void* stream);
+int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* workspace, float* dW1, size_t branch_stride, int f, int M,
+                  void* stream);
 
 /* Mixture negative log-likelihood over K flow components.
  * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
