@@ -5,7 +5,11 @@ from .decoders import LocalCondRNVPDecoder
 from .mixture import MixtureStack, flow_mixture_nll
 from . import optim
 from . import metrics
+from .encoders import PointNetCloudEncoder, FeatureEncoder, WeightsEncoder
+from .prior import RealNVPFlow, RealNVPFlowCouple, GlobalRNVPDecoder, GaussianFlowNLL, GaussianEntropy
 from ._lib import GwtfError
 
 __all__ = ['SharedDot', 'Swish', 'CondRealNVPFlow3D', 'CondRealNVPFlow3DTriple', 'LocalCondRNVPDecoder',
-           'WARP_PATTERNS', 'GwtfError', 'MixtureStack', 'flow_mixture_nll', 'optim', 'metrics']
+           'WARP_PATTERNS', 'GwtfError', 'MixtureStack', 'flow_mixture_nll', 'optim', 'metrics',
+           'PointNetCloudEncoder', 'FeatureEncoder', 'WeightsEncoder', 'RealNVPFlow', 'RealNVPFlowCouple',
+           'GlobalRNVPDecoder', 'GaussianFlowNLL', 'GaussianEntropy']

@@ -38,7 +38,7 @@ def synth_state(template_state, seed):
             v = rng.normal(0.0, 0.15, shape) if kind == 'weight' else rng.normal(0.0, 0.1, shape)
         elif name.endswith('film_w0') or name.endswith('film_b0'):
             v = rng.uniform(-1.0, 1.0, shape) / np.sqrt(shape[-1])
-        elif name.endswith('film_w1') or name.endswith('film_b1') or name in ('mu_mlp0', 'logvar_mlp0'):
+        elif name.endswith('film_w1') or name.endswith('film_b1') or name in ('mu_mlp0', 'logvar_mlp0', 'mu_mlp1', 'logvar_mlp1'):
             v = rng.normal(0.0, 0.08, shape) if kind == 'weight' else rng.normal(0.0, 0.1, shape)
         else:
             raise KeyError(f'synth_state: unknown parameter kind {key}')

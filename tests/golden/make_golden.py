@@ -36,7 +36,7 @@ T = torch.from_numpy
 
 
 def npy(x):
-    return x.detach().cpu().numpy()
+    return x.detach().cpu().numpy().copy()      # copy: .numpy() aliases module buffers that later runs overwrite
 
 
 def load_into(ref_module, our_module, seed):
@@ -345,6 +345,42 @@ def g11_encoder():
     save('g11_encoder', **out)
 
 
+def g12_prior():
+    """Global prior flow on the latent (GlobalRNVPDecoder) and the Gaussian latent losses, as models.py:137-151 calls them."""
+    from go_with_the_flows_amd import prior as oprior
+    out = {}
+    n_flows, F_, G, B = 3, 24, 16, 6
+    ref, mine = rdec.GlobalRNVPDecoder(n_flows, F_, G), oprior.GlobalRNVPDecoder(n_flows, F_, G)
+    out['dims'] = np.array([n_flows, F_, G, B])
+    rng = np.random.default_rng(1200)
+    g = rng.standard_normal((B, G)).astype(np.float32)
+    mu0 = (0.1 * rng.standard_normal((1, G))).astype(np.float32)
+    lv0 = (0.3 * rng.standard_normal((1, G))).astype(np.float32)
+    post_lv = (0.5 * rng.standard_normal((B, G))).astype(np.float32)
+    out.update(g=g, mu0=mu0, lv0=lv0, post_lv=post_lv)
+    for training in (False, True):
+        for mode in ('direct', 'inverse'):
+            load_into(ref, mine, 1210)
+            ref.train(training)
+            with torch.no_grad():
+                gs, mus, lvs = ref(T(g), mode=mode)
+                t = f'{"train" if training else "eval"}_{mode}'
+                out[f'gs_{t}'] = np.stack([npy(x) for x in gs])
+                out[f'mus_{t}'] = np.stack([npy(x) for x in mus])
+                out[f'lvs_{t}'] = np.stack([npy(x) for x in lvs])
+                if mode == 'inverse':     # models.py:137-151 + losses.py: the training-mode latent loss terms
+                    samples = gs + [T(g)]
+                    all_mus = [T(mu0).expand(B, G)] + mus
+                    all_lvs = [T(lv0).expand(B, G)] + lvs
+                    out[f'gnll_{t}'] = npy(rloss.GaussianFlowNLL()(samples, all_mus, all_lvs))
+                    out[f'gent_{t}'] = npy(rloss.GaussianEntropy()(T(post_lv)))
+            if training:
+                sd = ref.state_dict()
+                out[f'rm_{t}'] = npy(sd['flows.1.nvp2.T_mu_0.mu_mlp0_bn.running_mean'])
+                out[f'rv_{t}'] = npy(sd['flows.1.nvp2.T_mu_0.mu_mlp0_bn.running_var'])
+    save('g12_prior', **out)
+
+
 def contract():
     """Reference state_dict keys/shapes for a small decoder, as JSON (checkpoint contract)."""
     ref = rdec.LocalCondRNVPDecoder(2, 8, 16)
@@ -370,3 +406,4 @@ if __name__ == '__main__':
     g9_train_gradients()
     g10_optimizer()
     g11_encoder()
+    g12_prior()
