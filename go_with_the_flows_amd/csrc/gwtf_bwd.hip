@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
           const float pre = fmaf(sp[0], xa[nb], fmaf(sp[1], xb[nb], sp[2]));
           const float dp = pre > 0.f ? dh[nb][r] : 0.f;
           const int n = n_wave0 + 16 * nb + i16;
-          if (n < N) h0_mat[(((size_t)br * FP + fi) * B + b) * N + n] = fmaxf(pre, 0.f);
+          if (h0_mat && n < N) h0_mat[(((size_t)br * FP + fi) * B + b) * N + n] = fmaxf(pre, 0.f);
           pxa[nb] = fmaf(sp[0], dp, pxa[nb]);
           pxb[nb] = fmaf(sp[1], dp, pxb[nb]);
           g0 = fmaf(dp, xa[nb], g0);
@@ -479,7 +479,7 @@ extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, con
 extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c,
                                    const float* packed_b_c, float* g_in, float* dA_mat, float* h0_mat, float* g_sd0, int B,
                                    int N, int f, int pattern, void* stream) {
-  if (!x_in || !g_stats || !packed_w_c || !packed_b_c || !g_in || !dA_mat || !h0_mat || !g_sd0 || B <= 0 || N <= 0 ||
+  if (!x_in || !g_stats || !packed_w_c || !packed_b_c || !g_in || !dA_mat || !g_sd0 || B <= 0 || N <= 0 ||
       f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5)
     return GWTF_E_BADARG;
   return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dA_mat, h0_mat,

@@ -442,7 +442,8 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   if (rc) return rc;
   hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
                      g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP);
-  rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dA_mat, h0_mat, g_sd0, B, N, f, pat, stream);
+  // h0_mat already holds this coupling's h (written by the coupling path above): the statistics path does not rewrite it
+  rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dA_mat, nullptr, g_sd0, B, N, f, pat, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(fold0_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, moments_c, n_total, pat, g_sd0, g_raw_c,
                      g_mom, f, G, FP);

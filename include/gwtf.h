@@ -152,7 +152,8 @@ int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const fl
 
 /* Backward of gwtf_train_stats: g_stats [2][2][FP] = dL/d{sum y, sum y^2} per branch and feature (replicas already
  * summed by the caller) -> g_in (kept coordinates only); dA_mat += dL/dy (ACCUMULATED: the coupling path wrote it first,
- * or pre-zero it), h0_mat for the dW1 GEMM; g_sd0 [64][2][3][FP] +=. */
+ * or pre-zero it), h0_mat for the dW1 GEMM (NULL: not written -- the coupling path of the same input already wrote it);
+ * g_sd0 [64][2][3][FP] +=. */
 int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
                         float* g_in, float* dA_mat, float* h0_mat, float* g_sd0, int B, int N, int f, int pattern,
                         void* stream);
