@@ -100,9 +100,16 @@ class PointNetCloudEncoder(nn.Module):
                                                   _ptr(pooled, 'pooled'), B, N, w, n, _stream(x)))
         return feat, pooled
 
+    def has_fused_kernel(self):
+        """True when csrc/gwtf_encoder.hip holds an instantiation for this width list."""
+        w, n = self._widths_c()
+        return _lib.lib().gwtf_encoder_packed_floats(w, n) != 0
+
     def _needs_graph(self, x):
-        return self.training or (torch.is_grad_enabled() and
-                                 (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+        if self.training or (torch.is_grad_enabled() and
+                             (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            return True
+        return not self.has_fused_kernel()        # widths without an instantiation: the library-GEMM path on the device
 
     def forward(self, input):
         """(B,3,N) -> (B,C_last,N) per-point features (reference encoders.py:27-28)."""

@@ -1,0 +1,303 @@
+"""The callers on either side of the point-flow decoder: the VAE wrapper and the K-component flow-mixture model.
+
+Host-side mirror of lib/networks/models.py:12-265 (Local_Cond_RNVP_MC_Global_RNVP_VAE) and
+lib/networks/flow_mixture.py:11-179 (Flow_Mixture_Model) with lib/networks/losses.py:88-170 (FlowMixtureNLL,
+Flow_Mixture_Loss): same constructor keywords, attribute names, ``state_dict`` keys (so the reference's checkpoints load
+with strict=True), the same nested dict-of-lists outputs from ``forward`` and the same host-side randomness (torch RNG for
+the reparameterisations, ``np.random.choice`` for the per-point component draw).
+
+Besides the reference-shaped API there is the path a training loop should use: ``Flow_Mixture_Model.forward_fused`` runs
+the encoder (fused HIP kernel in eval), the prior flow, ONE batched launch for the K decoders and returns the tensors
+``Flow_Mixture_Loss.fused`` reduces with the mixture-NLL kernel -- no 9*n_flows lists, no B x K Python loop.
+
+The image-conditioned variant (Flow_Mixture_SVR_Model, flow_mixture.py:181-239) is not mirrored: its ResNet-18 image
+encoder is convolutional work outside the point-flow path (out of scope).
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .decoders import LocalCondRNVPDecoder
+from .encoders import FeatureEncoder, PointNetCloudEncoder, WeightsEncoder
+from .mixture import MixtureStack, flow_mixture_nll
+from .prior import GaussianEntropy, GaussianFlowNLL, GlobalRNVPDecoder
+
+
+class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
+    """Encoder + prior flow on the latent + ONE point-flow decoder (reference models.py:12-265)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        g = kwargs.get
+        self.train_mode, self.mode, self.deterministic = g('train_mode'), g('util_mode'), g('deterministic')
+        self.pc_enc_init_n_channels = g('pc_enc_init_n_channels')
+        self.pc_enc_init_n_features = g('pc_enc_init_n_features')
+        self.pc_enc_n_features = g('pc_enc_n_features')
+        self.g_latent_space_size = g('g_latent_space_size')
+        self.g_prior_n_flows, self.g_prior_n_features = g('g_prior_n_flows'), g('g_prior_n_features')
+        self.g_posterior_n_layers = g('g_posterior_n_layers')
+        self.p_latent_space_size, self.p_prior_n_layers = g('p_latent_space_size'), g('p_prior_n_layers')
+        self.p_decoder_n_flows, self.p_decoder_n_features = g('p_decoder_n_flows'), g('p_decoder_n_features')
+        self.p_decoder_base_type, self.p_decoder_base_var = g('p_decoder_base_type'), g('p_decoder_base_var')
+
+        self.pc_encoder = PointNetCloudEncoder(self.pc_enc_init_n_channels, self.pc_enc_init_n_features,
+                                               self.pc_enc_n_features)
+        G = self.g_latent_space_size
+        self.g0_prior_mus = nn.Parameter(torch.empty(1, G).normal_(mean=0.0, std=0.033))         # models.py:66-70
+        self.g0_prior_logvars = nn.Parameter(torch.empty(1, G).normal_(mean=0.0, std=0.33))
+        self.g_prior = GlobalRNVPDecoder(self.g_prior_n_flows, self.g_prior_n_features, G, weight_std=0.01)
+        self.g_posterior = FeatureEncoder(self.g_posterior_n_layers, self.pc_enc_n_features[-1], G, deterministic=False,
+                                          mu_weight_std=0.0033, mu_bias=0.0, logvar_weight_std=0.033, logvar_bias=0.0)
+        P = self.p_latent_space_size
+        if self.p_decoder_base_type == 'free':
+            self.p_prior = FeatureEncoder(self.p_prior_n_layers, G, P, deterministic=False, mu_weight_std=0.001,
+                                          mu_bias=0.0, logvar_weight_std=0.01, logvar_bias=0.0)
+        elif self.p_decoder_base_type == 'freevar':
+            self.register_buffer('p_prior_mus', torch.zeros((1, P, 1)))
+            self.p_prior = FeatureEncoder(self.p_prior_n_layers, G, P, deterministic=True, mu_weight_std=0.01, mu_bias=0.0)
+        elif self.p_decoder_base_type == 'fixed':
+            self.register_buffer('p_prior_mus', torch.zeros((1, P, 1)))
+            self.register_buffer('p_prior_logvar', self.p_decoder_base_var * torch.ones((1, P, 1)))
+        self.pc_decoder = self._build_pc_decoder(kwargs)
+
+    def _build_pc_decoder(self, kwargs):
+        return LocalCondRNVPDecoder(self.p_decoder_n_flows, self.p_decoder_n_features, self.g_latent_space_size,
+                                    weight_std=0.01)
+
+    def reparameterize(self, mu, logvar):
+        """mu + exp(0.5 logvar) * N(0,1)   (models.py:99-109; torch RNG of the tensors' device)."""
+        std = torch.exp(0.5 * logvar)
+        return torch.randn_like(std).mul(std).add_(mu)
+
+    def _pooled_features(self, g_input):
+        return self.pc_encoder.forward_max(g_input)          # == torch.max(self.pc_encoder(g_input), dim=2)[0]
+
+    def encode(self, g_input):
+        """models.py:111-151: posterior from the cloud (training / autoencoding) or a draw from the learned prior
+        (generating), pushed through the prior flow; lists are ordered base -> data."""
+        B, G = g_input.shape[0], self.g_latent_space_size
+        out = {'g_prior_mus': [self.g0_prior_mus.expand(B, G)], 'g_prior_logvars': [self.g0_prior_logvars.expand(B, G)]}
+        if self.mode in ('training', 'autoencoding'):
+            out['g_posterior_mus'], out['g_posterior_logvars'] = self.g_posterior(self._pooled_features(g_input))
+            out['g_posterior_samples'] = (self.reparameterize(out['g_posterior_mus'], out['g_posterior_logvars'])
+                                          if self.mode == 'training' else out['g_posterior_mus'])
+            buf_g = self.g_prior(out['g_posterior_samples'], mode='inverse')
+            out['g_prior_samples'] = buf_g[0] + [out['g_posterior_samples']]
+        elif self.mode == 'generating':
+            out['g_prior_samples'] = [self.reparameterize(out['g_prior_mus'][0], out['g_prior_logvars'][0])]
+            buf_g = self.g_prior(out['g_prior_samples'][0], mode='direct')
+            out['g_prior_samples'] += buf_g[0]
+        else:
+            raise ValueError(f'unknown util_mode {self.mode!r}')
+        out['g_prior_mus'] += buf_g[1]
+        out['g_prior_logvars'] += buf_g[2]
+        return out
+
+    def _base_gaussian(self, g_sample):
+        """(mu0, lv0) of the decoder's base distribution, each broadcastable to (B,P,1)  (models.py:169-193)."""
+        if self.p_decoder_base_type == 'free':
+            mu0, lv0 = self.p_prior(g_sample)
+            return mu0.unsqueeze(2), lv0.unsqueeze(2)
+        if self.p_decoder_base_type == 'freevar':
+            return self.p_prior_mus, self.p_prior(g_sample).unsqueeze(2)
+        if self.p_decoder_base_type == 'fixed':
+            return self.p_prior_mus, self.p_prior_logvar
+        raise ValueError(f'unknown p_decoder_base_type {self.p_decoder_base_type!r}')
+
+    def one_flow_decode(self, p_input, g_sample, pc_decoder, n_sampled_points):
+        """models.py:153-207: lists for ONE component (inverse on p_input when training, direct on a base draw otherwise)."""
+        B, P = g_sample.shape[0], self.p_latent_space_size
+        mu0, lv0 = self._base_gaussian(g_sample)
+        out = {'p_prior_mus': [mu0.expand(B, P, n_sampled_points)], 'p_prior_logvars': [lv0.expand(B, P, n_sampled_points)]}
+        if self.mode == 'training':
+            buf = pc_decoder(p_input, g_sample, mode='inverse')
+            out['p_prior_samples'] = buf[0] + [p_input]
+        else:
+            out['p_prior_samples'] = [self.reparameterize(out['p_prior_mus'][0], out['p_prior_logvars'][0])]
+            buf = pc_decoder(out['p_prior_samples'][0], g_sample, mode='direct')
+            out['p_prior_samples'] += buf[0]
+        out['p_prior_mus'] += buf[1]
+        out['p_prior_logvars'] += buf[2]
+        return out
+
+    def decode(self, p_input, g_sample, n_sampled_points, labeled_samples=False, warmup=False):
+        """Single-decoder decode (the body the reference keeps commented out at models.py:209-223)."""
+        return self.one_flow_decode(p_input, g_sample, self.pc_decoder, n_sampled_points), None
+
+    def forward(self, g_input, p_input, images=None, n_sampled_points=None, labeled_samples=False, warmup=False):
+        """models.py:224-265."""
+        size = p_input.shape[2] if n_sampled_points is None else n_sampled_points
+        if images is not None and self.train_mode == 'p_rnvp_mc_g_rnvp_vae_ic':
+            raise NotImplementedError('image-conditioned encoding (ResNet-18) is outside the point-flow path')
+        output_encoder = self.encode(g_input)
+        g_sample = (output_encoder['g_posterior_samples'] if self.mode in ('training', 'autoencoding')
+                    else output_encoder['g_prior_samples'][-1])
+        if labeled_samples:
+            samples, labels, logits = self.decode(p_input, g_sample, size, labeled_samples, warmup)
+            return output_encoder, samples, labels, logits
+        output_decoder, logits = self.decode(p_input, g_sample, size, labeled_samples, warmup)
+        return output_encoder, output_decoder, logits
+
+
+class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
+    """K point-flow decoders with per-shape mixture weights (reference flow_mixture.py:11-179)."""
+
+    def __init__(self, **kwargs):
+        self.n_components = kwargs['n_components']
+        self.params_reduce_mode = kwargs['params_reduce_mode']
+        self.weights_type = kwargs['weights_type']
+        super().__init__(**kwargs)
+        # registered after the base class's parameters, as in the reference (state_dict order)
+        self.mixture_weights_logits = nn.Parameter(torch.zeros(self.n_components), requires_grad=True)
+        self.mixture_weights_encoder = WeightsEncoder(3, self.g_latent_space_size, self.n_components, deterministic=True,
+                                                      mu_weight_std=0.001, mu_bias=0.0, logvar_weight_std=0.01,
+                                                      logvar_bias=0.0)
+        self._stack = None
+
+    def _build_pc_decoder(self, kwargs):
+        n_flows, f = self._get_decoder_params()
+        return nn.ModuleList([LocalCondRNVPDecoder(n_flows, f, self.g_latent_space_size, weight_std=0.01)
+                              for _ in range(self.n_components)])
+
+    # -- parameter-budget rules (flow_mixture.py:44-102) --------------------------------------------------------------
+    def _get_decoder_params(self):
+        n = self.n_components
+        if n == 1 or self.params_reduce_mode == 'none':
+            return self.p_decoder_n_flows, self.p_decoder_n_features
+        count = LocalCondRNVPDecoder.get_param_count
+        if self.params_reduce_mode == 'depth_and_feature':
+            depth = math.ceil(self.p_decoder_n_flows / math.sqrt(n))
+            f, _ = self._get_p_decoder_n_features(depth)
+        elif self.params_reduce_mode == 'depth_first':
+            depth = math.ceil(self.p_decoder_n_flows / n)
+            f, _ = self._get_p_decoder_n_features(depth)
+        elif self.params_reduce_mode == 'feature_first':
+            depth = self.p_decoder_n_flows
+            f, (over, budget, total) = self._get_p_decoder_n_features(depth)
+            if over:
+                while total > budget:
+                    depth -= 1
+                    total = count(depth, f, self.g_latent_space_size) * n
+        else:
+            raise ValueError(f'Unknown params_reduce_mode: {self.params_reduce_mode}')
+        return depth, f
+
+    def _get_p_decoder_n_features(self, depth):
+        f, n, G = self.p_decoder_n_features, self.n_components, self.g_latent_space_size
+        count = LocalCondRNVPDecoder.get_param_count
+        budget = count(self.p_decoder_n_flows, f, G)
+        total = budget * n
+        while total > budget and f > 4:
+            f -= 1
+            total = count(depth, f, G) * n
+        return f, (total > budget, budget, total)
+
+    # -- mixture weights and decoding (flow_mixture.py:104-179) ------------------------------------------------------
+    def get_weights(self, g_sample, warmup=False):
+        if warmup or self.weights_type == 'global_weights':
+            return self.mixture_weights_logits.unsqueeze(0).expand(g_sample.shape[0], self.n_components)
+        if self.weights_type == 'learned_weights':
+            return self.mixture_weights_encoder(g_sample)
+        raise ValueError(f'unknown weights_type {self.weights_type!r}')
+
+    def _draw_components(self, logits_row, n_points):
+        """np.random.choice over the normalised weights of ONE shape (flow_mixture.py:146-160) -> per-point component."""
+        w = np.exp(logits_row.detach().cpu().numpy())
+        return np.random.choice(range(self.n_components), size=n_points, p=w / w.sum())
+
+    def decode(self, p_input, g_sample, n_sampled_points, labeled_samples=False, warmup=False):
+        logits = self.get_weights(g_sample, warmup)
+        K = self.n_components
+        if self.mode == 'training':
+            sizes = [n_sampled_points] * K
+        else:
+            assert p_input.shape[0] == 1                     # evaluation feeds one shape at a time (flow_mixture.py:146)
+            flows_idx = self._draw_components(logits[0], n_sampled_points)
+            sizes = [int((flows_idx == t).sum()) for t in range(K)]
+        output_decoder = [self.one_flow_decode(p_input, g_sample, self.pc_decoder[i], sizes[i]) for i in range(K)]
+        if not labeled_samples:
+            return output_decoder, logits
+        samples = torch.zeros_like(p_input)
+        labels = torch.zeros(p_input.size(0), p_input.size(2))
+        for t in range(K):
+            mask = torch.from_numpy(flows_idx == t)
+            samples[:, :, mask] = output_decoder[t]['p_prior_samples'][-1]
+            labels[:, mask] = t + 1
+        return samples, labels, logits
+
+    # -- the fused path ------------------------------------------------------------------------------------------------
+    def mixture_stack(self):
+        if self._stack is None:
+            self._stack = MixtureStack(self.pc_decoder)
+        return self._stack
+
+    def forward_fused(self, g_input, p_input, warmup=False):
+        """Training / density pass without the list API: -> (output_encoder, dec) with dec = {z, logdet (K,B,3,N); mu0, lv0
+        (K,B,P); logits (B,K)}: everything ``Flow_Mixture_Loss.fused`` needs.  Same arithmetic as ``forward`` in 'training'
+        mode (one encoder pass, the prior flow, every component on every point in ONE batched launch when BatchNorm is in
+        eval mode and no gradient is needed; per component otherwise)."""
+        if self.mode != 'training':
+            raise ValueError("forward_fused is the density ('training') pass; use sample_fused for generation")
+        output_encoder = self.encode(g_input)
+        g_sample = output_encoder['g_posterior_samples']
+        logits = self.get_weights(g_sample, warmup)
+        B, K, P = g_sample.shape[0], self.n_components, self.p_latent_space_size
+        mu0, lv0 = [], []
+        for _ in range(K):                   # the reference evaluates p_prior once per component (running statistics!)
+            m, v = self._base_gaussian(g_sample)
+            mu0.append(m.expand(B, P, 1)[:, :, 0])
+            lv0.append(v.expand(B, P, 1)[:, :, 0])
+        z, logdet = self.mixture_stack().forward_all(p_input, g_sample, mode='inverse')
+        return output_encoder, {'z': z, 'logdet': logdet, 'mu0': torch.stack(mu0), 'lv0': torch.stack(lv0), 'logits': logits}
+
+    @torch.no_grad()
+    def sample_fused(self, g_sample, n_points, return_labels=False):
+        """Generation for ONE shape (flow_mixture.py:146-177 without the K Python passes): draw each point's component,
+        draw base samples, push every point through its own component in one launch.  -> (1,3,n_points)[, labels]."""
+        assert g_sample.shape[0] == 1
+        logits = self.get_weights(g_sample)
+        flows_idx = np.sort(self._draw_components(logits[0], n_points))       # points laid out component by component
+        counts = [int((flows_idx == t).sum()) for t in range(self.n_components)]
+        P = self.p_latent_space_size
+        mu0, lv0 = self._base_gaussian(g_sample)
+        z0 = self.reparameterize(mu0.expand(1, P, n_points), lv0.expand(1, P, n_points))
+        x, _ = self.mixture_stack().forward_partition(z0, g_sample, counts, mode='direct')
+        if return_labels:
+            return x, torch.from_numpy(flows_idx + 1).to(x.device).unsqueeze(0).float()
+        return x
+
+
+class FlowMixtureNLL(nn.Module):
+    """Mixture point NLL on the reference's list outputs (losses.py:88-137), reduced by the fused HIP kernel."""
+
+    def forward(self, output_decoder, mixture_weights_logits):
+        z = torch.stack([o['p_prior_samples'][0] for o in output_decoder])
+        logdet = torch.stack([sum(o['p_prior_logvars'][1:]) for o in output_decoder])
+        mu0 = torch.stack([o['p_prior_mus'][0][:, :, 0] for o in output_decoder])
+        lv0 = torch.stack([o['p_prior_logvars'][0][:, :, 0] for o in output_decoder])
+        return flow_mixture_nll(z, logdet, mu0, lv0, mixture_weights_logits)[0]
+
+
+class Flow_Mixture_Loss(nn.Module):
+    """pnll_weight * pnll + gnll_weight * gnll - gent_weight * gent   (losses.py:140-170)."""
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self.pnll_weight, self.gnll_weight, self.gent_weight = kwargs.get('pnll_weight'), kwargs.get('gnll_weight'), kwargs.get('gent_weight')
+        self.n_components = kwargs.get('n_components')
+        self.PNLL, self.GNLL, self.GENT = FlowMixtureNLL(), GaussianFlowNLL(), GaussianEntropy()
+
+    def _combine(self, pnll, output_prior):
+        gnll = self.GNLL(output_prior['g_prior_samples'], output_prior['g_prior_mus'], output_prior['g_prior_logvars'])
+        gent = self.GENT(output_prior['g_posterior_logvars'])
+        return self.pnll_weight * pnll + self.gnll_weight * gnll - self.gent_weight * gent, pnll, gnll, gent
+
+    def forward(self, output_prior, output_decoder, mixture_weights_logits):
+        return self._combine(self.PNLL(output_decoder, mixture_weights_logits), output_prior)
+
+    def fused(self, output_prior, dec):
+        """Same four values from ``Flow_Mixture_Model.forward_fused``'s outputs."""
+        pnll = flow_mixture_nll(dec['z'], dec['logdet'], dec['mu0'], dec['lv0'], dec['logits'])[0]
+        return self._combine(pnll, output_prior)

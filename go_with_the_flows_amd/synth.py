@@ -18,7 +18,13 @@ def synth_state(template_state, seed):
         shape = tuple(template_state[key].shape)
         leaf = ('', '') + tuple(key.rsplit('.', 2))
         name, kind = leaf[-2], leaf[-1]
-        if kind == 'eps':
+        if kind in ('g0_prior_mus', 'g0_prior_logvars', 'mixture_weights_logits'):      # top-level model parameters
+            v = rng.normal(0.0, 0.3, shape)
+        elif kind == 'p_prior_mus':
+            v = np.zeros(shape)
+        elif kind == 'p_prior_logvar':
+            v = np.full(shape, -1.0)
+        elif kind == 'eps':
             v = np.full(shape, 1e-6, np.float32)
         elif kind == 'num_batches_tracked':
             v = np.zeros(shape, np.int64)

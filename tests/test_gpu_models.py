@@ -1,0 +1,139 @@
+"""Flow_Mixture_Model / Flow_Mixture_Loss end to end on the GPU against the genuine reference (golden g13: every parameter
+seeded, reparameterisation noise recorded).  Needs an MI355X."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden, GOLDEN, TOL_COORD
+from helpers import maxabs
+from go_with_the_flows_amd import models
+from go_with_the_flows_amd.synth import load_synth_
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def build(**over):
+    cfg = dict(json.load(open(os.path.join(GOLDEN, 'contract_model.json')))['cfg'], **over)
+    m = models.Flow_Mixture_Model(**cfg)
+    load_synth_(m, 1310)
+    return m.to(DEV), cfg
+
+
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('base_type', ['free', 'freevar'])
+def test_training_mode_forward_and_loss_match_reference(base_type, training):
+    D = golden('g13_full_model')
+    m, cfg = build(p_decoder_base_type=base_type)
+    m.train(training)
+    noise = dev(D['noise_g'])
+    m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+    t = f'{base_type}_{"train" if training else "eval"}'
+    tol = 5e-4 if training else 2e-5          # train: B=4 batch statistics amplify fp32 noise (as in g3)
+    loss_fn = models.Flow_Mixture_Loss(**cfg)
+    with torch.no_grad():
+        enc, dec, logits = m(dev(D['gcloud']), dev(D['pcloud']))
+        terms = [float(v) for v in loss_fn(enc, dec, logits)]
+    assert [len(enc['g_prior_samples']), len(enc['g_prior_mus']), len(dec[0]['p_prior_samples'])] == list(D[f'n_lists_{t}'])
+    assert maxabs(host(logits), D[f'logits_{t}']) < tol
+    assert maxabs(host(enc['g_posterior_samples']), D[f'g_sample_{t}']) < tol
+    assert maxabs(host(enc['g_prior_samples'][0]), D[f'g_base_{t}']) < 10 * tol
+    assert maxabs(np.stack([host(o['p_prior_samples'][0]) for o in dec]), D[f'z_{t}']) < 10 * tol
+    assert maxabs(np.stack([host(o['p_prior_logvars'][0][:, :, 0]) for o in dec]), D[f'lv0_{t}']) < tol
+    ref = D[f'terms_{t}']
+    for got, want in zip(terms, ref):
+        assert abs(got - want) < (1e-3 if training else 2e-5) * max(1.0, abs(want))
+    if training:
+        assert maxabs(host(m.state_dict()['p_prior.features.mlp0_bn.running_mean']), D[f'rm_pprior_{t}']) < 1e-4
+        return
+    # the fused path computes the same four numbers (eval BatchNorm: one batched decoder launch + the NLL kernel)
+    with torch.no_grad():
+        enc2, fused = m.forward_fused(dev(D['gcloud']), dev(D['pcloud']))
+        terms2 = [float(v) for v in loss_fn.fused(enc2, fused)]
+    assert fused['z'].shape == (cfg['n_components'], 4, 3, 48)
+    for got, want in zip(terms2, ref):
+        assert abs(got - want) < 2e-5 * max(1.0, abs(want))
+
+
+def test_fused_training_step_is_differentiable_and_matches_list_api():
+    D = golden('g13_full_model')
+    m, cfg = build()
+    m.train()
+    noise = dev(D['noise_g'])
+    m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+    loss_fn = models.Flow_Mixture_Loss(**cfg)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    enc, dec, logits = m(dev(D['gcloud']), dev(D['pcloud']))
+    l1 = loss_fn(enc, dec, logits)[0]
+    l1.backward()
+    g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.load_state_dict(state)                       # undo the running-statistic updates
+    m.zero_grad(set_to_none=True)
+    enc, fused = m.forward_fused(dev(D['gcloud']), dev(D['pcloud']))
+    l2 = loss_fn.fused(enc, fused)[0]
+    l2.backward()
+    assert abs(float(l1) - float(l2)) < 1e-4 * abs(float(l1))
+    names = [n for n, p in m.named_parameters() if p.grad is not None]
+    assert set(names) == set(g1) and len(names) > 600
+    # per parameter, relative to its own scale with a floor (gradients that are analytically ~0 -- a bias in front of a
+    # BatchNorm -- are pure rounding noise), and globally
+    worst = max(float((p.grad - g1[n]).abs().max() / (g1[n].abs().max() + 1e-3)) for n, p in m.named_parameters() if n in g1)
+    assert worst < 1e-3
+    gnorm = float(torch.sqrt(sum((v ** 2).sum() for v in g1.values())))
+    dnorm = float(torch.sqrt(sum(((p.grad - g1[n]) ** 2).sum() for n, p in m.named_parameters() if n in g1)))
+    assert dnorm < 1e-5 * gnorm
+
+
+def test_labelled_generation_matches_reference():
+    D = golden('g13_full_model')
+    m, cfg = build(util_mode='generating')
+    m.eval()
+    noise_p, noise_g = dev(D['gen_noise_p']), dev(D['gen_noise_g'])
+
+    def rep(mu, logvar):
+        if mu.dim() == 2:
+            return noise_g * torch.exp(0.5 * logvar) + mu
+        return noise_p[:, :, :mu.shape[2]] * torch.exp(0.5 * logvar) + mu
+    m.reparameterize = rep
+    Ns = D['gen_samples'].shape[2]
+    np.random.seed(1320)
+    with torch.no_grad():
+        enc, samples, labels, logits = m(dev(D['gcloud'][:1, :, :Ns]), dev(D['pcloud'][:1, :, :Ns]), None, Ns, True, False)
+    assert maxabs(host(enc['g_prior_samples'][-1]), D['gen_g']) < 2e-5
+    assert maxabs(host(logits), D['gen_logits']) < 2e-5
+    assert np.array_equal(host(labels), D['gen_labels'])
+    assert maxabs(host(samples), D['gen_samples']) < TOL_COORD
+
+
+def test_sample_fused_equals_per_component_decoding():
+    m, cfg = build(util_mode='generating')
+    m.eval()
+    n = 500
+    g = torch.randn(1, cfg['g_latent_space_size'], device=DEV)
+    draw = np.random.default_rng(3).integers(0, cfg['n_components'], n)
+    m._draw_components = lambda row, k: draw
+    base = torch.randn(1, 3, n, device=DEV)
+    m.reparameterize = lambda mu, logvar: base[:, :, :mu.shape[2]] * torch.exp(0.5 * logvar) + mu
+    x, labels = m.sample_fused(g, n, return_labels=True)
+    srt = np.sort(draw)
+    assert np.array_equal(host(labels)[0], srt + 1)
+    off = 0
+    with torch.no_grad():
+        for k in range(cfg['n_components']):
+            cnt = int((srt == k).sum())
+            mu0, lv0 = m._base_gaussian(g)
+            z0 = base[:, :, off:off + cnt] * torch.exp(0.5 * lv0) + mu0
+            want = m.pc_decoder[k](z0.contiguous(), g, mode='direct')[0][-1]
+            assert maxabs(host(x[:, :, off:off + cnt]), host(want)) < TOL_COORD
+            off += cnt

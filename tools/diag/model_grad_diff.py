@@ -1,0 +1,28 @@
+import sys, json, os, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from go_with_the_flows_amd import models
+from go_with_the_flows_amd.synth import load_synth_
+D = np.load("tests/golden/g13_full_model.npz")
+cfg = json.load(open("tests/golden/contract_model.json"))["cfg"]
+m = models.Flow_Mixture_Model(**cfg); load_synth_(m, 1310); m = m.cuda(); m.train()
+dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+noise = dev(D["noise_g"])
+m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+loss_fn = models.Flow_Mixture_Loss(**cfg)
+state = {k: v.clone() for k, v in m.state_dict().items()}
+enc, dec, logits = m(dev(D["gcloud"]), dev(D["pcloud"]))
+l1 = loss_fn(enc, dec, logits); l1[0].backward()
+g1 = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+m.load_state_dict(state); m.zero_grad(set_to_none=True)
+enc, fused = m.forward_fused(dev(D["gcloud"]), dev(D["pcloud"]))
+l2 = loss_fn.fused(enc, fused); l2[0].backward()
+print([float(v) for v in l1]); print([float(v) for v in l2])
+rows = []
+for n, p in m.named_parameters():
+    if n in g1:
+        d = float((p.grad - g1[n]).abs().max()); s = float(g1[n].abs().max())
+        rows.append((d / (s + 1e-6), d, s, n))
+rows.sort(reverse=True)
+for r in rows[:15]: print("%.3e  abs %.3e  scale %.3e  %s" % r)
+gn = float(torch.sqrt(sum((v ** 2).sum() for v in g1.values())))
+print("global grad norm", gn, "global diff norm", float(torch.sqrt(sum(((p.grad - g1[n]) ** 2).sum() for n, p in m.named_parameters() if n in g1))))
