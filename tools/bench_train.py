@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""End-to-end training step of the airplane generative config (config_generative_modeling_airplane.yaml: K=4 components,
+decoders resolve to 11 Triples x f=37, G=128, B=64 x N=2048) on one MI355X: encoder + posterior + prior flow + 4 decoders
+(batch-statistic BatchNorm) + mixture NLL + backward + fused Adam.  GPU box only.
+
+    python tools/bench_train.py [--batch 64] [--steps 5] [--graph]
+"""
+import argparse
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+from go_with_the_flows_amd import models, optim
+from go_with_the_flows_amd.synth import load_synth_, synth_inputs
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--batch', type=int, default=64)
+ap.add_argument('--points', type=int, default=2048)
+ap.add_argument('--steps', type=int, default=5)
+ap.add_argument('--graph', action='store_true', help='capture forward + backward in one hipGraph')
+ap.add_argument('--parts', default='epd', help='debug: which parts run (e=encoder, p=prior flow, d=decoders)')
+a = ap.parse_args()
+
+CFG = dict(train_mode='p_rnvp_mc_g_rnvp_vae', util_mode='training', deterministic=False,
+           pc_enc_init_n_channels=3, pc_enc_init_n_features=64, pc_enc_n_features=[128, 256, 512],
+           g_latent_space_size=128, g_prior_n_flows=7, g_prior_n_features=128, g_posterior_n_layers=1,
+           p_latent_space_size=3, p_prior_n_layers=1, p_decoder_n_flows=21, p_decoder_n_features=64,
+           p_decoder_base_type='free', p_decoder_base_var=-3.9551, n_components=4,
+           params_reduce_mode='depth_and_feature', weights_type='learned_weights',
+           pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0)
+torch.manual_seed(0)
+model = models.Flow_Mixture_Model(**CFG).cuda().train()
+crit = models.Flow_Mixture_Loss(**CFG)
+opt = optim.Adam(model.parameters(), lr=2.56e-4, betas=(0.9, 0.999), weight_decay=1e-5, amsgrad=True)
+n_params = sum(p.numel() for p in model.parameters())
+print(f'decoders: {len(model.pc_decoder)} x ({model.pc_decoder[0].n_flows} Triples, f={model.pc_decoder[0].f_n_features}); '
+      f'{n_params / 1e6:.2f} M parameters')
+g_in = torch.from_numpy(synth_inputs(a.batch, a.points, 4, 1)[0]).cuda()
+p_in = torch.from_numpy(synth_inputs(a.batch, a.points, 4, 2)[0]).cuda()
+
+
+g_fix = torch.randn(a.batch, CFG['g_latent_space_size'], device='cuda')
+
+
+def fwd_bwd():
+    opt.zero_grad(set_to_none=True)
+    if a.parts == 'epd':
+        enc, dec = model.forward_fused(g_in, p_in)
+        loss, pnll, gnll, gent = crit.fused(enc, dec)
+    else:                                   # debug: isolate one part of the step
+        loss = 0.0
+        if 'e' in a.parts:
+            loss = loss + model.g_posterior(model.pc_encoder.forward_max(g_in))[0].sum()
+        if 'r' in a.parts:
+            loss = loss + torch.randn_like(g_fix).sum() * model.g0_prior_mus.sum()
+        if 'p' in a.parts:
+            gs, mus, lvs = model.g_prior(g_fix, mode='inverse')
+            loss = loss + gs[0].square().sum() + sum(lvs).sum()
+        if 'd' in a.parts:
+            z, ld = model.mixture_stack().forward_all(p_in, g_fix, mode='inverse')
+            loss = loss + (z.square().sum() + ld.sum()) / a.batch
+        if 'n' in a.parts:
+            z, ld = model.mixture_stack().forward_all(p_in, g_fix, mode='inverse')
+            mu0 = torch.zeros(4, a.batch, 3, device='cuda'); lv0 = torch.zeros(4, a.batch, 3, device='cuda')
+            from go_with_the_flows_amd.mixture import flow_mixture_nll
+            loss = loss + flow_mixture_nll(z, ld, mu0, lv0, model.get_weights(g_fix))[0]
+    loss.backward()
+    return loss
+
+
+def step():
+    loss = fwd_bwd()
+    opt.step()
+    return loss
+
+
+def timed(fn, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for _ in range(2):
+    l = step()
+print('loss after warm-up', float(l.detach()))
+del l                       # keep no reference to an autograd graph across iterations (hipGraph capture needs that)
+ms = timed(step, a.steps)
+pts = a.batch * a.points
+print(f'eager   : {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s (each point through all {CFG["n_components"]} components)')
+if a.graph:
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        fwd_bwd()          # the optimiser stays outside: its bias corrections depend on the host-side step count
+
+    def replay_step():
+        graph.replay()
+        opt.step()
+    ms = timed(replay_step, a.steps)
+    print(f'hipGraph: {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s')
