@@ -481,6 +481,7 @@ class TrainStackFn(torch.autograd.Function):
     def backward(ctx, g_out, g_logdet, _gl, _gb):
         p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats = ctx.saved_tensors
         C, f, G, FP, pattern0, eps, mode = ctx.meta
+        C, f, G, FP, pattern0 = int(C), int(f), int(G), int(FP), int(pattern0)     # numpy ints would poison the pointer arithmetic
         inverse = mode == 'inverse'
         L = _lib.lib()
         B, _, N = p.shape
@@ -503,24 +504,35 @@ class TrainStackFn(torch.autograd.Function):
         gxa, gxb = torch.empty_like(p), torch.empty_like(p)
         bufs = [torch.empty_like(p), torch.empty_like(p)]
         st = _lib._stream(p)
+        # raw device addresses (integer arithmetic instead of ~10 tensor slices per coupling: this loop is host-bound)
+        P = lambda t: t.data_ptr()
+        a_raw, a_pw, a_pb, a_mom, a_ys, a_graw = P(raw), P(pw), P(pb), P(mom), P(ystats), P(g_raw)
+        a_gsd0, a_gbias, a_gstats, a_gmom = P(g_sd0), P(g_bias), P(g_stats), P(g_mom)
+        a_ps, a_p, ps_stride = P(ps), P(p), ps[0].numel() * 4
+        a_cur, a_gld, a_bufs = P(cur), P(g_ld), (P(bufs[0]), P(bufs[1]))
+        a_frec, a_fraw, a_gxa, a_gxb, a_dA, a_H0, a_gfilm, a_gfraw = (P(film_rec), P(film_raw), P(gxa), P(gxb), P(dA), P(H0),
+                                                                      P(g_film), P(g_film_raw))
+        ws = torch.empty(L.gwtf_dw1_workspace_floats(f), device=dev, dtype=torch.float32)
+        a_ws, M = P(ws), B * N
+        eps_f, mode_i = float(eps), _lib._MODES[mode]
         with torch.cuda.device(dev):
             for c in (range(C) if inverse else range(C - 1, -1, -1)):   # reverse of the forward's processing order
                 step = C - 1 - c if inverse else c               # this coupling's position in the forward order
                 if inverse:
-                    x_in = ps[c + 1] if c + 1 < C else p
+                    x_in = a_ps + (c + 1) * ps_stride if c + 1 < C else a_p
                 else:
-                    x_in = ps[c - 1] if c > 0 else p
-                nxt = bufs[c & 1]
-                g_raw_c = g_raw[c * RC:(c + 1) * RC]
+                    x_in = a_ps + (c - 1) * ps_stride if c > 0 else a_p
+                nxt = a_bufs[c & 1]
+                g_raw_c = a_graw + c * RC * 4
                 _lib.check(L.gwtf_train_coupling_backward(
-                    x_in.data_ptr(), cur.data_ptr(), g_ld.data_ptr(), raw[c * RC:].data_ptr(), pw[c * PW:].data_ptr(),
-                    pb[c * PB:].data_ptr(), film_rec.data_ptr(), film_raw.data_ptr(), mom[step].data_ptr(),
-                    ystats[c].data_ptr(), nxt.data_ptr(), gxa.data_ptr(), gxb.data_ptr(), dA.data_ptr(), H0.data_ptr(),
-                    g_film.data_ptr(), g_sd0[c].data_ptr(), g_bias[c].data_ptr(), g_stats[c].data_ptr(), g_mom[c].data_ptr(),
-                    g_film_raw.data_ptr(), g_raw_c.data_ptr(), c, B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], st))
+                    x_in, a_cur, a_gld, a_raw + c * RC * 4, a_pw + c * PW * 4, a_pb + c * PB * 4, a_frec, a_fraw,
+                    a_mom + step * R * 16 * 4, a_ys + c * R * 2 * FP * 2 * 4, nxt, a_gxa, a_gxb, a_dA, a_H0, a_gfilm,
+                    a_gsd0 + c * R * 2 * 3 * FP * 4, a_gbias + c * R * 4 * 4, a_gstats + c * 2 * 2 * FP * 4, a_gmom + c * 16 * 4,
+                    a_gfraw, g_raw_c, c, B, N, C, f, G, pattern0, eps_f, mode_i, st))
                 # dW1 (2,f,f): one skinny GEMM with K = B*N, written at GwtfRaw::sd1_w of both branch records
-                _lib.dw1_gemm(dA, H0, f, out=g_raw_c[6 * f:], branch_stride=br_size)
-                cur = nxt
+                _lib.check(L.gwtf_dw1_gemm(a_dA, a_H0, a_ws, g_raw_c + 6 * f * 4, br_size, f, M, st))
+                a_cur = nxt
+        cur = bufs[(C - 1) & 1] if inverse else bufs[0]          # written by the last coupling processed
         return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None, None
 
 

@@ -10,8 +10,9 @@
 // accumulate), as in the stack kernel (gwtf_device.h).  BatchNorm is folded into the weight rows and a bias (the bias is
 // the accumulators' start value).  Weights (672 KiB for 64-128-256-512) stream L2 -> LDS by LDS-DMA in 32-KiB chunks
 // shared by the 8 wavefronts, double-buffered against the MFMAs.  The last layer's output is never stored unless the
-// caller asks for it: max over the wavefront's points (DPP row reduction), LDS atomics per workgroup, one global atomic
-// per (workgroup, feature) -- values are >= 0 after ReLU, so integer max on the bit patterns is exact.
+// caller asks for it: element-wise integer-max LDS atomics (every lane its own slot: conflict-free) combine the 8
+// wavefronts, the 16 point-lanes of each feature are reduced once at the end, one global atomic per (workgroup, feature)
+// -- values are >= 0 after ReLU, so integer max on the bit patterns is exact.
 #include <hip/hip_runtime.h>
 #include "gwtf_device.h"
 
@@ -72,14 +73,6 @@ __global__ void enc_pack_l0_kernel(const float* __restrict__ W, const float* __r
   tab[c] = make_float4(W[c * 3] * s, W[c * 3 + 1] * s, W[c * 3 + 2] * s, bn[C0 + c] - bn[2 * C0 + c] * s);
 }
 
-__device__ __forceinline__ float row_max16(float v) {   // max over the 16 lanes of a DPP row, result in every lane
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));   // quad_perm [1,0,3,2]
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));   // quad_perm [2,3,0,1]
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));  // row_half_mirror
-  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)));  // row_mirror
-  return v;
-}
-
 // ReLU + split of one accumulator tile into elements 4*(m&1)..+3 of the next layer's B fragment
 __device__ __forceinline__ void relu_split_into(const f32x4& a, f16x8& hi, f16x8& lo, int half) {
 #pragma unroll
@@ -116,7 +109,7 @@ __global__ __launch_bounds__(kEncThreads) void encoder_kernel(const float* __res
   constexpr int NB = 2;
   __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
   __shared__ __attribute__((aligned(16))) float head[E::HEAD];
-  __shared__ int wgmax[C3];
+  __shared__ int wgmax[C3 * 16];   // [tile][row r][lane]: element-wise max over the 8 wavefronts, reduced over lanes at the end
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.y, n_wave0 = blockIdx.x * kEncPoints + wave * 32;
   const float* chunks = packed + E::HEAD;
@@ -131,7 +124,7 @@ __global__ __launch_bounds__(kEncThreads) void encoder_kernel(const float* __res
   };
   stage(0, 0);
   for (int t = tid; t < E::HEAD; t += kEncThreads) head[t] = packed[t];
-  for (int t = tid; t < C3; t += kEncThreads) wgmax[t] = 0;
+  for (int t = tid; t < C3 * 16; t += kEncThreads) wgmax[t] = 0;
 
   float px[NB], py[NB], pz[NB];
   bool valid[NB];
@@ -216,17 +209,15 @@ __global__ __launch_bounds__(kEncThreads) void encoder_kernel(const float* __res
     for (int t = 0; t < E::TM3; ++t) {
       const int m = ci * E::TM3 + t;
       const f32x4 bias = *reinterpret_cast<const f32x4*>(bias3 + 16 * m + 4 * q);
-      const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
       f32x4 acc[NB];
-      tile_mfma<E::KS3, NB>(L + t * E::KS3 * 512, lane, h2hi, h2lo, zero, acc);
+      tile_mfma<E::KS3, NB>(L + t * E::KS3 * 512, lane, h2hi, h2lo, bias, acc);
       if (feat) {
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb)
           if (valid[nb]) {
             const int n = n_wave0 + 16 * nb + i16;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              feat[((size_t)b * C3 + 16 * m + 4 * q + r) * N + n] = fmaxf(acc[nb][r] + bias[r], 0.f);
+            for (int r = 0; r < 4; ++r) feat[((size_t)b * C3 + 16 * m + 4 * q + r) * N + n] = fmaxf(acc[nb][r], 0.f);
           }
       }
       if (pooled) {
@@ -234,20 +225,29 @@ __global__ __launch_bounds__(kEncThreads) void encoder_kernel(const float* __res
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[nb][r] = valid[nb] ? acc[nb][r] : -3.0e38f;
+            for (int r = 0; r < 4; ++r) acc[nb][r] = valid[nb] ? acc[nb][r] : 0.f;
         }
-        // max over points commutes with the per-feature bias and the ReLU
+        // ReLU'd values are >= 0: integer max on the bit patterns is exact.  One conflict-free LDS atomic per (tile, row):
+        // every lane owns its slot, the 16 point-lanes of a row are combined once at the end of the kernel.
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float v = fmaxf(row_max16(fmaxf(acc[0][r], acc[1][r])) + bias[r], 0.f);
-          if (i16 == 0) atomicMax(&wgmax[16 * m + 4 * q + r], __builtin_bit_cast(int, v));
-        }
+        for (int r = 0; r < 4; ++r)
+          atomicMax(&wgmax[(m * 4 + r) * 64 + lane], __builtin_bit_cast(int, fmaxf(fmaxf(acc[0][r], acc[1][r]), 0.f)));
       }
     }
   }
   if (pooled) {
     __syncthreads();
-    for (int t = tid; t < C3; t += kEncThreads) atomicMax(reinterpret_cast<int*>(pooled) + (size_t)b * C3 + t, wgmax[t]);
+    for (int ft = tid; ft < C3; ft += kEncThreads) {
+      const int m = ft >> 4, qq = (ft >> 2) & 3, r = ft & 3;
+      const int4* src = reinterpret_cast<const int4*>(&wgmax[(m * 4 + r) * 64 + 16 * qq]);
+      int v = 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int4 w = src[i];
+        v = max(max(v, max(w.x, w.y)), max(w.z, w.w));
+      }
+      atomicMax(reinterpret_cast<int*>(pooled) + (size_t)b * C3 + ft, v);
+    }
   }
 }
 

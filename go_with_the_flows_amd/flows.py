@@ -198,6 +198,8 @@ class StackEngine:
         self._srcs, self._src_stamp, self._zeros = None, None, None
         self._cache_key = None
         self._packed = None
+        self._flat_key, self._flat = None, None
+        self._bn_cache = None
 
     def raw_arena(self):
         """Parameters + BatchNorm buffers of all couplings as one flat tensor (autograd-aware torch.cat).  The list
@@ -209,9 +211,21 @@ class StackEngine:
             dev = self.couplings[0].eps.device
             self._zeros = {n: torch.zeros(n, device=dev) for n in {op for t, op in self._srcs if t is None}}
             self._src_stamp = stamp
-        z = self._zeros
-        return torch.cat([z[op] if t is None else (t[0].t().reshape(-1) if op == 't' else t.view(-1))
-                          for t, op in self._srcs])
+            self._flat_key = None
+        # the flattened views are cached too (1320 of them for an 11-Triple decoder: building them costs more host time
+        # than the copy); they are created with grad mode ON so the cat below is differentiable whenever the caller's
+        # context is, and rebuilt when a requires_grad flag changes
+        key = sum(1 for t, _ in self._srcs if t is not None and t.requires_grad)
+        if key != self._flat_key:
+            z = self._zeros
+            with torch.enable_grad():
+                self._flat = [z[op] if t is None else (None if op == 't' else t.view(-1)) for t, op in self._srcs]
+            self._transposed = [i for i, (t, op) in enumerate(self._srcs) if op == 't']
+            self._flat_key = key
+        flat = self._flat
+        for i in self._transposed:          # sd0.weight is stored transposed: a copy, so it is re-made every time
+            flat[i] = self._srcs[i][0][0].t().reshape(-1)
+        return torch.cat(flat)
 
     def _collect(self):
         self._key(False)
@@ -306,20 +320,27 @@ class StackEngine:
 
     def _update_running_stats(self, bn_batch):
         """running = (1-m)*running + m*batch with the unbiased batch variance (torch.nn.BatchNorm1d semantics)."""
-        with torch.no_grad():
+        stamp = sum(c._stamp for c in self.couplings)
+        if self._bn_cache is None or self._bn_cache[0] != stamp:     # module / buffer lists per momentum value, cached
             mods = self._bn_modules()
-            flat = bn_batch.reshape(len(mods), 2, self.f)
             groups = {}
             for i, m in enumerate(mods):
                 if m.track_running_stats and m.running_mean is not None:
                     groups.setdefault(0.1 if m.momentum is None else float(m.momentum), []).append(i)
-            for mom, idx in groups.items():
-                rms, rvs = [mods[i].running_mean for i in idx], [mods[i].running_var for i in idx]
+            plan = [(mom, idx, [mods[i].running_mean for i in idx], [mods[i].running_var for i in idx])
+                    for mom, idx in groups.items()]
+            self._bn_cache = (stamp, len(mods), plan, [m.num_batches_tracked for m in mods if m.num_batches_tracked is not None])
+        _, n_mods, plan, counters = self._bn_cache
+        with torch.no_grad():
+            flat = bn_batch.reshape(n_mods, 2, self.f)
+            means, variances = flat[:, 0].unbind(0), flat[:, 1].unbind(0)
+            for mom, idx, rms, rvs in plan:
+                whole = len(idx) == n_mods
                 torch._foreach_mul_(rms, 1.0 - mom)
-                torch._foreach_add_(rms, [flat[i, 0] for i in idx], alpha=mom)
+                torch._foreach_add_(rms, list(means) if whole else [means[i] for i in idx], alpha=mom)
                 torch._foreach_mul_(rvs, 1.0 - mom)
-                torch._foreach_add_(rvs, [flat[i, 1] for i in idx], alpha=mom)
-            torch._foreach_add_([m.num_batches_tracked for m in mods if m.num_batches_tracked is not None], 1)
+                torch._foreach_add_(rvs, list(variances) if whole else [variances[i] for i in idx], alpha=mom)
+            torch._foreach_add_(counters, 1)
 
     def _run_train(self, p, g, mode, want_lists):
         """model.train() forward: statistics over all B*N points (and, when torch.distributed is initialised,

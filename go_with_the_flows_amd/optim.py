@@ -17,7 +17,33 @@ from . import _lib
 class Adam(Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
-        self._tables = {}
+        self._plans = {}
+
+    def load_state_dict(self, state_dict):
+        self._plans = {}
+        return super().load_state_dict(state_dict)
+
+    def _make_plan(self, plist, dev, step, ams):
+        """Pointer tables of parameters and moments (stable across steps) for one launch group."""
+        n = len(plist)
+        arr = ctypes.c_void_p * n
+        sts = [self.state[p] for p in plist]
+        ptr = lambda ts: arr(*[t.data_ptr() for t in ts])
+        return {'n': n, 'arr': arr, 'dev': dev, 'step': step, 'ams': ams, 'states': sts, 'p0': plist[0].data_ptr(),
+                'p': ptr(plist), 'm': ptr([s['exp_avg'] for s in sts]), 'v': ptr([s['exp_avg_sq'] for s in sts]),
+                'vmax': ptr([s['max_exp_avg_sq'] for s in sts]) if ams else None,
+                'numel': (ctypes.c_size_t * n)(*[p.numel() for p in plist])}
+
+    @staticmethod
+    def _launch(L, group, plan, grads, step):
+        gptr = plan['arr'](*[(g if g.is_contiguous() else g.contiguous()).data_ptr() for g in grads])
+        b1, b2 = group['betas']
+        dev = plan['dev']
+        with torch.cuda.device(dev):
+            _lib.check(L.gwtf_adam_step(plan['p'], gptr, plan['m'], plan['v'], plan['vmax'], plan['numel'], plan['n'],
+                                        float(group['lr']), float(b1), float(b2), float(group['eps']),
+                                        float(group['weight_decay']), step, int(plan['ams']),
+                                        torch.cuda.current_stream(dev).cuda_stream))
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -26,10 +52,24 @@ class Adam(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         L = _lib.lib()
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ams = bool(group['amsgrad'])
+            params = group['params']
+            plan = self._plans.get(gi)
+            # fast path: the same parameters as last step carry gradients (and only those), one common step count -> reuse
+            # the pointer tables; only the step counters and the gradient pointers are touched
+            if plan is not None and plan['ams'] == ams and plan['n_group'] == len(params) and plan['p0'] == params[0].data_ptr():
+                all_grads = [p.grad for p in params]
+                grads = [all_grads[i] for i in plan['idx']]
+                if all(g is not None for g in grads) and sum(g is not None for g in all_grads) == plan['n']:
+                    step = plan['step'] = plan['step'] + 1
+                    for st in plan['states']:
+                        st['step'] = step
+                    self._launch(L, group, plan, grads, step)
+                    continue
+            self._plans.pop(gi, None)
             by_step = {}
-            for p in group['params']:
+            for i, p in enumerate(params):
                 if p.grad is None:
                     continue
                 if p.grad.is_sparse:
@@ -41,28 +81,15 @@ class Adam(Optimizer):
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p)
                     st['exp_avg_sq'] = torch.zeros_like(p)
-                    if ams:
-                        st['max_exp_avg_sq'] = torch.zeros_like(p)
+                if ams and 'max_exp_avg_sq' not in st:
+                    st['max_exp_avg_sq'] = torch.zeros_like(p)
                 st['step'] += 1
-                by_step.setdefault((int(st['step']), p.device), []).append(p)
-            for (step, dev), plist in by_step.items():
-                n = len(plist)
-                arr = ctypes.c_void_p * n
-                # parameter / state pointers are stable across steps: cache the tables, refresh only the gradients
-                key = (id(group), step > 1, dev, n, plist[0].data_ptr(), plist[-1].data_ptr(), ams)
-                tabs = self._tables.get(key)
-                if tabs is None:
-                    sts = [self.state[p] for p in plist]
-                    ptr = lambda ts: arr(*[t.data_ptr() for t in ts])
-                    tabs = (ptr(plist), ptr([s['exp_avg'] for s in sts]), ptr([s['exp_avg_sq'] for s in sts]),
-                            ptr([s['max_exp_avg_sq'] for s in sts]) if ams else None,
-                            (ctypes.c_size_t * n)(*[p.numel() for p in plist]))
-                    self._tables = {key: tabs} if len(self._tables) > 8 else {**self._tables, key: tabs}
-                grads = [p.grad if p.grad.is_contiguous() else p.grad.contiguous() for p in plist]
-                gptr = arr(*[t.data_ptr() for t in grads])
-                b1, b2 = group['betas']
-                with torch.cuda.device(dev):
-                    _lib.check(L.gwtf_adam_step(tabs[0], gptr, tabs[1], tabs[2], tabs[3], tabs[4], n, float(group['lr']),
-                                                float(b1), float(b2), float(group['eps']), float(group['weight_decay']), step,
-                                                int(ams), torch.cuda.current_stream(dev).cuda_stream))
+                by_step.setdefault((int(st['step']), p.device), []).append(i)
+            for (step, dev), idx in by_step.items():
+                plist = [params[i] for i in idx]
+                plan = self._make_plan(plist, dev, step, ams)
+                plan['idx'], plan['n_group'], plan['p0'] = idx, len(params), params[0].data_ptr()
+                self._launch(L, group, plan, [p.grad for p in plist], step)
+                if len(by_step) == 1:
+                    self._plans[gi] = plan
         return loss
