@@ -38,13 +38,15 @@ _SIGNATURES = {
     'gwtf_train_apply': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_train_forward': (ctypes.c_int, [_c_fp] * 14 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_pack_w1t': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_train_coupling_backward': (ctypes.c_int, [_c_fp] * 22 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_train_coupling_backward': (ctypes.c_int, [_c_fp] * 21 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_packed_b_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_pack_folded': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
-    'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 4 + [_c_fp]),
-    'gwtf_dw1_workspace_floats': (ctypes.c_size_t, [ctypes.c_int]),
-    'gwtf_dw1_gemm': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 11 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 4 + [_c_fp]),
+    'gwtf_dw1_partials': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    'gwtf_dw1_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'gwtf_dw1_reduce_scratch_floats': (ctypes.c_size_t, [ctypes.c_int]),
+    'gwtf_dw1_reduce': (ctypes.c_int, [_c_fp, ctypes.c_int, _c_fp, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_mixture_nll': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_mixture_nll_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_adam_step': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_double,
@@ -190,16 +192,20 @@ def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segment
     return out, logdet
 
 
-def dw1_gemm(dA, H0, f, out=None, branch_stride=None):
-    """(2,FP,M) x (2,FP,M)^T -> (2,f,f): the sd1 weight gradient (csrc/gwtf_bwd.hip, deterministic split-K MFMA GEMM).
-    With ``branch_stride`` the two (f,f) blocks go to out + br*branch_stride (in-place into a gradient record)."""
+def dw1_workspace(f, B, N, device, passes=1):
+    """Workspace for the per-workgroup dW1 partials of `passes` backward passes over B x N points (csrc/gwtf_bwd.hip)."""
     L = lib()
-    M = dA.shape[2]
-    ws = torch.empty(L.gwtf_dw1_workspace_floats(f), device=dA.device, dtype=torch.float32)
+    return torch.empty(passes * L.gwtf_dw1_workspace_floats(f, B, N) + L.gwtf_dw1_reduce_scratch_floats(f), device=device,
+                       dtype=torch.float32)
+
+
+def dw1_reduce(ws, passes, f, B, N, out=None, branch_stride=None):
+    """Sum the partials -> (2,f,f) sd1 weight gradient (deterministic).  With ``branch_stride`` the two (f,f) blocks go to
+    out + br*branch_stride (in place into a gradient record)."""
     if out is None:
-        out = torch.empty(2, f, f, device=dA.device, dtype=torch.float32)
-    check(L.gwtf_dw1_gemm(_ptr(dA, 'dA'), _ptr(H0, 'H0'), ws.data_ptr(), out.data_ptr(),
-                          f * f if branch_stride is None else branch_stride, f, M, _stream(dA)))
+        out = torch.empty(2, f, f, device=ws.device, dtype=torch.float32)
+    check(lib().gwtf_dw1_reduce(_ptr(ws, 'dw1_ws'), passes, out.data_ptr(), f * f if branch_stride is None else branch_stride,
+                                f, B, N, _stream(ws)))
     return out
 
 

@@ -121,8 +121,7 @@ class StackDensityFn(torch.autograd.Function):
         g_film = torch.zeros(B, C, 2, 3, FP, device=dev, dtype=torch.float32)
         g_sd0 = torch.zeros(C, R, 2, 3, FP, device=dev, dtype=torch.float32)
         g_bias = torch.zeros(C, R, 4, device=dev, dtype=torch.float32)
-        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
-        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        ws = _lib.dw1_workspace(f, B, N, dev)            # per-workgroup dW1 partials of one backward pass
         gW1p = torch.empty(C, 2, f, f, device=dev, dtype=torch.float32)
         bufs = [torch.empty_like(p), torch.empty_like(p)]
         st = _lib._stream(p)
@@ -135,11 +134,11 @@ class StackDensityFn(torch.autograd.Function):
                 nxt = bufs[c & 1]
                 _lib.check(L.gwtf_coupling_backward(x_in.data_ptr(), cur.data_ptr(), g_ld.data_ptr(),
                                                     pw[c * PW:].data_ptr(), pb[c * PB:].data_ptr(), rec.data_ptr(),
-                                                    nxt.data_ptr(), dA.data_ptr(), H0.data_ptr(), g_film.data_ptr(),
+                                                    nxt.data_ptr(), ws.data_ptr(), g_film.data_ptr(),
                                                     g_sd0[c].data_ptr(), g_bias[c].data_ptr(), c, B, N, C, f, pattern0,
                                                     float(eps), _lib._MODES[mode], st))
-                # dW1p[k][j][i] = sum_{b,n} dacc[k,j,(b,n)] h[k,i,(b,n)]: one skinny GEMM with K = B*N (split-K MFMA kernel)
-                _lib.dw1_gemm(dA, H0, f, out=gW1p[c])
+                # dW1p[k][j][i] = sum_{b,n} dacc[k,j,(b,n)] h[k,i,(b,n)]: accumulated inside the kernel, summed here
+                _lib.dw1_reduce(ws, 1, f, B, N, out=gW1p[c])
                 cur = nxt
         gs = g_sd0.sum(1)                                              # (C,2,3,FP)
         g_W0f = gs[:, :, 0:2, :f].permute(0, 1, 3, 2).contiguous()    # (C,2,f,2)
@@ -232,13 +231,12 @@ class StatsFn(torch.autograd.Function):
         gst[:, 0, :f] = gS[:, :, 0]
         gst[:, 1, :f] = gS[:, :, 1]
         g_x = torch.empty_like(x)
-        dA = torch.zeros(2, FP, B * N, device=dev, dtype=torch.float32)     # the kernel accumulates into it
-        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        ws = _lib.dw1_workspace(f, B, N, dev)
         g_sd0 = torch.zeros(_lib.STAT_REPLICAS, 2, 3, FP, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             _lib.check(L.gwtf_stats_backward(x.data_ptr(), gst.data_ptr(), pw.data_ptr(), pb.data_ptr(), g_x.data_ptr(),
-                                             dA.data_ptr(), H0.data_ptr(), g_sd0.data_ptr(), B, N, f, pat, _lib._stream(x)))
-        gW1 = _lib.dw1_gemm(dA, H0, f)
+                                             ws.data_ptr(), g_sd0.data_ptr(), B, N, f, pat, _lib._stream(x)))
+        gW1 = _lib.dw1_reduce(ws, 1, f, B, N)
         gs = g_sd0.sum(0)
         return g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1, None, None, None, None
 
@@ -272,14 +270,13 @@ class ApplyFn(torch.autograd.Function):
         g_film = torch.zeros(B, 1, 2, 3, FP, device=dev, dtype=torch.float32)
         g_sd0 = torch.zeros(R, 2, 3, FP, device=dev, dtype=torch.float32)
         g_bias = torch.zeros(R, 4, device=dev, dtype=torch.float32)
-        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
-        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        ws = _lib.dw1_workspace(f, B, N, dev)
         with torch.cuda.device(dev):
             _lib.check(L.gwtf_coupling_backward(x.data_ptr(), g_out.data_ptr(), g_lv.data_ptr(), pw.data_ptr(), pb.data_ptr(),
-                                                rec.data_ptr(), g_x.data_ptr(), dA.data_ptr(), H0.data_ptr(),
+                                                rec.data_ptr(), g_x.data_ptr(), ws.data_ptr(),
                                                 g_film.data_ptr(), g_sd0.data_ptr(), g_bias.data_ptr(), 0, B, N, 1, f, pat,
                                                 float(eps), _lib._MODES[mode], _lib._stream(x)))
-        gW1 = _lib.dw1_gemm(dA, H0, f)
+        gW1 = _lib.dw1_reduce(ws, 1, f, B, N)
         gs = g_sd0.sum(0)
         return (g_x, gs[:, 0:2, :f].permute(0, 2, 1).contiguous(), gs[:, 2, :f].contiguous(), gW1,
                 g_film[:, 0, :, 0, :f].contiguous(), g_film[:, 0, :, 1:3, :f].contiguous(), g_bias.sum(0).reshape(2, 2),
@@ -499,8 +496,7 @@ class TrainStackFn(torch.autograd.Function):
         g_bias = torch.zeros(C, R * 4, device=dev, dtype=torch.float32)
         g_stats = torch.empty(C, 2 * 2 * FP, device=dev, dtype=torch.float32)
         g_mom = torch.empty(C, 16, device=dev, dtype=torch.float32)
-        dA = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
-        H0 = torch.empty(2, FP, B * N, device=dev, dtype=torch.float32)
+        ws = _lib.dw1_workspace(f, B, N, dev, passes=2)      # dW1 partials of the coupling and the statistics pass
         gxa, gxb = torch.empty_like(p), torch.empty_like(p)
         bufs = [torch.empty_like(p), torch.empty_like(p)]
         st = _lib._stream(p)
@@ -510,10 +506,8 @@ class TrainStackFn(torch.autograd.Function):
         a_gsd0, a_gbias, a_gstats, a_gmom = P(g_sd0), P(g_bias), P(g_stats), P(g_mom)
         a_ps, a_p, ps_stride = P(ps), P(p), ps[0].numel() * 4
         a_cur, a_gld, a_bufs = P(cur), P(g_ld), (P(bufs[0]), P(bufs[1]))
-        a_frec, a_fraw, a_gxa, a_gxb, a_dA, a_H0, a_gfilm, a_gfraw = (P(film_rec), P(film_raw), P(gxa), P(gxb), P(dA), P(H0),
+        a_frec, a_fraw, a_gxa, a_gxb, a_ws, _unused, a_gfilm, a_gfraw = (P(film_rec), P(film_raw), P(gxa), P(gxb), P(ws), 0,
                                                                       P(g_film), P(g_film_raw))
-        ws = torch.empty(L.gwtf_dw1_workspace_floats(f), device=dev, dtype=torch.float32)
-        a_ws, M = P(ws), B * N
         eps_f, mode_i = float(eps), _lib._MODES[mode]
         with torch.cuda.device(dev):
             for c in (range(C) if inverse else range(C - 1, -1, -1)):   # reverse of the forward's processing order
@@ -526,11 +520,9 @@ class TrainStackFn(torch.autograd.Function):
                 g_raw_c = a_graw + c * RC * 4
                 _lib.check(L.gwtf_train_coupling_backward(
                     x_in, a_cur, a_gld, a_raw + c * RC * 4, a_pw + c * PW * 4, a_pb + c * PB * 4, a_frec, a_fraw,
-                    a_mom + step * R * 16 * 4, a_ys + c * R * 2 * FP * 2 * 4, nxt, a_gxa, a_gxb, a_dA, a_H0, a_gfilm,
+                    a_mom + step * R * 16 * 4, a_ys + c * R * 2 * FP * 2 * 4, nxt, a_gxa, a_gxb, a_ws, a_gfilm,
                     a_gsd0 + c * R * 2 * 3 * FP * 4, a_gbias + c * R * 4 * 4, a_gstats + c * 2 * 2 * FP * 4, a_gmom + c * 16 * 4,
                     a_gfraw, g_raw_c, c, B, N, C, f, G, pattern0, eps_f, mode_i, st))
-                # dW1 (2,f,f): one skinny GEMM with K = B*N, written at GwtfRaw::sd1_w of both branch records
-                _lib.check(L.gwtf_dw1_gemm(a_dA, a_H0, a_ws, g_raw_c + 6 * f * 4, br_size, f, M, st))
                 a_cur = nxt
         cur = bufs[(C - 1) & 1] if inverse else bufs[0]          # written by the last coupling processed
         return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None, None

@@ -13,9 +13,14 @@
 //     dpre = dh[pre>0]   dxk = W0f^T dpre   dx_w = g_out_w / s
 // Reductions over points (per-shape FiLM record grads dc, du_w; sd0 grads; sd2 bias grads) are done in-lane over
 // the point blocks, by shuffles over the 16 lanes of a quarter, in LDS over the 4 waves, then one atomic per value
-// and workgroup.  The f x f weight gradient dW1p = sum_p dacc(p) h(p)^T is a plain GEMM over all points: dacc and h
-// are written out ([2][FP][B][N]: the contraction index (shape, point) is contiguous) and contracted by ONE batched
-// library GEMM with K = B*N on the host side.
+// and workgroup.  The f x f weight gradient dW1p = sum_p dacc(p) h(p)^T contracts over POINTS, which sit on the lanes
+// (MFMA N axis) everywhere else in this kernel.  dacc (already split into f16 hi/lo for the dh product) is transposed
+// through LDS -- one [FP][points of the workgroup] image aliased onto the forward-weight buffer, dead by then -- and read
+// back as the A operand (rows = dacc features, k-slots = points); h = relu(W0f x + c0f) is simply RECOMPUTED in B-operand
+// layout (a lane = one h feature x 8 points: 3 weights, 16 coordinates from a 1-KiB LDS table), so only one matrix is
+// transposed.  Each wavefront owns one column of 16x16 output tiles over ALL points of the workgroup (no cross-wave
+// reduction), and writes it to a per-workgroup partial that gwtf_dw1_reduce sums in a fixed order: nothing of size
+// O(B N f) is written to HBM any more (it was 100-150 MB per coupling).
 #include "gwtf_device.h"
 
 namespace {
@@ -37,8 +42,8 @@ template <int MB, int NB, bool STATS>
 __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
-                                                  float* __restrict__ g_in, float* __restrict__ dA_mat,
-                                                  float* __restrict__ h0_mat, float* __restrict__ g_film,
+                                                  float* __restrict__ g_in, float* __restrict__ dw1_ws,
+                                                  float* __restrict__ g_film,
                                                   float* __restrict__ g_sd0, float* __restrict__ g_bias,
                                                   const float* __restrict__ g_stats, int B, int N, int C, int c, int pat,
                                                   float eps, int kk_steps, int f, int mode) {
@@ -47,6 +52,14 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
   constexpr int FP = K::FP;
   __shared__ __align__(16) float lds[K::PW + K::FSP + KB::PB];
   __shared__ float s_film[2][3][FP], s_sd0[2][3][FP], s_bias[4];
+  // dW1 machinery: coordinates of the workgroup's points, per-wave |dacc| maxima, the transposed dacc image
+  constexpr int PTS = 64 * NB;                      // points per workgroup
+  constexpr int XPITCH = 2 * PTS + 8;               // bytes per feature row (+8: rows land 8 B apart in the banks)
+  constexpr int XBYTES = 2 * FP * XPITCH;           // hi image | lo image
+  constexpr bool XALIAS = XBYTES <= K::PW * 4;      // fits over the forward weights (dead after the forward recompute)
+  __shared__ float2 s_pts[PTS];
+  __shared__ float s_amax[2][4];
+  __shared__ __align__(16) unsigned char s_xt_own[XALIAS ? 16 : XBYTES];
   for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
     (&s_film[0][0][0])[t] = 0.f;
     (&s_sd0[0][0][0])[t] = 0.f;
@@ -101,6 +114,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     xa[nb] = __shfl(sel3(xo[0], xo[1], xo[2], k0), 16 * nb + i16);
     xb[nb] = keep2 ? __shfl(sel3(xo[0], xo[1], xo[2], k1), 16 * nb + i16) : 0.f;
   }
+  if (q < NB) s_pts[wave * 16 * NB + 16 * q + i16] = make_float2(sel3(xo[0], xo[1], xo[2], k0), keep2 ? sel3(xo[0], xo[1], xo[2], k1) : 0.f);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const float* L = lds;
@@ -216,8 +230,6 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
             const int n = n_wave0 + 16 * nb + i16;
             const float da = n < N ? fmaf(gq2, acc[br][m][nb][r], gs) : 0.f;
             acc[br][m][nb][r] = da;
-            // the statistics path shares h with the coupling path: dW1 = (dacc_apply + dacc_stats) h^T -> accumulate
-            if (n < N) dA_mat[(((size_t)br * FP + ft) * B + b) * N + n] += da;
           }
           continue;
         }
@@ -231,8 +243,6 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
           const float da = a > 0.f ? fmaf(u0[r], d0[nb], u1[r] * d1[nb]) : 0.f;
           sdc += da;
           acc[br][m][nb][r] = da;
-          const int n = n_wave0 + 16 * nb + i16;
-          if (n < N) dA_mat[(((size_t)br * FP + ft) * B + b) * N + n] = da;
         }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) {
@@ -248,8 +258,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
       }
     }
     // dh[16mi + 4q + r][point] = sum_j W1p[j][16mi + ..] dacc[j][point] on the f16 MFMA with the three-product split.
-    // Gradients have no natural scale (a 1/(B N) loss normalisation puts them near the f16 subnormals), so the wave
-    // rescales dacc by a power of two that brings its largest magnitude to [2^8, 2^9) and undoes it on dh: exact.
+    // Gradients have no natural scale (a 1/(B N) loss normalisation puts them near the f16 subnormals), so the WORKGROUP
+    // rescales dacc by a power of two that brings its largest magnitude to [2^8, 2^9) and undoes it on dh and dW1: exact.
+    // (One scale per workgroup, not per wave: the dW1 product below mixes the waves' points on its K axis.)
     float amax = 0.f;
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -259,6 +270,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
         for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(acc[br][m][nb][r]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) s_amax[br][wave] = amax;
+    __syncthreads();   // also: every wave is past its forward recompute (branch 0) / past reading the previous X image (branch 1)
+    amax = fmaxf(fmaxf(s_amax[br][0], s_amax[br][1]), fmaxf(s_amax[br][2], s_amax[br][3]));
     const int ebits = (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, amax)) >> 23) & 0xff;
     const bool rescale = ebits >= 16 && ebits <= 240;
     const float up = rescale ? __builtin_bit_cast(float, (262 - ebits) << 23) : 1.0f;     // 2^(8 - (ebits - 127))
@@ -314,8 +328,6 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
         for (int nb = 0; nb < NB; ++nb) {
           const float pre = fmaf(sp[0], xa[nb], fmaf(sp[1], xb[nb], sp[2]));
           const float dp = pre > 0.f ? dh[nb][r] : 0.f;
-          const int n = n_wave0 + 16 * nb + i16;
-          if (h0_mat && n < N) h0_mat[(((size_t)br * FP + fi) * B + b) * N + n] = fmaxf(pre, 0.f);
           pxa[nb] = fmaf(sp[0], dp, pxa[nb]);
           pxb[nb] = fmaf(sp[1], dp, pxb[nb]);
           g0 = fmaf(dp, xa[nb], g0);
@@ -337,6 +349,66 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     }
     dxa_own += quarter_reduce<NB>(pxa, q);
     dxb_own += quarter_reduce<NB>(pxb, q);
+
+    // ---- dW1[br] partial of this workgroup: X = scaled dacc (hi/lo), transposed through LDS; H recomputed --------------
+    {
+      unsigned char* xt = XALIAS ? reinterpret_cast<unsigned char*>(lds) : s_xt_own;
+      const int col = (wave * 16 * NB + i16) * 2;
+#pragma unroll
+      for (int ks = 0; ks < KB::KS; ++ks)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int m = 2 * ks + (e >> 2);
+            if (m < MB) {
+              unsigned char* dst = xt + (16 * m + 4 * q + (e & 3)) * XPITCH + col + 32 * nb;
+              *reinterpret_cast<_Float16*>(dst) = dhi[ks][nb][e];
+              *reinterpret_cast<_Float16*>(dst + FP * XPITCH) = dlo[ks][nb][e];
+            }
+          }
+      __syncthreads();
+      if (wave < MB) {
+        const int ni = wave;                                  // this wave's column of output tiles: h features 16 ni ..
+        const f32x4 sp = sd0n[16 * ni + i16];                 // the lane's h feature: {w0a, w0b, c0, -}
+        f32x4 dw[MB];
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi) dw[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2 * NB; ++s) {                     // k-steps of 32 points
+          const float4* pp = reinterpret_cast<const float4*>(&s_pts[32 * s + 8 * q]);
+          f16x8 hhi, hlo;
+#pragma unroll
+          for (int e2 = 0; e2 < 4; ++e2) {
+            const float4 two = pp[e2];                         // points 32 s + 8 q + 2 e2, + 1: (xa, xb) each
+            f32x2 h = {fmaxf(fmaf(sp[0], two.x, fmaf(sp[1], two.y, sp[2])), 0.f),
+                       fmaxf(fmaf(sp[0], two.z, fmaf(sp[1], two.w, sp[2])), 0.f)};
+            f16x2 hh, hl;
+            split_pair(h, hh, hl);
+            hhi[2 * e2] = hh[0]; hhi[2 * e2 + 1] = hh[1];
+            hlo[2 * e2] = hl[0]; hlo[2 * e2 + 1] = hl[1];
+          }
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) {
+            const unsigned char* src = xt + (16 * mi + i16) * XPITCH + 64 * s + 16 * q;
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            const f16x4 a0 = *reinterpret_cast<const f16x4*>(src), a1 = *reinterpret_cast<const f16x4*>(src + 8);
+            const f16x4 b0 = *reinterpret_cast<const f16x4*>(src + FP * XPITCH), b1 = *reinterpret_cast<const f16x4*>(src + FP * XPITCH + 8);
+            const f16x8 xhi = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            const f16x8 xlo = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+            dw[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xhi, hhi, dw[mi], 0, 0, 0);
+            dw[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xhi, hlo, dw[mi], 0, 0, 0);
+            dw[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xlo, hhi, dw[mi], 0, 0, 0);
+          }
+        }
+        // C layout: lane (col = h feature 16 ni + i16, q) holds rows = dacc features 16 mi + 4 q + r
+        float* out = dw1_ws + ((size_t)blockIdx.x * 2 + br) * FP * FP;
+#pragma unroll
+        for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) out[(16 * mi + 4 * q + r) * FP + 16 * ni + i16] = dw[mi][r] * down;
+      }
+    }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -421,11 +493,11 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
 
 template <int MB, bool STATS>
 int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
-               const float* film, float* g_in, float* dA, float* h0, float* g_film, float* g_sd0, float* g_bias,
+               const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0, float* g_bias,
                const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, int mode, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg))), block(256);
-#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dA, h0, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode)
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B
   return (int)hipGetLastError();
@@ -446,14 +518,20 @@ extern "C" int gwtf_pack_folded(const float* W1p, const float* W0f, const float*
   return (int)hipGetLastError();
 }
 
+static int bwd_points_per_wg(int B, int N) { return (long)B * N >= 2048L * 32 ? 128 : 64; }
+static int bwd_grid(int B, int N) {
+  const int pts = bwd_points_per_wg(B, N);
+  return B * ((N + pts - 1) / pts);
+}
+
 static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
-                        const float* packed_b_c, const float* film, float* g_in, float* dA_mat, float* h0_mat,
-                        float* g_film, float* g_sd0, float* g_bias, const float* g_stats, int c, int B, int N, int C, int f,
-                        int pat, float eps, int mode, void* stream) {
+                        const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0,
+                        float* g_bias, const float* g_stats, int c, int B, int N, int C, int f, int pat, float eps, int mode,
+                        void* stream) {
   const int kk_steps = (f + 3) / 4;
-  const int nb = (long)B * N >= 2048L * 32 ? 2 : 1;
+  const int nb = bwd_points_per_wg(B, N) / 64;
   hipStream_t st = (hipStream_t)stream;
-#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, st
+#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, st
   switch (gwtf_padded_width(f) / 16) {
     case 1: return stats ? launch_bwd<1, true>(nb, GWTF_A) : launch_bwd<1, false>(nb, GWTF_A);
     case 2: return stats ? launch_bwd<2, true>(nb, GWTF_A) : launch_bwd<2, false>(nb, GWTF_A);
@@ -465,142 +543,96 @@ static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const
 }
 
 extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
-                                      const float* packed_b_c, const float* film, float* g_in, float* dA_mat,
-                                      float* h0_mat, float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C,
-                                      int f, int pattern0, float eps, int mode, void* stream) {
-  if (!x_in || !g_out || !g_ld || !packed_w_c || !packed_b_c || !film || !g_in || !dA_mat || !h0_mat || !g_film || !g_sd0 ||
+                                      const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
+                                      float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0, float eps,
+                                      int mode, void* stream) {
+  if (!x_in || !g_out || !g_ld || !packed_w_c || !packed_b_c || !film || !g_in || !dw1_ws || !g_film || !g_sd0 ||
       !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5 ||
       (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE))
     return GWTF_E_BADARG;
-  return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dA_mat, h0_mat, g_film, g_sd0, g_bias,
-                      nullptr, c, B, N, C, f, (pattern0 + c) % 6, eps, mode, stream);
+  return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
+                      B, N, C, f, (pattern0 + c) % 6, eps, mode, stream);
 }
 
 extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c,
-                                   const float* packed_b_c, float* g_in, float* dA_mat, float* h0_mat, float* g_sd0, int B,
-                                   int N, int f, int pattern, void* stream) {
-  if (!x_in || !g_stats || !packed_w_c || !packed_b_c || !g_in || !dA_mat || !g_sd0 || B <= 0 || N <= 0 ||
-      f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5)
+                                   const float* packed_b_c, float* g_in, float* dw1_ws, float* g_sd0, int B, int N, int f,
+                                   int pattern, void* stream) {
+  if (!x_in || !g_stats || !packed_w_c || !packed_b_c || !g_in || !dw1_ws || !g_sd0 || B <= 0 || N <= 0 || f <= 0 ||
+      f > GWTF_MAX_FP || pattern < 0 || pattern > 5)
     return GWTF_E_BADARG;
-  return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dA_mat, h0_mat,
+  return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dw1_ws,
                       g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// dW1[br] = dA[br] h0[br]^T : (FP x M) . (M x FP) with M = B*N points on the contraction axis -- a skinny GEMM (48 x 48
-// output, K = 131072) that library GEMMs serve badly (rocBLAS picks a 16x16x256 macro tile: 94 us).  Split-K over
-// (chunks x 2 branches) workgroups on v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate); a lane's float4 of
-// four consecutive points feeds four successive MFMAs (k-slot (kq, s) <-> point p0 + 4 kq + s for BOTH operands, so the
-// sum covers every point once).  Per-workgroup partials go to a workspace and a second kernel sums them in a fixed
-// order: deterministic, no atomics.
+// dW1[br][j][i] = sum over the per-workgroup partials the backward kernels leave in the workspace ([partial][2][FP][FP],
+// `passes` consecutive regions of gwtf_dw1_partials(B, N) partials each: coupling path [+ statistics path]); fixed
+// summation order -> deterministic.  64 outputs per workgroup x 4 slices of the partial axis, combined through LDS.
 namespace {
-constexpr int kDw1Chunks = 128;
+constexpr int kDw1Stage = 64;    // stage 1 folds the partials into this many sums (fixed partition -> deterministic)
 
-template <int MB>
-__global__ __launch_bounds__(256) void dw1_partial_kernel(const float* __restrict__ dA, const float* __restrict__ h0,
-                                                          float* __restrict__ ws, int M) {
-  constexpr int FP = 16 * MB;
-  __shared__ float red[4][MB * MB * 256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, row = lane & 15, kq = lane >> 4;
-  const int br = blockIdx.y;
-  const float* A = dA + (size_t)br * FP * M;
-  const float* Hm = h0 + (size_t)br * FP * M;
-  f32x4 acc[MB][MB];
+// stage 1: grid (element tiles of 256, kDw1Stage); out[chunk][e] = sum over the chunk's partials of ws[p][e], e over the
+// whole [2][FP][FP] record (coalesced); thousands of workgroups stream the workspace at HBM rate
+__global__ __launch_bounds__(256) void dw1_fold_kernel(const float* __restrict__ ws, int n_partials, float* __restrict__ mid,
+                                                       int rec) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= rec) return;
+  const int per = (n_partials + kDw1Stage - 1) / kDw1Stage;
+  const int p0 = blockIdx.y * per, p1 = min(n_partials, p0 + per);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int p = p0;
+  for (; p + 3 < p1; p += 4)
 #pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int steps = (M + 15) / 16;
-  const int per = (steps + kDw1Chunks - 1) / kDw1Chunks;
-  const int s_begin = blockIdx.x * per, s_end = min(steps, s_begin + per);
-  const bool vec_ok = (M & 3) == 0;
-  for (int s = s_begin + wave; s < s_end; s += 4) {
-    const int p = s * 16 + 4 * kq;
-    float4 a[MB], b[MB];
-    if (vec_ok && p + 4 <= M) {
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        a[i] = *reinterpret_cast<const float4*>(A + (size_t)(16 * i + row) * M + p);
-        b[i] = *reinterpret_cast<const float4*>(Hm + (size_t)(16 * i + row) * M + p);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < MB; ++i) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          av[e] = p + e < M ? A[(size_t)(16 * i + row) * M + p + e] : 0.f;
-          bv[e] = p + e < M ? Hm[(size_t)(16 * i + row) * M + p + e] : 0.f;
-        }
-        a[i] = make_float4(av[0], av[1], av[2], av[3]);
-        b[i] = make_float4(bv[0], bv[1], bv[2], bv[3]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-      for (int j = 0; j < MB; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-      }
-  }
-  // C layout: lane (col = row of the B operand = h0 feature j, q = kq) holds rows 4q..4q+3 (dA features) of tile (i, j)
-#pragma unroll
-  for (int i = 0; i < MB; ++i)
-#pragma unroll
-    for (int j = 0; j < MB; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) red[wave][((i * MB + j) * 4 + r) * 64 + lane] = acc[i][j][r];
-  __syncthreads();
-  float* out = ws + ((size_t)blockIdx.x * 2 + br) * FP * FP;
-  for (int t = threadIdx.x; t < MB * MB * 256; t += 256) {
-    const float v = (red[0][t] + red[1][t]) + (red[2][t] + red[3][t]);
-    const int ln = t & 63, r = (t >> 6) & 3, tile = t >> 8, i = tile / MB, j = tile % MB;
-    out[(size_t)(16 * i + 4 * (ln >> 4) + r) * FP + 16 * j + (ln & 15)] = v;
-  }
+    for (int u = 0; u < 4; ++u) s[u] += ws[(size_t)(p + u) * rec + e];
+  for (; p < p1; ++p) s[0] += ws[(size_t)p * rec + e];
+  mid[(size_t)blockIdx.y * rec + e] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
-// 64 outputs per workgroup x 4 slices of the chunk axis, LDS-combined: fixed summation order
-__global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int FP, int f,
+// stage 2: 64 outputs per workgroup x 4 slices of the kDw1Stage sums, combined through LDS; crops FP -> f
+__global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict__ mid, float* __restrict__ out, int FP, int f,
                                                          size_t branch_stride) {
   __shared__ float part[4][64];
   const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + e;
   const bool on = t < 2 * f * f;
-  const int br = on ? t / (f * f) : 0, i = on ? (t / f) % f : 0, j = on ? t % f : 0;
+  const int br = on ? t / (f * f) : 0, j = on ? (t / f) % f : 0, i = on ? t % f : 0;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (on) {
+    const float* src = mid + (size_t)br * FP * FP + (size_t)j * FP + i;
+    const size_t stride = (size_t)2 * FP * FP;
 #pragma unroll
-    for (int c = sl * (kDw1Chunks / 4); c < (sl + 1) * (kDw1Chunks / 4); c += 4)
+    for (int c = sl * (kDw1Stage / 4); c < (sl + 1) * (kDw1Stage / 4); c += 4)
 #pragma unroll
-      for (int u = 0; u < 4; ++u) s[u] += ws[((size_t)(c + u) * 2 + br) * FP * FP + (size_t)i * FP + j];
+      for (int u = 0; u < 4; ++u) s[u] += src[(size_t)(c + u) * stride];
   }
   part[sl][e] = (s[0] + s[1]) + (s[2] + s[3]);
   __syncthreads();
-  if (sl == 0 && on) out[(size_t)br * branch_stride + (size_t)i * f + j] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  if (sl == 0 && on) out[(size_t)br * branch_stride + (size_t)j * f + i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
 }
 }  // namespace
 
-extern "C" size_t gwtf_dw1_workspace_floats(int f) {
+extern "C" int gwtf_dw1_partials(int B, int N) { return (B > 0 && N > 0) ? bwd_grid(B, N) : 0; }
+
+extern "C" size_t gwtf_dw1_workspace_floats(int f, int B, int N) {
   const size_t FP = gwtf_padded_width(f);
-  return (size_t)kDw1Chunks * 2 * FP * FP;
+  return (size_t)gwtf_dw1_partials(B, N) * 2 * FP * FP;
 }
 
-extern "C" int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* workspace, float* dW1, size_t branch_stride, int f,
-                             int M, void* stream) {
-  if (!dA_mat || !h0_mat || !workspace || !dW1 || f <= 0 || f > GWTF_MAX_FP || M <= 0 || branch_stride < (size_t)f * f)
+// `workspace`: `passes` regions written by the backward kernels, followed by kDw1Stage records of scratch for the first
+// reduction stage (gwtf_dw1_reduce_scratch_floats(f) floats after the last region).
+extern "C" size_t gwtf_dw1_reduce_scratch_floats(int f) {
+  const size_t FP = gwtf_padded_width(f);
+  return (size_t)kDw1Stage * 2 * FP * FP;
+}
+
+extern "C" int gwtf_dw1_reduce(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N,
+                               void* stream) {
+  if (!workspace || !dW1 || passes < 1 || f <= 0 || f > GWTF_MAX_FP || B <= 0 || N <= 0 || branch_stride < (size_t)f * f)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  const int FP = gwtf_padded_width(f);
-  const dim3 grid(kDw1Chunks, 2), block(256);
-  switch (FP / 16) {
-    case 1: hipLaunchKernelGGL(dw1_partial_kernel<1>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
-    case 2: hipLaunchKernelGGL(dw1_partial_kernel<2>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
-    case 3: hipLaunchKernelGGL(dw1_partial_kernel<3>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
-    default: hipLaunchKernelGGL(dw1_partial_kernel<4>, grid, block, 0, st, dA_mat, h0_mat, workspace, M); break;
-  }
-  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 63) / 64), block, 0, st, workspace, dW1, FP, f, branch_stride);
+  const int FP = gwtf_padded_width(f), rec = 2 * FP * FP, n_partials = passes * bwd_grid(B, N);
+  float* mid = workspace + (size_t)n_partials * rec;
+  hipLaunchKernelGGL(dw1_fold_kernel, dim3((rec + 255) / 256, kDw1Stage), dim3(256), 0, st, workspace, n_partials, mid, rec);
+  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 63) / 64), dim3(256), 0, st, mid, dW1, FP, f, branch_stride);
   return (int)hipGetLastError();
 }

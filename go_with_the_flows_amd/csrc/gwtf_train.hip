@@ -419,35 +419,37 @@ extern "C" int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, in
 }
 
 // Backward of one coupling of the train-mode pipeline (single rank): coupling path, fold1, statistics path, fold0,
-// moments path, in five launches.  dA_mat holds dacc_apply + dacc_stats afterwards (dW1 = dA_mat h0_mat^T is the
-// caller's GEMM).  Workspaces g_sd0 [64][2][3][FP], g_bias [64][4] must be zero on entry; g_film [B][C][2][3][FP] is
-// accumulated for coupling c only (zero on entry).  g_raw_c receives dW0, dgamma0, dbeta0, dW2, db2 (other entries of the
-// record are left untouched).
+// moments path, dW1 reduction.  dw1_ws: 2 * gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f) floats (the two backward
+// passes leave their per-workgroup dW1 partials in consecutive regions; both are summed into g_raw_c's sd1 blocks).
+// Workspaces g_sd0 [64][2][3][FP], g_bias [64][4] must be zero on entry; g_film [B][C][2][3][FP] is accumulated for
+// coupling c only (zero on entry).  g_raw_c receives dW0, dgamma0, dbeta0, dW1, dW2, db2 (other entries of the record are
+// left untouched).
 extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* raw_c,
                                             const float* packed_w_c, const float* packed_b_c, const float* film_rec,
                                             const float* film_raw, const float* moments_c, const float* ystats_c,
-                                            float* g_in, float* g_xa, float* g_xb, float* dA_mat, float* h0_mat,
-                                            float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom,
-                                            float* g_film_raw, float* g_raw_c, int c, int B, int N, int C, int f, int G,
-                                            int pattern0, float eps, int mode, void* stream) {
+                                            float* g_in, float* g_xa, float* g_xb, float* dw1_ws, float* g_film, float* g_sd0,
+                                            float* g_bias, float* g_stats, float* g_mom, float* g_film_raw, float* g_raw_c,
+                                            int c, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
+                                            void* stream) {
   if (!x_in || !g_out || !g_ld || !raw_c || !packed_w_c || !packed_b_c || !film_rec || !film_raw || !moments_c ||
-      !ystats_c || !g_in || !g_xa || !g_xb || !dA_mat || !h0_mat || !g_film || !g_sd0 || !g_bias || !g_stats || !g_mom ||
+      !ystats_c || !g_in || !g_xa || !g_xb || !dw1_ws || !g_film || !g_sd0 || !g_bias || !g_stats || !g_mom ||
       !g_film_raw || !g_raw_c)
     return GWTF_E_BADARG;
   const int FP = gwtf_padded_width(f), pat = (pattern0 + c) % 6;
   const double n_total = (double)B * N;
   hipStream_t st = (hipStream_t)stream;
-  int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dA_mat, h0_mat, g_film, g_sd0,
+  int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dw1_ws, g_film, g_sd0,
                                   g_bias, c, B, N, C, f, pattern0, eps, mode, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
                      g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP);
-  // h0_mat already holds this coupling's h (written by the coupling path above): the statistics path does not rewrite it
-  rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dA_mat, nullptr, g_sd0, B, N, f, pat, stream);
+  rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0, B, N,
+                           f, pat, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(fold0_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, moments_c, n_total, pat, g_sd0, g_raw_c,
                      g_mom, f, G, FP);
   const int bx = (N + 255) / 256;
   hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B), dim3(256), 0, st, x_in, g_xa, g_xb, g_mom, g_in, B, N);
-  return (int)hipGetLastError();
+  const GwtfRaw R(f, G);
+  return gwtf_dw1_reduce(dw1_ws, 2, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, stream);
 }

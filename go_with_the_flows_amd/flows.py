@@ -177,6 +177,33 @@ class _NoBackwardYet(torch.autograd.Function):
                                   'built yet (there is no autograd/CPU fallback)')
 
 
+class _ArenaCat(torch.autograd.Function):
+    """raw arena = cat(flattened parameters / buffers) as ONE autograd node: forward concatenates cached detached views,
+    backward hands every parameter its slice of the flat gradient (views, no kernels)."""
+
+    @staticmethod
+    def forward(ctx, engine, *tensors):
+        ctx.engine = engine
+        return engine._cat_detached()
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        eng = ctx.engine
+        pieces = g_raw.split_with_sizes(eng._sizes)
+        grads, k = [], 0
+        for (t, op), piece in zip(eng._srcs, pieces):
+            if t is None:
+                continue
+            k += 1
+            if not ctx.needs_input_grad[k]:
+                grads.append(None)
+            elif op == 't':                                   # stored as weight[0]^T: (k, f) -> (1, f, k)
+                grads.append(piece.view(t.shape[2], t.shape[1]).t().unsqueeze(0))
+            else:
+                grads.append(piece.view(t.shape))
+        return (None, *grads)
+
+
 class StackEngine:
     """Host-side driver of the HIP path for a run of consecutive couplings (direct order).
 
@@ -212,19 +239,24 @@ class StackEngine:
             self._zeros = {n: torch.zeros(n, device=dev) for n in {op for t, op in self._srcs if t is None}}
             self._src_stamp = stamp
             self._flat_key = None
-        # the flattened views are cached too (1320 of them for an 11-Triple decoder: building them costs more host time
-        # than the copy); they are created with grad mode ON so the cat below is differentiable whenever the caller's
-        # context is, and rebuilt when a requires_grad flag changes
-        key = sum(1 for t, _ in self._srcs if t is not None and t.requires_grad)
-        if key != self._flat_key:
+        # The 1320 flattened views (11-Triple decoder) are cached as DETACHED views: building them costs more host time
+        # than the copy.  They must not carry autograd history -- a cached differentiable view of a parameter that the
+        # optimiser then updates in place gets an AsStridedBackward grad_fn (new_zeros + copy per parameter, measured:
+        # +2000 kernels per step).  The autograd link is one custom node instead (_ArenaCat below).
+        if self._flat_key is None:
             z = self._zeros
-            with torch.enable_grad():
-                self._flat = [z[op] if t is None else (None if op == 't' else t.view(-1)) for t, op in self._srcs]
+            self._flat = [z[op] if t is None else (None if op == 't' else t.detach().view(-1)) for t, op in self._srcs]
             self._transposed = [i for i, (t, op) in enumerate(self._srcs) if op == 't']
-            self._flat_key = key
+            self._sizes = [op if t is None else t.numel() for t, op in self._srcs]
+            self._flat_key = True
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t, _ in self._srcs):
+            return _ArenaCat.apply(self, *[t for t, _ in self._srcs if t is not None])
+        return self._cat_detached()
+
+    def _cat_detached(self):
         flat = self._flat
         for i in self._transposed:          # sd0.weight is stored transposed: a copy, so it is re-made every time
-            flat[i] = self._srcs[i][0][0].t().reshape(-1)
+            flat[i] = self._srcs[i][0].detach()[0].t().reshape(-1)
         return torch.cat(flat)
 
     def _collect(self):

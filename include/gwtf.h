@@ -127,45 +127,49 @@ int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float*
  *   FiLM record [B][C][6FP+4] = {c, u0, u1} x 2 branches + biases (gwtf_layout.h).
  * gwtf_pack_folded builds the forward record (packed_w) and the backward record (packed_b) from them.
  * gwtf_coupling_backward: x_in = the coupling's input saved by the forward, g_out/g_ld = dL/d(out), dL/d(logdet);
- *   -> g_in [B][3][N]; dA_mat, h0_mat [2][FP][B][N] (dL/dacc and relu(sd0) per point: dW1p = sum_p dA h0^T is left to
- *   one batched library GEMM with K = B*N); g_film [B][C][2][3][FP] += {dc, du0, du1}; g_sd0 [64][2][3][FP] += {dW0f[:,0], dW0f[:,1], dc0f};
+ *   -> g_in [B][3][N]; dw1_ws: per-workgroup partials of dW1p = sum_p dL/dacc(p) relu(sd0)(p)^T, gwtf_dw1_workspace_floats(f,B,N)
+ *   floats, summed by gwtf_dw1_reduce; g_film [B][C][2][3][FP] += {dc, du0, du1}; g_sd0 [64][2][3][FP] += {dW0f[:,0], dW0f[:,1], dc0f};
  *   g_bias [64][4] += {db_lv0, db_lv1, db_mu0, db_mu1}   (64 = GWTF_STAT_REPLICAS copies, sum them; all pre-zeroed). */
 size_t gwtf_packed_b_coupling_floats(int f);
 int gwtf_pack_folded(const float* W1p, const float* W0f, const float* c0f, float* packed_w, float* packed_b,
                      int C, int f, void* stream);
 int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
-                           const float* packed_b_c, const float* film, float* g_in, float* dA_mat, float* h0_mat,
-                           float* g_film, float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0,
-                           float eps, int mode, void* stream);
+                           const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
+                           float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                           void* stream);
 
 /* Backward records of the train pipeline: W1T sections from the un-scaled sd1 weights (sd0 sections: gwtf_train_fold0). */
 int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, int G, void* stream);
 /* Backward of ONE coupling of the single-rank train pipeline (coupling path + fold1 + statistics path + fold0 + moments
- * path; csrc/gwtf_train.hip).  Workspace contract at the definition. */
+ * path + dW1 reduction; csrc/gwtf_train.hip).  dw1_ws: 2 * gwtf_dw1_workspace_floats(f, B, N) +
+ * gwtf_dw1_reduce_scratch_floats(f) floats.  Workspace contract at
+ * the definition. */
 int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* raw_c,
                                  const float* packed_w_c, const float* packed_b_c, const float* film_rec,
                                  const float* film_raw, const float* moments_c, const float* ystats_c, float* g_in,
-                                 float* g_xa, float* g_xb, float* dA_mat, float* h0_mat, float* g_film, float* g_sd0,
+                                 float* g_xa, float* g_xb, float* dw1_ws, float* g_film, float* g_sd0,
                                  float* g_bias, float* g_stats, float* g_mom, float* g_film_raw, float* g_raw_c,
                                  int c, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
                                  void* stream);
 
 /* Backward of gwtf_train_stats: g_stats [2][2][FP] = dL/d{sum y, sum y^2} per branch and feature (replicas already
- * summed by the caller) -> g_in (kept coordinates only); dA_mat += dL/dy (ACCUMULATED: the coupling path wrote it first,
- * or pre-zero it), h0_mat for the dW1 GEMM (NULL: not written -- the coupling path of the same input already wrote it);
+ * summed by the caller) -> g_in (kept coordinates only); dw1_ws: this pass's dW1 partials (as gwtf_coupling_backward);
  * g_sd0 [64][2][3][FP] +=. */
 int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
-                        float* g_in, float* dA_mat, float* h0_mat, float* g_sd0, int B, int N, int f, int pattern,
-                        void* stream);
+                        float* g_in, float* dw1_ws, float* g_sd0, int B, int N, int f, int pattern, void* stream);
 
-/* dW1[br][i][j] = sum_p dA_mat[br][i][p] * h0_mat[br][j][p]  (i, j < f; p < M = B*N): the sd1 weight gradient from the two
- * matrices the backward kernels leave behind ([2][FP][M] each, FP = gwtf_padded_width(f)).  Deterministic split-K on the
- * fp32 MFMA; workspace: gwtf_dw1_workspace_floats(f) floats.  Branch br is written as an [f][f] block at
- * dW1 + br * branch_stride (branch_stride = f*f for a dense [2][f][f]; the raw-arena branch size to write gradient records
- * in place). */
-size_t gwtf_dw1_workspace_floats(int f);
-int gwtf_dw1_gemm(const float* dA_mat, const float* h0_mat, float* workspace, float* dW1, size_t branch_stride, int f, int M,
-                  void* stream);
+/* The sd1 weight gradient dW1[br][j][i] = sum_p dL/dacc[br][j](p) * h[br][i](p) is accumulated INSIDE the backward kernels
+ * (points on the MFMA K axis, csrc/gwtf_bwd.hip); every workgroup leaves a [2][FP][FP] partial in the workspace.
+ *   gwtf_dw1_partials(B, N)             partials one backward pass writes
+ *   gwtf_dw1_workspace_floats(f, B, N)  floats of one pass's workspace region
+ *   gwtf_dw1_reduce_scratch_floats(f)   floats of scratch the reduction needs AFTER the last region of the same buffer
+ *   gwtf_dw1_reduce                     fixed-order (deterministic) two-stage sum over `passes` consecutive regions; branch br
+ *                                       is written as an [f][f] block at dW1 + br * branch_stride (f*f for a dense [2][f][f];
+ *                                       the raw-arena branch size to write a gradient record in place) */
+int gwtf_dw1_partials(int B, int N);
+size_t gwtf_dw1_workspace_floats(int f, int B, int N);
+size_t gwtf_dw1_reduce_scratch_floats(int f);
+int gwtf_dw1_reduce(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N, void* stream);
 
 /* Mixture negative log-likelihood over K flow components.
  * Replaces FlowMixtureNLL.forward (lib/networks/losses.py:88-137; per-component body :112-122 is
