@@ -18,7 +18,7 @@ def stats(d, pat, n=8):
         if i < n or any(p in r["Name"] for p in pat):
             print(f"  {r['Name'][:86]:86s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:10.2f} pct={r['Percentage']}")
 print("===== PointNet encoder, 64 x 2048 points (tools/bench_encoder.py) =====")
-print(open(f"{out}/enc.log").read().strip().splitlines()[-3:])
+print("\n".join("  " + l for l in open(f"{out}/enc.log").read().splitlines() if " ms" in l and "rocprof" not in l))
 stats("enc", ["encoder_kernel"], 4)
 agg = collections.defaultdict(list); meta = {}
 for d in ("enc_pmc", "enc_fetch"):
@@ -35,7 +35,7 @@ if agg.get("SQ_INSTS_MFMA"):
 if agg.get("FETCH_SIZE"):
     print(f"  HBM read per dispatch = 2*FETCH_SIZE*1024 = {2*sum(agg['FETCH_SIZE'])/len(agg['FETCH_SIZE'])*1024:.3e} B (gfx950 correction x2)")
 print("===== structural losses, 64 pairs of 2048-point clouds (tools/bench_metrics.py) =====")
-print(open(f"{out}/met.log").read().strip().splitlines()[-3:])
+print("\n".join("  " + l for l in open(f"{out}/met.log").read().splitlines() if " ms" in l and "rocprof" not in l))
 stats("met", ["nnd_kernel", "emd_"], 8)
 print("===== train step, one 33-coupling component, 64 x 2048 (tools/diag/trainstep_kernels.py, eager, 7 steps) =====")
 f = glob.glob(f"{out}/ts/*kernel_stats.csv")
