@@ -122,3 +122,27 @@ def test_full_size_properties():
     assert float(metrics.emd_approx(xt, xt.clone()).max()) < 1e-3 * float(emd.min())      # identical clouds cost ~0
     perm = torch.randperm(n, device=DEV)
     np.testing.assert_allclose(host(metrics.emd_approx(xt[:, perm].contiguous(), yt)), host(emd), rtol=2e-3)
+
+
+def test_evaluation_metrics_accelerated_path_matches_torch_path_and_oracle():
+    """compute_all_metrics / EMD_CD_F1 with the HIP kernels against the pure-torch Chamfer path and the EMD oracle."""
+    from go_with_the_flows_amd import evaluation as ev
+    s_np, r_np = clouds(41, 7, 96, 96, scale=0.25)
+    s, r = dev(s_np), dev(r_np)
+    fast = ev.EMD_CD_F1(s, r, batch_size=3, accelerated_cd=True, reduced=False, cd_option=True, emd_option=True,
+                        one_part_of_cd=True, f1_option=True, f1_threshold=0.01)
+    slow = ev.EMD_CD_F1(s, r, batch_size=3, accelerated_cd=False, reduced=False, cd_option=True, f1_option=True,
+                        f1_threshold=0.01)
+    np.testing.assert_allclose(host(fast['CD']), host(slow['CD']), rtol=1e-4, atol=1e-6)
+    ref_emd = mo.match_cost(s_np, r_np, mo.approx_match(s_np, r_np)) / 96
+    np.testing.assert_allclose(host(fast['EMD']), ref_emd, rtol=1e-4)
+    # nn_distance's (dist1, dist2) are per-sample-point / per-ref-point; the torch path returns them the other way round
+    d1, _, d2, _ = mo.nn_distance(s_np, r_np)
+    np.testing.assert_allclose(host(fast['CDL']), d1.mean(1), rtol=1e-5)
+    np.testing.assert_allclose(host(fast['CDR']), d2.mean(1), rtol=1e-5)
+    res = ev.compute_all_metrics(s, r, batch_size=4, accelerated_cd=True, cd_option=True, emd_option=True)
+    res_t = ev.compute_all_metrics(s, r, batch_size=4, accelerated_cd=False, cd_option=True)
+    for key in ('lgan_mmd-CD', 'lgan_cov-CD', 'lgan_mmd_smp-CD', '1-NN-CD-acc'):
+        assert abs(float(res[key]) - float(res_t[key])) < 1e-5 * max(1.0, abs(float(res_t[key]))), key
+    assert '1-NN-EMD-acc' in res and 0.0 <= float(res['lgan_cov-EMD']) <= 1.0
+    assert float(ev.compute_all_metrics(s, s.clone(), 4, accelerated_cd=True, cd_option=True, emd_option=True)['lgan_mmd-EMD']) < 1e-3
