@@ -93,3 +93,23 @@ class Adam(Optimizer):
                 if len(by_step) == 1:
                     self._plans[gi] = plan
         return loss
+
+
+class LRUpdater:
+    """Cosine cycle of the learning rate and of beta2 (reference optimizers.py:79-97): within a cycle of ``cycle_length``
+    epochs both go from their max to their min; beta1 is fixed.  Called as ``updater(optimizer, epoch, iteration)``."""
+
+    def __init__(self, epoch_length, **kwargs):
+        self.epoch_length = epoch_length
+        self.cycle_length = kwargs['cycle_length']
+        self.min_lr, self.max_lr = kwargs['min_lr'], kwargs['max_lr']
+        self.beta1 = kwargs['beta1']
+        self.min_beta2, self.max_beta2 = kwargs['min_beta2'], kwargs['max_beta2']
+
+    def __call__(self, optimizer, epoch, iteration):
+        import math
+        phase = ((epoch % self.cycle_length) * self.epoch_length + iteration) / (self.cycle_length * self.epoch_length)
+        w = 0.5 * (1.0 + math.cos(math.pi * phase))
+        for group in optimizer.param_groups:
+            group['lr'] = self.min_lr + (self.max_lr - self.min_lr) * w
+            group['betas'] = (self.beta1, self.min_beta2 + (self.max_beta2 - self.min_beta2) * w)
