@@ -137,3 +137,44 @@ def test_sample_fused_equals_per_component_decoding():
             want = m.pc_decoder[k](z0.contiguous(), g, mode='direct')[0][-1]
             assert maxabs(host(x[:, :, off:off + cnt]), host(want)) < TOL_COORD
             off += cnt
+
+
+def test_graphed_train_step_equals_eager_steps():
+    """Three optimiser steps through GraphedTrainStep == three eager steps (same noise, same batches)."""
+    from go_with_the_flows_amd import optim
+    from go_with_the_flows_amd.training import GraphedTrainStep
+    D = golden('g13_full_model')
+    noise = dev(D['noise_g'])
+    batches = [(dev(D['gcloud']) * s, dev(D['pcloud']) * s) for s in (1.0, 0.9, 1.1)]
+    runs = []
+    for graphed in (False, True):
+        m, cfg = build()
+        m.train()
+        m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+        crit = models.Flow_Mixture_Loss(**cfg)
+        opt = optim.Adam(m.parameters(), lr=1e-4, amsgrad=True)
+        losses = []
+        if graphed:
+            state = {k: v.clone() for k, v in m.state_dict().items()}
+            step = GraphedTrainStep(m, crit, opt, *batches[0])
+            m.load_state_dict(state)                 # undo the running-statistic updates of warm-up and capture
+            for g_in, p_in in batches:
+                losses.append(float(step(g_in, p_in)[0]))
+        else:
+            for g_in, p_in in batches:
+                opt.zero_grad(set_to_none=True)
+                enc, dec = m.forward_fused(g_in, p_in)
+                loss = crit.fused(enc, dec)[0]
+                loss.backward()
+                opt.step()
+                losses.append(float(loss.detach()))
+                del loss, enc, dec
+        runs.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+    (l0, s0), (l1, s1) = runs
+    for a, b in zip(l0, l1):
+        assert abs(a - b) < 1e-4 * abs(a)
+    # Adam normalises every gradient entry to ~lr: entries whose gradient is rounding noise (atomic summation order differs
+    # between the two runs) move by +-lr either way, so compare against the step size, not against the gradient noise
+    rel = [float((s0[k].float() - s1[k].float()).abs().max() / (s0[k].float().abs().max() + 1e-3)) for k in s0]
+    assert max(rel) < 2e-2 and sum(rel) / len(rel) < 2e-4
+
