@@ -33,7 +33,7 @@ from go_with_the_flows_amd.synth import load_synth_, synth_inputs  # noqa: E402
 WORKLOADS = {
     'airplane': dict(K=4, L=11, f=37, G=128, B=64, N=2048, mode='inverse',
                      name='configs[1] airplane generative (config_generative_modeling_airplane.yaml): '
-                          'K=4 flows x 33 couplings, f=37, G=128, B=64 x N=2048, inverse + sum(logvars), eval BN'),
+                          'K=4 flows x 33 couplings, f=37, G=128, B=64 x N=2048, inverse + sum(logvars) + mixture NLL, eval BN'),
     'm1': dict(K=1, L=4, f=64, G=128, B=32, N=2048, mode='inverse',
                name='north-star shape: single flow, 12 couplings, f=64, G=128, B=32 x N=2048, inverse + sum(logvars)'),
     'ae': dict(K=4, L=11, f=33, G=512, B=16, N=2048, mode='inverse',
@@ -129,10 +129,22 @@ def main():
     stack = gw.MixtureStack(decoders)                    # K components: one FiLM launch + one stack launch
     counts = [N // K] * K
 
+    # density workloads with K > 1 end in the fused mixture NLL, as the training loss consumes them (shape M2):
+    # synthetic base Gaussians and mixture logits, resident like the inputs
+    with_nll = (not sideways) and K > 1
+    if with_nll:
+        rng = np.random.default_rng(77 + rank)
+        mu0 = torch.from_numpy((0.05 * rng.standard_normal((K, B, 3))).astype(np.float32)).to(dev)
+        lv0 = torch.from_numpy((0.2 * rng.standard_normal((K, B, 3))).astype(np.float32)).to(dev)
+        logits = torch.from_numpy(rng.standard_normal((B, K)).astype(np.float32)).to(dev)
+
     def launch_step():
         if sideways:
             return stack.forward_partition(pd, gd, counts, mode)
-        return stack.forward_all(pd, gd, mode)
+        z, ld = stack.forward_all(pd, gd, mode)
+        if with_nll:
+            return z, ld, _lib.mixture_nll(z, ld, mu0, lv0, logits)
+        return z, ld
 
     def step(timers=None):
         """Eager path with HIP events around the stack launch (kernel-duration probe)."""
@@ -147,6 +159,8 @@ def main():
         e1.record()
         if timers is not None:
             timers.append((e0, e1))
+        if with_nll:
+            res = (*res, _lib.mixture_nll(res[0], res[1], mu0, lv0, logits))
         return res
 
     eager_step = step
@@ -229,7 +243,8 @@ def main():
                        'couplings_per_component': 3 * L, 'f': f, 'G': G, 'direction': mode,
                        'point_definition': 'one 3-D point through one component stack (coords + sum logvars)',
                        'sharding': f'batch of shapes over {world} rank(s), no data-path collective',
-                       'launch': ('eager: ' if args.eager else 'one hipGraph replay per step: ') + '1 FiLM + 1 stack launch for all components'},
+                       'launch': ('eager: ' if args.eager else 'one hipGraph replay per step: ') + '1 FiLM + 1 stack launch for all components'
+                                 + (' + 1 mixture-NLL launch (per-shape NLL over K components)' if with_nll else '')},
             'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
                          'peak_split_f16': round(MFMA_F16_PEAK_TFLOPS / 3, 1),

@@ -14,7 +14,7 @@ namespace {
 
 constexpr int kMaxK = 64;
 constexpr int kThreads = 256;
-constexpr int kPtsPerBlock = 2048;
+constexpr int kPtsPerBlock = 512;    // 2 points per thread: (N/512) x B workgroups (8 k for 64 x 2048) keep all 256 CUs streaming
 
 __global__ __launch_bounds__(kThreads) void nll_kernel(const float* __restrict__ z, const float* __restrict__ logdet,
                                                        const float* __restrict__ mu0, const float* __restrict__ lv0,

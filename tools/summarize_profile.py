@@ -30,5 +30,12 @@ for w in ('airplane', 'm1'):
         g = lambda k: sum(agg[k]) / len(agg[k]) if agg.get(k) else float('nan')
         waves = float(meta['Grid_Size']) / 64
         print(f'waves={waves:.0f}  VALU/wave={g("SQ_INSTS_VALU") / waves:.0f}  MFMA/wave={g("SQ_INSTS_MFMA") / waves:.0f}')
+        if agg.get('SQ_VALU_MFMA_BUSY_CYCLES') and agg.get('GRBM_GUI_ACTIVE'):
+            # SQ_VALU_MFMA_BUSY_CYCLES = matrix-pipe busy cycles summed over the 1024 SIMDs (= 16 x SQ_INSTS_MFMA for the
+            # 16x16x32 f16 MFMA); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            cyc = g('GRBM_GUI_ACTIVE') / 8
+            print(f'kernel cycles ~ {cyc:.3e}; MFMA pipe utilisation = MFMA_BUSY / (cycles x 1024 SIMDs) = '
+                  f'{g("SQ_VALU_MFMA_BUSY_CYCLES") / (cyc * 1024):.3f}; VALU issue share = 4 x SQ_INSTS_VALU / (cycles x 1024) = '
+                  f'{4 * g("SQ_INSTS_VALU") / (cyc * 1024):.3f}')
         print(f'HBM bytes per dispatch: read = 2*FETCH_SIZE*1024 = {2 * g("FETCH_SIZE") * 1024:.3e} (gfx950 correction x2), '
               f'write = WRITE_SIZE*1024 = {g("WRITE_SIZE") * 1024:.3e}')
