@@ -45,13 +45,13 @@ def sum_over_ranks(t):
     return t
 
 
-def all_reduce_gradients(module, average=True):
+def all_reduce_gradients(module, average=True, force=False):
     """Data-parallel gradient exchange as ONE flat fp32 buffer (19-104 MB per step for the shipped
     configs): flatten every .grad, a single all-reduce over the default group (RCCL on ROCm: backend 'nccl'), divide
     by the world size (DDP semantics, reference train_ae.py:153), scatter back.  A drop-in for DistributedDataParallel
     when the model is used without the DDP wrapper; with DDP, its bucketed all-reduce does the same job."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return 0
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
+        return 0          # force=True still runs the collective on a 1-rank group (exercises the RCCL path on one GPU)
     params = [p for p in module.parameters() if p.grad is not None]
     if not params:
         return 0

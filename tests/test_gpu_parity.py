@@ -575,6 +575,16 @@ def test_two_rank_syncbn_training_matches_single_process(tmp_path):
     assert 'DIST2' in r.stdout and 'DDP wrapped' in r.stdout, r.stdout[-2000:]
 
 
+def test_flat_gradient_all_reduce_over_rccl_single_rank():
+    """backend 'nccl' (= RCCL): process-group init on the MI355X and the flat gradient all-reduce, 1-rank group."""
+    import os
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'rccl_single_rank_worker.py')],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'RCCL1 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_whole_train_step_hipgraph_replay_equals_eager():
     """forward(train BN) + backward + SGD captured in ONE hipGraph: replays continue the eager trajectory."""
     L, f, G, B, N = 1, 19, 16, 4, 128
