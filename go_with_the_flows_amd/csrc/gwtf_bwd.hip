@@ -244,12 +244,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
           sdc += da;
           acc[br][m][nb][r] = da;
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-          sdc += __shfl_xor(sdc, off);
-          sdu0 += __shfl_xor(sdu0, off);
-          sdu1 += __shfl_xor(sdu1, off);
-        }
+        sdc = row_sum16(sdc);
+        sdu0 = row_sum16(sdu0);
+        sdu1 = row_sum16(sdu1);
         if (i16 == 0) {
           atomicAdd(&s_film[br][0][ft], sdc);
           atomicAdd(&s_film[br][1][ft], sdu0);
@@ -334,12 +331,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
           g1 = fmaf(dp, xb[nb], g1);
           g2 += dp;
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-          g0 += __shfl_xor(g0, off);
-          g1 += __shfl_xor(g1, off);
-          g2 += __shfl_xor(g2, off);
-        }
+        g0 = row_sum16(g0);
+        g1 = row_sum16(g1);
+        g2 = row_sum16(g2);
         if (i16 == 0) {
           atomicAdd(&s_sd0[br][0][fi], g0);
           atomicAdd(&s_sd0[br][1][fi], g1);

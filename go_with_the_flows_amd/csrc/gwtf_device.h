@@ -44,6 +44,16 @@ __device__ __forceinline__ void split_pair(f32x2 h, f16x2& hi, f16x2& lo) {
   lo = __builtin_convertvector(r, f16x2);
 }
 
+// Sum over the 16 lanes of a DPP row (= one quarter of the wavefront = the 16 points of a column group); every lane ends
+// with the total.  Four v_add_f32 with DPP operand modifiers -- no LDS traffic (a __shfl_xor goes through ds_bpermute).
+__device__ __forceinline__ float row_sum16(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  return v;
+}
+
 // Sum the per-quarter partials o[nb] over the four 16-lane quarters so that the lane in quarter q ends
 // with the total of point block (q & (NB-1)).
 template <int NB>

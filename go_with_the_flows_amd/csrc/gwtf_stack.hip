@@ -159,11 +159,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
           s1 += v;
           s2 = fmaf(v, v, s2);
         }
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) {
-          s1 += __shfl_xor(s1, off);
-          s2 += __shfl_xor(s2, off);
-        }
+        s1 = row_sum16(s1);
+        s2 = row_sum16(s2);
         if (i16 == 0) {
           const int ft = 16 * m + 4 * q + r;
           atomicAdd(&s_stats[(br * FP + ft) * 2 + 0], s1);   // LDS: 4 waves

@@ -228,11 +228,28 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
   constexpr int TW = 2 * GWTF_MAX_FP;
   __shared__ float st_part[kFoldSlices][TW][2];
   __shared__ double acc_part[kFoldSlices][TW][4];
+  __shared__ float bias_part[kFoldSlices][4];
   const int t = threadIdx.x % TW, sl = threadIdx.x / TW;
   const bool lane_on = t < 2 * FP;
   const int br = lane_on ? t / FP : 0, j = lane_on ? t % FP : 0;
   const bool on = lane_on && j < f;
   const GwtfRaw R(f, G);
+  // every global load this thread needs is issued BEFORE the first barrier (one memory round trip instead of three):
+  // its statistic replicas, and the FiLM records of its first kPre shapes (covers B <= 64; the rest loops normally)
+  constexpr int kPre = 8;
+  float pa[kPre], pb[kPre], pgc[kPre], pg0[kPre], pg1[kPre];
+  const float* rb = raw_c + (size_t)br * R.branch_size();
+  float* grb = g_raw_c + (size_t)br * R.branch_size();
+  const float w20 = on ? rb[R.sd2_w() + j] : 0.f, w21 = on ? rb[R.sd2_w() + f + j] : 0.f;
+#pragma unroll
+  for (int i = 0; i < kPre; ++i) {
+    const int b = sl + i * kFoldSlices;
+    const bool ok = on && b < B;
+    const float* fr = film_raw + (((size_t)(ok ? b : 0) * C + c) * 2 + br) * 2 * FP;
+    const float* gf = g_film + (((size_t)(ok ? b : 0) * C + c) * 2 + br) * 3 * FP;
+    pa[i] = ok ? fr[j] : 1.f; pb[i] = ok ? fr[FP + j] : 0.f;
+    pgc[i] = ok ? gf[j] : 0.f; pg0[i] = ok ? gf[FP + j] : 0.f; pg1[i] = ok ? gf[2 * FP + j] : 0.f;
+  }
   {
     float ys = 0.f, yq = 0.f;
     if (on)
@@ -242,6 +259,11 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
       }
     st_part[sl][t][0] = ys;
     st_part[sl][t][1] = yq;
+    if (lane_on && j < 2) {
+      float bsum = 0.f;
+      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) bsum += g_bias[r * 4 + 2 * br + j];
+      bias_part[sl][2 * br + j] = bsum;
+    }
   }
   __syncthreads();
   float ys = 0.f, yq = 0.f;
@@ -251,25 +273,27 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
   double var = yq / n_total - mean * mean;
   if (var < 0.0) var = 0.0;
   const float s1 = 1.0f / sqrtf((float)var + GWTF_BN_EPS);
-  const float* rb = raw_c + (size_t)br * R.branch_size();
-  float* grb = g_raw_c + (size_t)br * R.branch_size();
-  const float w20 = on ? rb[R.sd2_w() + j] : 0.f, w21 = on ? rb[R.sd2_w() + f + j] : 0.f;
   double g_m1 = 0.0, g_s1 = 0.0, gw20 = 0.0, gw21 = 0.0;
-  if (on)
-    for (int b = sl; b < B; b += kFoldSlices) {
+  auto one = [&](int b, float a, float bs, float gc, float gu0, float gu1) {
+    float* go = g_film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
+    const float guw = gu0 * w20 + gu1 * w21;
+    go[j] = -gc * bs / (a * a * s1) + guw * s1;   // dL/da
+    go[FP + j] = gc / (a * s1);                   // dL/dbsh
+    gw20 += (double)gu0 * a * s1;
+    gw21 += (double)gu1 * a * s1;
+    g_s1 += (double)(-gc * bs / (a * s1 * s1)) + (double)guw * a;
+    g_m1 -= gc;
+  };
+  if (on) {
+#pragma unroll
+    for (int i = 0; i < kPre; ++i)
+      if (sl + i * kFoldSlices < B) one(sl + i * kFoldSlices, pa[i], pb[i], pgc[i], pg0[i], pg1[i]);
+    for (int b = sl + kPre * kFoldSlices; b < B; b += kFoldSlices) {
       const float* fr = film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
       const float* gf = g_film + (((size_t)b * C + c) * 2 + br) * 3 * FP;
-      float* go = g_film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
-      const float a = fr[j], bs = fr[FP + j];
-      const float gc = gf[j], gu0 = gf[FP + j], gu1 = gf[2 * FP + j];
-      const float guw = gu0 * w20 + gu1 * w21;
-      go[j] = -gc * bs / (a * a * s1) + guw * s1;   // dL/da
-      go[FP + j] = gc / (a * s1);                   // dL/dbsh
-      gw20 += (double)gu0 * a * s1;
-      gw21 += (double)gu1 * a * s1;
-      g_s1 += (double)(-gc * bs / (a * s1 * s1)) + (double)guw * a;
-      g_m1 -= gc;
+      one(b, fr[j], fr[FP + j], gf[j], gf[FP + j], gf[2 * FP + j]);
     }
+  }
   acc_part[sl][t][0] = g_m1; acc_part[sl][t][1] = g_s1; acc_part[sl][t][2] = gw20; acc_part[sl][t][3] = gw21;
   __syncthreads();
   if (sl != 0 || !lane_on) return;
@@ -290,7 +314,8 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
   grb[R.sd2_w() + f + j] = (float)gw21;
   if (j < 2) {
     float bsum = 0.f;
-    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) bsum += g_bias[r * 4 + 2 * br + j];
+#pragma unroll
+    for (int i = 0; i < kFoldSlices; ++i) bsum += bias_part[i][2 * br + j];
     grb[R.sd2_b() + j] = bsum;
   }
 }
@@ -375,11 +400,20 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kerne
     red[t][4] = g_var * wb * wb;
   }
   __syncthreads();
+  __shared__ double r5s[5];
+  if (threadIdx.x < 5) {           // five sums over the 2f rows, four independent accumulators each
+    double a4[4] = {0.0, 0.0, 0.0, 0.0};
+    const int n = 2 * f;
+    int u = 0;
+    for (; u + 3 < n; u += 4) {
+      a4[0] += red[u][threadIdx.x]; a4[1] += red[u + 1][threadIdx.x]; a4[2] += red[u + 2][threadIdx.x]; a4[3] += red[u + 3][threadIdx.x];
+    }
+    for (; u < n; ++u) a4[0] += red[u][threadIdx.x];
+    r5s[threadIdx.x] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    double r5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    for (int u = 0; u < 2 * f; ++u)
-#pragma unroll
-      for (int i = 0; i < 5; ++i) r5[i] += red[u][i];
+    const double r5[5] = {r5s[0], r5s[1], r5s[2], r5s[3], r5s[4]};
     for (int i = 0; i < 16; ++i) g_mom[i] = 0.f;
     const double gC00 = r5[2], gC01 = r5[3], gC11 = r5[4];
     const double gE0 = r5[0] - 2.0 * e0 * gC00 - e1 * gC01;

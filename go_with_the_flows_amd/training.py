@@ -2,7 +2,7 @@
 
 The reference's loop (lib/networks/training.py:25-60: forward, loss, backward, optimiser step per batch) is host-bound on
 an MI355X: ~3000 kernel launches per step for the airplane config.  ``GraphedTrainStep`` captures forward + loss + backward
-once and replays it per batch (35 ms instead of 61 ms per step for K=4 x 33 couplings, 64 x 2048 points); the optimiser
+once and replays it per batch (31 ms instead of 62 ms per step for K=4 x 33 couplings, 64 x 2048 points); the optimiser
 stays outside the graph because its bias corrections and the learning-rate schedule are host-side state.
 """
 import torch
