@@ -691,3 +691,40 @@ def test_fused_adam_on_a_decoder_many_tensors():
     for q, b, g in zip(params, before, grads):
         ref = fo.adam_step(b, g, np.zeros_like(b), np.zeros_like(b), np.zeros_like(b), 1, 3e-3, 0.9, 0.999, 1e-8, 1e-4, True)[0]
         assert maxabs(host(q), ref) < 2e-6
+
+
+@pytest.mark.parametrize('training', [False, True])
+def test_full_size_weight_gradient_directional_derivative(training):
+    """Airplane-sized component (33 couplings, 64 x 2048 points): the in-kernel dW1 accumulation (131,072 points on the
+    MFMA K axis, per-workgroup power-of-two scaling, 2 x 1024 partials) against central finite differences of the loss
+    along a random direction in the sd1 weights of three couplings near the end of the inverse chain (further up the
+    chain the loss is too rough for fp32 finite differences: the same quotient moves by 2x between step sizes)."""
+    L, f, G, B, N = 11, 37, 128, 64, 2048
+    m, _ = decoder_and_state(L, f, G, 31)
+    m = m.to(DEV).train(training)
+    p, g = synth_inputs(B, N, G, 32)
+    pd, gd = dev(p), dev(g)
+    targets = [m.flows[0].nvp2.T_mu_0[3].weight, m.flows[1].nvp1.T_logvar_0[3].weight, m.flows[5].nvp1.T_logvar_0[3].weight]
+    gen = torch.Generator(device='cpu').manual_seed(5)
+    dirs = [torch.randn(t.shape, generator=gen).to(DEV) for t in targets]
+    frozen = {k: v.clone() for k, v in m.state_dict().items() if 'running' in k or 'num_batches' in k}
+
+    def loss_fn():
+        z, ld = m.forward_fused(pd, gd, 'inverse')
+        m.load_state_dict(frozen, strict=False)            # train mode: keep the running statistics fixed
+        return (0.5 * (ld + z * z).sum(dim=(1, 2)) / N).mean()
+
+    loss_fn().backward()
+    analytic = [float((t.grad * d).sum()) for t, d in zip(targets, dirs)]
+    base = [t.detach().clone() for t in targets]
+    h = 1e-3
+    for k in range(3):
+        vals = []
+        for sgn in (+1, -1):
+            with torch.no_grad():
+                for t, b0 in zip(targets, base):
+                    t.copy_(b0)
+                targets[k].add_(dirs[k], alpha=sgn * h)
+                vals.append(float(loss_fn()))
+        fd = (vals[0] - vals[1]) / (2 * h)
+        assert abs(fd - analytic[k]) < 3e-2 * abs(analytic[k]) + 2e-2, (k, fd, analytic[k])
