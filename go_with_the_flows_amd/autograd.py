@@ -354,7 +354,6 @@ def train_density_forward(engine, p, g, distributed=False, mode='inverse'):
     order; ps/lvs differentiable) and bn_batch (C,2,4,2,f) for the running-statistic update.
     distributed=True: statistics (and their gradients) are summed over torch.distributed's default group and the
     per-shape FiLM BatchNorm sees the latents of all ranks."""
-    from .flows import WARP_PATTERNS  # noqa: F401  (pattern table lives there)
     C, f, eps = engine.C, engine.f, engine.couplings[0]._eps_value
     B, _, N = p.shape
     P = _gather(engine)

@@ -13,7 +13,6 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib
 from .layers import SharedDot, Swish
