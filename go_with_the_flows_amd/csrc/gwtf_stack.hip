@@ -100,6 +100,155 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
   }
 }
 
+// Software-pipelined variant of coupling_body for a compile-time number of valid k-slots in the last k-step (NJL):
+// without the run-time "skip padded k positions" branches the whole coupling is ONE basic block, and the stages are
+// written -- and pinned with sched_group_barrier -- so that vector work sits in the shadow of the matrix pipe: a
+// v_mfma_f32_16x16x32_f16 holds the SIMD's vector issue for 8 of its 16 cycles (MI355X_MICROARCH.md, cycle constants),
+// two plain VALU instructions per MFMA are nearly free.
+//   A: B fragments (sd0 + ReLU + split) of branch 0                                   VALU only
+//   B: MFMAs of branch 0        interleaved with  B fragments of branch 1
+//   C: MFMAs of branch 1        interleaved with  ReLU + sd2 dot of branch 0
+//   D: ReLU + sd2 dot of branch 1, quarter reduce, transcendental tail                VALU only
+// Same arithmetic in the same order per accumulator as coupling_body: bit-identical results.
+template <int MB, int NB, int MODE, bool KEEP2, int NJL>
+__device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, int lane, int q, int k0, int k1, int w0,
+                                                   int w1, float eps, float s_keep, const float (&x)[NB][3],
+                                                   float (&xo)[3], float (&mu_d)[3], float (&lv_d)[3]) {
+  using K = Cfg<MB>;
+  constexpr int FP = K::FP, KS = K::KS;
+  constexpr int PAIRS_LAST = (NJL + 1) / 2;                       // valid pairs of k-slots in the last k-step
+  constexpr int UNITS = ((KS - 1) * 4 + PAIRS_LAST) * NB;         // (pair of k-slots, point block) work items per branch
+  constexpr int TRIPLES = KS * MB * NB;                           // (ks, m, nb) MFMA triplets per branch
+  float xa[NB], xb[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
+    xb[nb] = KEEP2 ? sel3(x[nb][0], x[nb][1], x[nb][2], k1) : 0.f;
+  }
+  f16x8 bhi[2][KS][NB], blo[2][KS][NB];
+#pragma unroll
+  for (int br = 0; br < 2; ++br)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+      for (int e = 2 * PAIRS_LAST; e < 8; ++e) bhi[br][KS - 1][nb][e] = blo[br][KS - 1][nb][e] = (_Float16)0.f;
+
+  auto unit = [&](int br, int u) {        // u-th (pair, point block) item of branch br
+    const int per_ks = 4 * NB;
+    const int ks = u / per_ks < KS - 1 ? u / per_ks : KS - 1;
+    const int rem = u - ks * per_ks, jp = rem / NB, nb = rem % NB, j0 = 2 * jp;
+    const f32x4* sp = reinterpret_cast<const f32x4*>(L + 2 * K::A16 + br * K::SD0 + q * 24 + ks * 96);
+    const f32x4 wa = sp[j0 >> 2], wb = KEEP2 ? sp[2 + (j0 >> 2)] : f32x4{0.f, 0.f, 0.f, 0.f}, cc = sp[4 + (j0 >> 2)];
+    const f32x2 wa2 = {wa[j0 & 3], wa[(j0 & 3) + 1]}, wb2 = {wb[j0 & 3], wb[(j0 & 3) + 1]}, cc2 = {cc[j0 & 3], cc[(j0 & 3) + 1]};
+    const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
+    f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
+                      : __builtin_elementwise_fma(wa2, xa2, cc2);
+    pre[0] = fmaxf(pre[0], 0.f);
+    pre[1] = fmaxf(pre[1], 0.f);
+    f16x2 hi, lo;
+    split_pair(pre, hi, lo);
+    bhi[br][ks][nb][j0] = hi[0]; bhi[br][ks][nb][j0 + 1] = hi[1];
+    blo[br][ks][nb][j0] = lo[0]; blo[br][ks][nb][j0 + 1] = lo[1];
+  };
+  f32x4 acc[2][MB][NB];
+  auto triple = [&](int br, int t) {      // t-th (ks, m, nb) triplet of branch br
+    const int ks = t / (MB * NB), m = (t / NB) % MB, nb = t % NB;
+    const float* aimg = L + br * K::A16 + lane * 4;
+    const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);
+    const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 1) * 256);
+    const f32x4 cinit = *reinterpret_cast<const f32x4*>(L + K::PW + br * 3 * FP + 4 * q + 16 * m);
+    acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[br][ks][nb], ks == 0 ? cinit : acc[br][m][nb], 0, 0, 0);
+    acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[br][ks][nb], acc[br][m][nb], 0, 0, 0);
+    acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
+  };
+  float o0[2][NB], o1[2][NB];
+#pragma unroll
+  for (int br = 0; br < 2; ++br)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) o0[br][nb] = o1[br][nb] = 0.f;
+  auto dot_piece = [&](int br, int pc) {  // ReLU + sd2 dot for accumulator row (m, r) and HALF of the point blocks: pc = ((m*4+r)*2+h)
+    const int m = pc / 8, r = (pc / 2) % 4, h = pc % 2;
+    const float* fe = L + K::PW + br * 3 * FP + 4 * q;
+    const float u0 = fe[FP + 16 * m + r], u1 = KEEP2 ? 0.f : fe[2 * FP + 16 * m + r];
+#pragma unroll
+    for (int nb = h * (NB / 2 > 0 ? NB / 2 : 1); nb < (NB >= 2 ? (h + 1) * (NB / 2) : (h == 0 ? 1 : 0)); ++nb) {
+      const float v = fmaxf(acc[br][m][nb][r], 0.f);
+      o0[br][nb] = fmaf(u0, v, o0[br][nb]);
+      if (!KEEP2) o1[br][nb] = fmaf(u1, v, o1[br][nb]);
+    }
+  };
+
+  // Two refinements measured at noise level (0.604-0.609 ms against 0.606 for the airplane config) and left off: computing
+  // only the first k-step's fragments of branch 0 up front, and starting branch 1's dot tile by tile inside stage C.
+  constexpr bool LATEFRAG = false, EARLYDOT = false;
+  // stage A: fragments of branch 0 (LATEFRAG: for its FIRST k-step only, the rest rides behind its own MFMAs)
+  constexpr int U0 = LATEFRAG ? 4 * NB : UNITS;                    // items computed up front
+  constexpr int T0 = MB * NB;                                      // triplets of one k-step
+#pragma unroll
+  for (int u = 0; u < U0; ++u) unit(0, u);
+  // stage B: MFMAs of branch 0; behind them, in this order: the rest of branch 0's fragments, then branch 1's
+  constexpr int QB = (UNITS - U0) + UNITS;
+  constexpr int PIECES = MB * 8;
+#pragma unroll
+  for (int t = 0; t < TRIPLES; ++t) {
+    triple(0, t);
+#pragma unroll
+    for (int i = t * QB / TRIPLES; i < (t + 1) * QB / TRIPLES; ++i) {
+      // a fragment must precede its first triplet in program order: branch 0's late items are all issued within the
+      // first k-step's T0 triplets whenever (UNITS - U0) * TRIPLES <= T0 * QB (asserted)
+      if (i < UNITS - U0) unit(0, U0 + i); else unit(1, i - (UNITS - U0));
+    }
+  }
+  static_assert(!LATEFRAG || (UNITS - U0) * TRIPLES <= T0 * QB, "late fragments of branch 0 would miss their k-step");
+  static_assert(KS <= 2, "the fragment queue assumes at most two k-steps");
+  // stage C: MFMAs of branch 1; behind them the ReLU + sd2 dot of branch 0 (EARLYDOT: then, as soon as a tile of
+  // branch 1 has seen its last k-step, that tile's own dot)
+  constexpr int TC = EARLYDOT ? (KS - 1) * T0 : TRIPLES;            // triplets that carry branch 0's dot
+#pragma unroll
+  for (int t = 0; t < TRIPLES; ++t) {
+    triple(1, t);
+    if (t < TC) {
+#pragma unroll
+      for (int pc = t * PIECES / TC; pc < (t + 1) * PIECES / TC; ++pc) dot_piece(0, pc);
+    } else {
+      const int tl = t - TC, m_done = tl / NB;                      // tiles 0 .. m_done-1 of branch 1 are complete
+      if (m_done > 0) {
+#pragma unroll
+        for (int i = (tl % NB) * 8 / NB; i < ((tl % NB) + 1) * 8 / NB; ++i) dot_piece(1, (m_done - 1) * 8 + i);
+      }
+    }
+  }
+  // stage D: what is left of branch 1's dot
+#pragma unroll
+  for (int pc = (EARLYDOT ? (MB - 1) * 8 : 0); pc < PIECES; ++pc) dot_piece(1, pc);
+  float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+  for (int br = 0; br < 2; ++br) {
+    res[br][0] = quarter_reduce<NB>(o0[br], q);
+    if (!KEEP2) res[br][1] = quarter_reduce<NB>(o1[br], q);
+  }
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
+  float lv_w[2] = {0.f, 0.f}, mu_w[2] = {0.f, 0.f}, sc_w[2] = {s_keep, s_keep};
+#pragma unroll
+  for (int s = 0; s < (KEEP2 ? 1 : 2); ++s) {
+    const float t = res[0][s] + bias[s];
+    lv_w[s] = t / (1.0f + fabsf(t));
+    mu_w[s] = res[1][s] + bias[2 + s];
+    sc_w[s] = sqrtf(eps + expf(lv_w[s]));
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const bool is0 = d == w0, is1 = !KEEP2 && d == w1;
+    lv_d[d] = is0 ? lv_w[0] : (is1 ? lv_w[1] : 0.f);
+    mu_d[d] = is0 ? mu_w[0] : (is1 ? mu_w[1] : 0.f);
+    const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : s_keep);
+    if (MODE == GWTF_MODE_DIRECT)
+      xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
+    else
+      xo[d] = __fdiv_rn(__fsub_rn(xo[d], mu_d[d]), sc);
+  }
+}
+
 // Work list of one launch: component k applies ITS stack to points [begin[k], end[k]) of every shape.
 // Passed by value in the kernel arguments (wave-uniform, scalar loads).
 // Train-mode statistics pass of ONE coupling: per-feature sum and sum of squares of y1 = sd1(relu(sd0_bn(sd0(x))))
@@ -189,7 +338,7 @@ struct Jobs {
   int begin[GWTF_MAX_COMPONENTS], end[GWTF_MAX_COMPONENTS];
 };
 
-template <int MB, int NB, int MODE, bool LISTS>
+template <int MB, int NB, int MODE, bool LISTS, int NJL = 0>
 __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p, const float* __restrict__ pw,
                                                     const float* __restrict__ film, float* __restrict__ out,
                                                     float* __restrict__ logdet, float* __restrict__ ps,
@@ -267,10 +416,17 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     int k0, k1, w0, w1;
     gwtf_pattern_dims(pat, &k0, &k1, &w0, &w1);
     float mu_d[3], lv_d[3];
-    if (pat < 3)
-      coupling_body<MB, NB, MODE, true>(lds[buf], kk_steps, lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
-    else
-      coupling_body<MB, NB, MODE, false>(lds[buf], kk_steps, lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
+    if constexpr (NJL > 0) {
+      if (pat < 3)
+        coupling_body_pipe<MB, NB, MODE, true, NJL>(lds[buf], lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
+      else
+        coupling_body_pipe<MB, NB, MODE, false, NJL>(lds[buf], lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
+    } else {
+      if (pat < 3)
+        coupling_body<MB, NB, MODE, true>(lds[buf], kk_steps, lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
+      else
+        coupling_body<MB, NB, MODE, false>(lds[buf], kk_steps, lane, q, k0, k1, w0, w1, eps, s_keep, x, xo, mu_d, lv_d);
+    }
 #pragma unroll
     for (int d = 0; d < 3; ++d) ld[d] += lv_d[d];
     if (LISTS && own_valid) {
@@ -321,6 +477,8 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   }
 }
 
+extern int g_pipe;
+
 template <int MB, int NB>
 int launch(const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps, float* mus,
            float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps, const int* segs, int K,
@@ -340,6 +498,27 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
 #define GWTF_LAUNCH(MODE_, LISTS_)                                                                                      \
   hipLaunchKernelGGL((stack_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, \
                      B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k, ex)
+  // Software-pipelined body (coupling_body_pipe) for the widths the reference's configs resolve to -- the number of valid
+  // k-slots of the last k-step must be a compile-time fact: f = 61..64 (NJL 8), 37..40 (2), 33..36 (1), 17..20 (5) -- and
+  // for the tiles whose fragments + both branches' accumulators fit 256 VGPRs.
+  const int njl = kk_steps - 8 * (Cfg<MB>::KS - 1);
+#define GWTF_PIPED(NJL_)                                                                                                    \
+  if (njl == NJL_) {                                                                                                        \
+    if (mode == GWTF_MODE_DIRECT) {                                                                                         \
+      if (lists) hipLaunchKernelGGL((stack_kernel<MB, NB, GWTF_MODE_DIRECT, true, NJL_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k, ex);   \
+      else hipLaunchKernelGGL((stack_kernel<MB, NB, GWTF_MODE_DIRECT, false, NJL_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k, ex);        \
+    } else {                                                                                                                \
+      if (lists) hipLaunchKernelGGL((stack_kernel<MB, NB, GWTF_MODE_INVERSE, true, NJL_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k, ex);  \
+      else hipLaunchKernelGGL((stack_kernel<MB, NB, GWTF_MODE_INVERSE, false, NJL_>), grid, block, 0, st, p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, kk_steps, jobs, p_stride_k, out_stride_k, ex);       \
+    }                                                                                                                       \
+    return (int)hipGetLastError();                                                                                          \
+  }
+  if (g_pipe) {
+    if constexpr (MB == 4 && NB <= 2) { GWTF_PIPED(8) }
+    if constexpr (MB == 3) { GWTF_PIPED(2) GWTF_PIPED(1) }
+    if constexpr (MB == 2) { GWTF_PIPED(5) }
+  }
+#undef GWTF_PIPED
   if (mode == GWTF_MODE_DIRECT) {
     if (lists) GWTF_LAUNCH(GWTF_MODE_DIRECT, true); else GWTF_LAUNCH(GWTF_MODE_DIRECT, false);
   } else {
@@ -361,10 +540,14 @@ int launch_nb(int nb, const float* p, const float* pw, const float* film, float*
 }
 
 int g_force_nb = 0;  // test/tuning hook, see gwtf_debug_set_points_per_wave
+int g_pipe = 1;      // test hook: 0 forces the generic (run-time k-slot count) coupling body
 
 }  // namespace
 
-extern "C" void gwtf_debug_set_points_per_wave(int pts) { g_force_nb = pts / 16; }
+extern "C" void gwtf_debug_set_points_per_wave(int pts) {   // bit 30 set: also force the generic coupling body
+  g_pipe = (pts & (1 << 30)) ? 0 : 1;
+  g_force_nb = (pts & 0xffff) / 16;
+}
 
 static int stack_dispatch(const float* p, const float* packed_w, const float* film, float* out, float* logdet, float* ps,
                           float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,

@@ -237,7 +237,9 @@ int gwtf_encoder_forward(const float* x, const float* packed, float* features, f
                          const int* widths, int n_widths, void* stream);
 
 /* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
- * (16, 32 or 64; anything else restores the size-based default).  Process-wide, not thread-safe. */
+ * (16, 32 or 64 in the low 16 bits; anything else restores the size-based default).  Bit 30 set: also force the generic
+ * coupling body instead of the software-pipelined one (the two are bit-identical; tests compare them).
+ * Process-wide, not thread-safe. */
 void gwtf_debug_set_points_per_wave(int points);
 
 #ifdef __cplusplus

@@ -728,3 +728,23 @@ def test_full_size_weight_gradient_directional_derivative(training):
                 vals.append(float(loss_fn()))
         fd = (vals[0] - vals[1]) / (2 * h)
         assert abs(fd - analytic[k]) < 3e-2 * abs(analytic[k]) + 2e-2, (k, fd, analytic[k])
+
+
+@pytest.mark.parametrize('L,f,G,B,N', [(2, 64, 32, 16, 2048), (2, 37, 32, 8, 1024), (2, 37, 32, 64, 2048), (2, 33, 64, 32, 2048),
+                                       (3, 19, 32, 32, 2048), (1, 19, 16, 2, 100), (1, 40, 16, 3, 700)])
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B, N, mode):
+    """The software-pipelined body (compile-time k-slot count: the shipped widths) reorders instructions, not arithmetic."""
+    m, _ = decoder_and_state(L, f, G, 77)
+    m = m.to(DEV).eval()
+    p, g = synth_inputs(B, N, G, 78)
+    pd, gd = dev(p), dev(g)
+    outs = []
+    for flag in (0, 1 << 30):
+        _lib.lib().gwtf_debug_set_points_per_wave(flag)
+        with torch.no_grad():
+            z, ld = m.forward_fused(pd, gd, mode)
+            ps, mus, lvs = m(pd, gd, mode=mode)
+        outs.append((z.clone(), ld.clone(), torch.stack(ps), torch.stack(lvs)))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
