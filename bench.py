@@ -204,7 +204,8 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            step(timers)
+            # graph mode: no event records inside the timed region (the per-kernel probe runs afterwards, eagerly)
+            step(timers if graph is None else None)
         sync_all()
         elapsed = time.perf_counter() - t0
     if dist is not None:
