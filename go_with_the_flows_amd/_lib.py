@@ -41,6 +41,7 @@ _SIGNATURES = {
     'gwtf_train_coupling_backward': (ctypes.c_int, [_c_fp] * 21 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_packed_b_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_pack_folded': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_backward': (ctypes.c_int, [_c_fp] * 23 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 11 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 4 + [_c_fp]),
     'gwtf_dw1_partials': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

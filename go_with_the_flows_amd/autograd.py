@@ -1,18 +1,20 @@
-"""Differentiable density pass (inverse direction) of a coupling stack: HIP forward + HIP backward.
+"""Differentiable density passes of a coupling stack: HIP forward + HIP backward behind torch.autograd.Function.
 
-Structure: the O(f^2 + B*f*G) "fold" that turns module parameters and the latent g into
-the folded quantities the kernels consume (BatchNorm folded into sd0/sd1, FiLM heads -> per-shape {c, u}) is a
-small torch graph -- elementwise ops and library GEMMs on (C,2,f,*) / (B,C,2,f) tensors, the same arithmetic as
-csrc/gwtf_pack.hip + csrc/gwtf_film.hip -- so autograd carries gradients from the folded quantities back to every
-reference parameter and to g.  Everything per point (the forward stack, and per coupling the recompute + dacc +
-dh = W1p^T dacc + sd0/FiLM-record gradient reductions + dx) is hand-written HIP (csrc/gwtf_stack.hip,
-csrc/gwtf_bwd.hip).  The f x f weight gradient sum_p dacc(p) h(p)^T is a plain GEMM over all points and goes
-to the BLAS library (torch.einsum -> rocBLAS).
+Structure (DESIGN.md sections 4.6 / 4.7).  Everything per point -- the forward stack and, per coupling, the recompute,
+dacc, dh = W1p^T dacc, the sd0 / FiLM-record gradient reductions, dx and the f x f weight gradient (accumulated inside
+the backward kernel, summed by gwtf_dw1_reduce) -- is hand-written HIP (csrc/gwtf_stack.hip, gwtf_bwd.hip,
+gwtf_train.hip).  What is O(f^2 + B*f*G) stays a small torch graph on views of ONE flat parameter arena: the "fold" from
+module parameters and the latent g to the quantities the kernels consume (BatchNorm folded into sd0 / sd1, FiLM heads ->
+per-shape {c, u}), so autograd carries the kernels' gradients to every reference parameter and to g.
 
-Scope: BatchNorm as a fixed affine (model.eval(): running statistics).  Batch-statistic BatchNorm adds
-gradient terms through the statistics; that backward is not built yet and train mode raises at backward().
-Reference semantics: loss.backward() through LocalCondRNVPDecoder.forward(mode='inverse'), training.py:54.
+  * eval BatchNorm (running statistics):  StackDensityFn                      -- one fused forward, one backward launch per coupling
+  * train BatchNorm, one rank:            TrainStackFn                        -- gwtf_train_forward / gwtf_train_backward
+  * train BatchNorm, several ranks:       MomentsFn / StatsFn / ApplyFn chain -- statistics all-reduced in both directions
+
+Reference semantics: loss.backward() through LocalCondRNVPDecoder.forward, training.py:54.
 """
+import ctypes
+
 import torch
 import torch.nn.functional as F
 
@@ -483,8 +485,6 @@ class TrainStackFn(torch.autograd.Function):
         B, _, N = p.shape
         dev = p.device
         R = _lib.STAT_REPLICAS
-        RC, PW, PB = L.gwtf_raw_coupling_floats(f, G), L.gwtf_packed_w_coupling_floats(f), L.gwtf_packed_b_coupling_floats(f)
-        br_size = RC // 2
         ps = lists[0]
         cur = (g_out if g_out is not None else torch.zeros_like(p)).contiguous().float()
         g_ld = (g_logdet if g_logdet is not None else torch.zeros_like(p)).contiguous().float()
@@ -497,33 +497,15 @@ class TrainStackFn(torch.autograd.Function):
         g_mom = torch.empty(C, 16, device=dev, dtype=torch.float32)
         ws = _lib.dw1_workspace(f, B, N, dev, passes=2)      # dW1 partials of the coupling and the statistics pass
         gxa, gxb = torch.empty_like(p), torch.empty_like(p)
-        bufs = [torch.empty_like(p), torch.empty_like(p)]
-        st = _lib._stream(p)
-        # raw device addresses (integer arithmetic instead of ~10 tensor slices per coupling: this loop is host-bound)
+        bufs = torch.empty(2, *p.shape, device=dev, dtype=torch.float32)
+        final = ctypes.c_int(0)
         P = lambda t: t.data_ptr()
-        a_raw, a_pw, a_pb, a_mom, a_ys, a_graw = P(raw), P(pw), P(pb), P(mom), P(ystats), P(g_raw)
-        a_gsd0, a_gbias, a_gstats, a_gmom = P(g_sd0), P(g_bias), P(g_stats), P(g_mom)
-        a_ps, a_p, ps_stride = P(ps), P(p), ps[0].numel() * 4
-        a_cur, a_gld, a_bufs = P(cur), P(g_ld), (P(bufs[0]), P(bufs[1]))
-        a_frec, a_fraw, a_gxa, a_gxb, a_ws, _unused, a_gfilm, a_gfraw = (P(film_rec), P(film_raw), P(gxa), P(gxb), P(ws), 0,
-                                                                      P(g_film), P(g_film_raw))
-        eps_f, mode_i = float(eps), _lib._MODES[mode]
         with torch.cuda.device(dev):
-            for c in (range(C) if inverse else range(C - 1, -1, -1)):   # reverse of the forward's processing order
-                step = C - 1 - c if inverse else c               # this coupling's position in the forward order
-                if inverse:
-                    x_in = a_ps + (c + 1) * ps_stride if c + 1 < C else a_p
-                else:
-                    x_in = a_ps + (c - 1) * ps_stride if c > 0 else a_p
-                nxt = a_bufs[c & 1]
-                g_raw_c = a_graw + c * RC * 4
-                _lib.check(L.gwtf_train_coupling_backward(
-                    x_in, a_cur, a_gld, a_raw + c * RC * 4, a_pw + c * PW * 4, a_pb + c * PB * 4, a_frec, a_fraw,
-                    a_mom + step * R * 16 * 4, a_ys + c * R * 2 * FP * 2 * 4, nxt, a_gxa, a_gxb, a_ws, a_gfilm,
-                    a_gsd0 + c * R * 2 * 3 * FP * 4, a_gbias + c * R * 4 * 4, a_gstats + c * 2 * 2 * FP * 4, a_gmom + c * 16 * 4,
-                    a_gfraw, g_raw_c, c, B, N, C, f, G, pattern0, eps_f, mode_i, st))
-                a_cur = nxt
-        cur = bufs[(C - 1) & 1] if inverse else bufs[0]          # written by the last coupling processed
+            _lib.check(L.gwtf_train_backward(
+                P(p), P(ps), P(cur), P(g_ld), P(raw), P(pw), P(pb), P(film_rec), P(film_raw), P(mom), P(ystats), P(bufs),
+                P(gxa), P(gxb), P(ws), P(g_film), P(g_sd0), P(g_bias), P(g_stats), P(g_mom), P(g_film_raw), P(g_raw),
+                ctypes.addressof(final), B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], _lib._stream(p)))
+        cur = bufs[final.value]
         return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None, None
 
 

@@ -487,3 +487,41 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   const GwtfRaw R(f, G);
   return gwtf_dw1_reduce(dw1_ws, 2, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, stream);
 }
+
+// Backward of the WHOLE train-mode stack (single rank): gwtf_train_coupling_backward for every coupling in the reverse of
+// the forward's processing order, ping-ponging dL/dx between the two halves of g_bufs.  Per-coupling slices of the
+// workspaces are addressed here (layouts as allocated by the forward / documented at gwtf_train_coupling_backward):
+//   ps [C][B][3][N] (the forward's list of coupling outputs), moments [C+1][64*16], ystats [C][64*2*FP*2],
+//   g_sd0 [C][64*2*3*FP], g_bias [C][64*4] (both zero on entry), g_stats [C][2*2*FP], g_mom [C][16], g_raw [C][raw record]
+// (zero on entry), g_bufs [2][B][3][N].  *final_buf receives the index (0/1) of the half of g_bufs that holds dL/dp.
+extern "C" int gwtf_train_backward(const float* p, const float* ps, const float* g_out, const float* g_ld, const float* raw,
+                                   const float* packed_w, const float* packed_b, const float* film_rec, const float* film_raw,
+                                   const float* moments, const float* ystats, float* g_bufs, float* g_xa, float* g_xb,
+                                   float* dw1_ws, float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom,
+                                   float* g_film_raw, float* g_raw, int* final_buf, int B, int N, int C, int f, int G,
+                                   int pattern0, float eps, int mode, void* stream) {
+  if (!p || !ps || !g_out || !g_ld || !raw || !packed_w || !packed_b || !moments || !ystats || !g_bufs || !g_sd0 || !g_bias ||
+      !g_stats || !g_mom || !g_raw || !final_buf || B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP)
+    return GWTF_E_BADARG;
+  const size_t FP = gwtf_padded_width(f), R = GWTF_STAT_REPLICAS, pts = (size_t)B * 3 * N;
+  const size_t RC = gwtf_raw_coupling_floats(f, G), PW = gwtf_packed_w_coupling_floats(f), PB = gwtf_packed_b_coupling_floats(f);
+  const bool inverse = mode == GWTF_MODE_INVERSE;
+  const float* cur = g_out;
+  int last = 0;
+  for (int i = 0; i < C; ++i) {
+    const int c = inverse ? i : C - 1 - i;                 // reverse of the forward's processing order
+    const int step = inverse ? C - 1 - c : c;              // this coupling's position in the forward order
+    const float* x_in = inverse ? (c + 1 < C ? ps + (size_t)(c + 1) * pts : p) : (c > 0 ? ps + (size_t)(c - 1) * pts : p);
+    float* nxt = g_bufs + (size_t)(c & 1) * pts;
+    const int rc = gwtf_train_coupling_backward(
+        x_in, cur, g_ld, raw + c * RC, packed_w + c * PW, packed_b + c * PB, film_rec, film_raw, moments + (size_t)step * R * 16,
+        ystats + (size_t)c * R * 2 * FP * 2, nxt, g_xa, g_xb, dw1_ws, g_film, g_sd0 + (size_t)c * R * 2 * 3 * FP,
+        g_bias + (size_t)c * R * 4, g_stats + (size_t)c * 2 * 2 * FP, g_mom + (size_t)c * 16, g_film_raw, g_raw + c * RC, c, B, N, C, f,
+        G, pattern0, eps, mode, stream);
+    if (rc) return rc;
+    cur = nxt;
+    last = c & 1;
+  }
+  *final_buf = last;
+  return 0;
+}

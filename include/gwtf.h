@@ -152,6 +152,16 @@ int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const fl
                                  int c, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
                                  void* stream);
 
+/* Backward of the whole single-rank train-mode stack: gwtf_train_coupling_backward for every coupling in reverse order
+ * (host loop in the library: one call per decoder instead of C).  Array layouts at the definition (csrc/gwtf_train.hip);
+ * *final_buf = which half of g_bufs [2][B][3][N] holds dL/dp. */
+int gwtf_train_backward(const float* p, const float* ps, const float* g_out, const float* g_ld, const float* raw,
+                        const float* packed_w, const float* packed_b, const float* film_rec, const float* film_raw,
+                        const float* moments, const float* ystats, float* g_bufs, float* g_xa, float* g_xb, float* dw1_ws,
+                        float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom, float* g_film_raw,
+                        float* g_raw, int* final_buf, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
+                        void* stream);
+
 /* Backward of gwtf_train_stats: g_stats [2][2][FP] = dL/d{sum y, sum y^2} per branch and feature (replicas already
  * summed by the caller) -> g_in (kept coordinates only); dw1_ws: this pass's dW1 partials (as gwtf_coupling_backward);
  * g_sd0 [64][2][3][FP] +=. */
