@@ -160,22 +160,6 @@ class CondRealNVPFlow3DTriple(nn.Module):
         return self._engine.run_lists(p, g, mode)
 
 
-class _NoBackwardYet(torch.autograd.Function):
-    """Keeps outputs attached to the graph so a training script fails loudly AT backward rather
-    than silently training nothing.  The HIP backward kernels replace this."""
-
-    @staticmethod
-    def forward(ctx, raw, p, g, *outs):
-        ctx.mark_non_differentiable()
-        return tuple(o.view_as(o) for o in outs)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError('go_with_the_flows_amd: backward is built for the density pass (mode="inverse") with '
-                                  'eval-mode BatchNorm only; train-mode BatchNorm / mode="direct" gradients are not '
-                                  'built yet (there is no autograd/CPU fallback)')
-
-
 class _ArenaCat(torch.autograd.Function):
     """raw arena = cat(flattened parameters / buffers) as ONE autograd node: forward concatenates cached detached views,
     backward hands every parameter its slice of the flat gradient (views, no kernels)."""
@@ -332,12 +316,7 @@ class StackEngine:
             pw, pf = self.packed(False)
             film = _lib.film_forward(gc, pf, self.C, self.f, eps, False)
             out, logdet, lists = _lib.stack_forward(pc, pw, film, self.C, self.f, self.pattern0, eps, mode, want_lists)
-        if needs_grad:
-            anchor = p if (p.requires_grad or g.requires_grad) else next(t for t in self._tracked if t.requires_grad)
-            res = _NoBackwardYet.apply(anchor, p, g, out, logdet, *([lists] if want_lists else []))
-            out, logdet = res[0], res[1]
-            lists = res[2] if want_lists else None
-        return out, logdet, lists
+        return out, logdet, lists                 # no-grad paths only: both differentiable cases returned above
 
     # -- train mode: batch-statistic BatchNorm ----------------------------------------------------------
     def _bn_modules(self):
