@@ -16,14 +16,15 @@ constexpr int kMaxK = 64;
 constexpr int kThreads = 256;
 constexpr int kPtsPerBlock = 512;    // 2 points per thread: (N/512) x B workgroups (8 k for 64 x 2048) keep all 256 CUs streaming
 
-__global__ __launch_bounds__(kThreads) void nll_kernel(const float* __restrict__ z, const float* __restrict__ logdet,
+__global__ __launch_bounds__(1024) void nll_kernel(const float* __restrict__ z, const float* __restrict__ logdet,
                                                        const float* __restrict__ mu0, const float* __restrict__ lv0,
                                                        const float* __restrict__ logits, float* __restrict__ point_lse,
                                                        float* __restrict__ nll_shape, int K, int B, int N) {
   __shared__ float s_logw[kMaxK];
   __shared__ float s_mu[kMaxK][3], s_lv[kMaxK][3], s_iv[kMaxK][3];
-  __shared__ float s_part[kThreads / 64];
+  __shared__ float s_part[16];
   const int b = blockIdx.y;
+  const int ppb = gridDim.x == 1 ? N : kPtsPerBlock;      // one workgroup per shape: the whole cloud, plain store at the end
   if (threadIdx.x < 64) {
     // log w = log(exp(logit)) - logsumexp(logits)   (losses.py:101-104)
     float m = -INFINITY;
@@ -43,8 +44,8 @@ __global__ __launch_bounds__(kThreads) void nll_kernel(const float* __restrict__
   __syncthreads();
   const float half_log2pi3 = 0.5f * 3.0f * 1.8378770664093453f;
   float local = 0.f;
-  const int n_end = min(N, (int)(blockIdx.x + 1) * kPtsPerBlock);
-  for (int n = blockIdx.x * kPtsPerBlock + threadIdx.x; n < n_end; n += blockDim.x) {
+  const int n_end = min(N, (int)(blockIdx.x + 1) * ppb);
+  for (int n = blockIdx.x * ppb + threadIdx.x; n < n_end; n += blockDim.x) {
     float m = -INFINITY, s = 0.f;  // online log-sum-exp over components
     for (int k = 0; k < K; ++k) {
       float qsum = 0.f;
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(kThreads) void nll_kernel(const float* __restrict__
   __syncthreads();
   if (threadIdx.x == 0) {
     float t = 0.f;
-    for (int w = 0; w < kThreads / 64; ++w) t += s_part[w];
-    atomicAdd(&nll_shape[b], -t);
+    for (int w = 0; w < (int)blockDim.x / 64; ++w) t += s_part[w];
+    if (gridDim.x == 1) nll_shape[b] = -t;
+    else atomicAdd(&nll_shape[b], -t);
   }
 }
 
@@ -189,6 +191,10 @@ extern "C" int gwtf_mixture_nll(const float* z, const float* logdet, const float
   if (K <= 0 || K > kMaxK || B <= 0 || N <= 0 || !z || !logdet || !mu0 || !lv0 || !logits || !nll_shape)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
+  if (N <= 4096 && B >= 16) {     // one 1024-thread workgroup per shape: no atomics, no memset node in front of the kernel
+    hipLaunchKernelGGL(nll_kernel, dim3(1, B), dim3(1024), 0, st, z, logdet, mu0, lv0, logits, point_lse, nll_shape, K, B, N);
+    return (int)hipGetLastError();
+  }
   hipError_t e = hipMemsetAsync(nll_shape, 0, sizeof(float) * (size_t)B, st);
   if (e != hipSuccess) return (int)e;
   const dim3 grid((N + kPtsPerBlock - 1) / kPtsPerBlock, B);
