@@ -55,13 +55,11 @@ def all_reduce_gradients(module, average=True, force=False):
     params = [p for p in module.parameters() if p.grad is not None]
     if not params:
         return 0
-    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    grads = [p.grad for p in params]
+    flat = torch.cat([g.reshape(-1) for g in grads])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat.div_(dist.get_world_size())
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
-        off += n
+    # scatter back with ONE multi-tensor copy (a per-parameter copy_ is ~650 launches for the airplane model)
+    torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split_with_sizes([g.numel() for g in grads]), grads)])
     return flat.numel()
