@@ -25,7 +25,7 @@ _SIGNATURES = {
     'gwtf_packed_w_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_packed_film_coupling_floats': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'gwtf_film_out_floats': (ctypes.c_size_t, [ctypes.c_int]),
-    'gwtf_pack_weights': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_pack_weights': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
     'gwtf_film_forward': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, _c_fp]),
@@ -117,14 +117,14 @@ def padded_width(f):
     return lib().gwtf_padded_width(f)
 
 
-def pack_weights(raw, C, f, G, training):
+def pack_weights(raw, C, f, G, training, pattern0=0):
     L = lib()
     pw = torch.empty(C * L.gwtf_packed_w_coupling_floats(f), device=raw.device, dtype=torch.float32)
     pf = torch.empty(C * L.gwtf_packed_film_coupling_floats(f, G), device=raw.device, dtype=torch.float32)
     if raw.numel() != C * L.gwtf_raw_coupling_floats(f, G):
         raise GwtfError(f'raw arena has {raw.numel()} floats, expected {C * L.gwtf_raw_coupling_floats(f, G)}')
     with torch.cuda.device(raw.device):
-        check(L.gwtf_pack_weights(_ptr(raw, 'raw'), _ptr(pw, 'packed_w'), _ptr(pf, 'packed_film'), C, f, G,
+        check(L.gwtf_pack_weights(_ptr(raw, 'raw'), _ptr(pw, 'packed_w'), _ptr(pf, 'packed_film'), C, f, G, int(pattern0),
                                   int(bool(training)), _stream(raw)))
     return pw, pf
 
@@ -240,7 +240,7 @@ def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum
     if Bg < 2:
         raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
     with torch.cuda.device(dev):
-        pw, pf = pack_weights(raw, C, f, G, True)
+        pw, pf = pack_weights(raw, C, f, G, True, pattern0)
         film_all, fstats = film_forward(gfull, pf, C, f, eps, True, want_stats=True)
         film_raw = film_all[row0:row0 + B].contiguous()
         mom = torch.zeros(C + 1, STAT_REPLICAS * 16, device=dev, dtype=torch.float32)

@@ -23,6 +23,26 @@ from . import _lib
 BN_EPS = 1e-5
 
 
+def _w0_view(rec, pattern0, C, f):
+    """sd0 weights of all couplings as (C,2,f,2).  The raw record holds sd0.weight as the module stores it: [f][2] for the
+    couplings that keep two coordinates (natural view) and [f][1] followed by f zeros for those that keep one.  Built with
+    slices only (no index tensors: the train step must stay hipGraph-capturable)."""
+    if C % 3 == 0 and pattern0 % 3 == 0:            # decoder stacks: Triples alternate between the two kinds
+        T, first_two = C // 3, (0 if pattern0 == 0 else 1)
+        r = rec.reshape(T, 3, 2, 2 * f)
+        out = rec.new_zeros(T, 3, 2, f, 2)
+        out[first_two::2] = r[first_two::2].reshape(-1, 3, 2, f, 2)
+        out[1 - first_two::2, :, :, :, 0] = r[1 - first_two::2][..., :f]
+        return out.reshape(C, 2, f, 2)
+    rows = []
+    for c in range(C):                              # single couplings / odd stacks: a handful of records
+        if (pattern0 + c) % 6 < 3:
+            rows.append(rec[c].reshape(2, f, 2))
+        else:
+            rows.append(torch.stack([rec[c][:, :f], torch.zeros_like(rec[c][:, :f])], dim=-1))
+    return torch.stack(rows)
+
+
 def _gather(engine, raw=None):
     """The couplings' parameters / buffers as (C,2,...) tensors, branch order (logvar, mu): VIEWS of the flat raw arena
     (engine.raw_arena(): one autograd-aware torch.cat in the record order of csrc/gwtf_layout.h GwtfRaw), so gathering
@@ -38,7 +58,7 @@ def _gather(engine, raw=None):
     o_hbn, o_l1, o_b1 = f * G, f * G + 4 * f, f * G + 4 * f + f * f
     return {
         'raw': raw,
-        'W0': rv[:, :, 0:2 * f].reshape(C, 2, 2, f).transpose(2, 3),                 # (C,2,f,2)  (stored transposed)
+        'W0': _w0_view(rv[:, :, 0:2 * f], engine.pattern0, C, f),                    # (C,2,f,2)
         'bn0': list(rv[:, :, o_bn0:o_w1].reshape(C, 2, 4, f).unbind(2)),             # weight, bias, mean, var
         'W1': rv[:, :, o_w1:o_bn1].reshape(C, 2, f, f),
         'bn1': list(rv[:, :, o_bn1:o_film].reshape(C, 2, 2, f).unbind(2)),           # mean, var
@@ -455,7 +475,7 @@ class TrainStackFn(torch.autograd.Function):
         film_raw[:, :, :, 1, :f] = bsh
         st = _lib._stream(p)
         with torch.cuda.device(dev):
-            pw, _pf = _lib.pack_weights(raw, C, f, G, True)
+            pw, _pf = _lib.pack_weights(raw, C, f, G, True, pattern0)
             pb = torch.zeros(C * PB, device=dev, dtype=torch.float32)
             _lib.check(L.gwtf_pack_w1t(raw.data_ptr(), pb.data_ptr(), C, f, G, st))
             mom = torch.zeros(C + 1, R * 16, device=dev, dtype=torch.float32)

@@ -5,9 +5,9 @@
 // RAW ARENA (input of gwtf_pack_weights): C coupling records in direct order, each made of
 // two branch records, branch 0 = logvar, branch 1 = mu.  A branch record is the reference's
 // parameters and BatchNorm buffers (lib/networks/flows.py:25-50 / 60-85) flattened row-major in
-// this order (k = kept coordinates padded to 2 with zeros, w = warped padded to 2 rows; sd0.weight is stored
-// TRANSPOSED so the padding is a tail, which lets the host build the arena with one torch.cat):
-//   sd0.weight^T[2][f] | sd0_bn.{weight,bias,running_mean,running_var}[f] | sd1.weight[f][f] |
+// this order (k = number of kept coordinates, 1 or 2, known from the coupling's warp pattern; w = warped padded to 2
+// rows; every tensor as the module stores it, so the host builds the arena from plain views with one torch.cat):
+//   sd0.weight[f][k] then (2-k)*f zeros | sd0_bn.{weight,bias,running_mean,running_var}[f] | sd1.weight[f][f] |
 //   sd1_bn.{running_mean,running_var}[f] |
 //   film_w0.weight[f][G] | film_w0_bn.{weight,bias,running_mean,running_var}[f] | film_w1.weight[f][f] | film_w1.bias[f] |
 //   film_b0.weight[f][G] | film_b0_bn.{...}[f] | film_b1.weight[f][f] | film_b1.bias[f] |
@@ -30,6 +30,8 @@ struct GwtfRaw {  // offsets inside one branch record
   int f, G;
   GWTF_HD GwtfRaw(int f_, int G_) : f(f_), G(G_) {}
   GWTF_HD size_t sd0_w() const { return 0; }
+  // sd0.weight[j][e] of a coupling with k kept coordinates (e < k; the record reserves 2*f floats either way)
+  GWTF_HD size_t sd0_w(int j, int e, int k) const { return (size_t)j * k + e; }
   GWTF_HD size_t bn0() const { return (size_t)2 * f; }              // gamma, beta, rm, rv
   GWTF_HD size_t sd1_w() const { return (size_t)6 * f; }
   GWTF_HD size_t bn1() const { return (size_t)6 * f + (size_t)f * f; }  // rm, rv
@@ -138,6 +140,7 @@ GWTF_HD size_t gwtf_film_out_size(int FP) { return 6 * (size_t)FP + 4; }
 
 // warp pattern of coupling c in direct order (reference flows.py:129-148, decoders.py:49-52):
 // index (pattern0 + c) % 6 -> 0:[0] 1:[1] 2:[2] 3:[0,1] 4:[0,2] 5:[1,2]
+GWTF_HD int gwtf_pattern_kept(int pat) { return pat < 3 ? 2 : 1; }
 GWTF_HD void gwtf_pattern_dims(int pat, int* k0, int* k1, int* w0, int* w1) {
   // kept dims (k1 = -1 when only... two kept -> both valid), warped dims (w1 = -1 when one warped)
   switch (pat) {

@@ -13,7 +13,7 @@ __device__ __forceinline__ float inv_std(float var) { return 1.0f / sqrtf(var + 
 
 // packed stack weights (split-f16 fragment images + sd0 parameters), see gwtf_layout.h
 __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__ out, int C, int f, int G, int FP,
-                              int training) {
+                              int training, int pattern0) {
   const GwtfRaw R(f, G);
   const GwtfPackW P(FP);
   const size_t per = P.coupling_size();
@@ -57,7 +57,8 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__
       if (ft < f && !training) {   // train: written per coupling by gwtf_train_fold0
         const float* bn = rb + R.bn0();
         const float s = bn[ft] * inv_std(bn[3 * f + ft]);
-        v = e < 2 ? rb[R.sd0_w() + (size_t)e * f + ft] * s : bn[f + ft] - bn[2 * f + ft] * s;
+        const int k = gwtf_pattern_kept((pattern0 + c) % 6);
+        v = e < 2 ? (e < k ? rb[R.sd0_w(ft, e, k)] * s : 0.f) : bn[f + ft] - bn[2 * f + ft] * s;
       }
     }
     out[idx] = v;
@@ -113,15 +114,16 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
 }  // namespace
 
 extern "C" int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film, int C, int f, int G,
-                                 int training, void* stream) {
-  if (C <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_w || !packed_film) return GWTF_E_BADARG;
+                                 int pattern0, int training, void* stream) {
+  if (C <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_w || !packed_film || pattern0 < 0 || pattern0 > 5)
+    return GWTF_E_BADARG;
   const int FP = gwtf_padded_width(f);
   hipStream_t st = (hipStream_t)stream;
   const int threads = 256;
   {
     const size_t total = GwtfPackW(FP).coupling_size() * (size_t)C;
     const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
-    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_w, C, f, G, FP, training);
+    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_w, C, f, G, FP, training, pattern0);
   }
   {
     const size_t total = GwtfPackF(FP, G).coupling_size() * (size_t)C;

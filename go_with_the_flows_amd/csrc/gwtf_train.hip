@@ -67,7 +67,8 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
   const double c00 = mom[mom2_index(k0, k0)] / n_total - e0 * e0;
   const double c11 = k1 >= 0 ? mom[mom2_index(k1, k1)] / n_total - e1 * e1 : 0.0;
   const double c01 = k1 >= 0 ? mom[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] / n_total - e0 * e1 : 0.0;
-  const double wa = rb[R.sd0_w() + j], wb = rb[R.sd0_w() + f + j];
+  const int kk = gwtf_pattern_kept(pat);
+  const double wa = rb[R.sd0_w(j, 0, kk)], wb = kk > 1 ? rb[R.sd0_w(j, 1, kk)] : 0.0;
   const double mean = wa * e0 + wb * e1;
   double var = wa * wa * c00 + 2.0 * wa * wb * c01 + wb * wb * c11;
   if (var < 0.0) var = 0.0;
@@ -374,7 +375,8 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kerne
     const GwtfRaw R(f, G);
     const float* rb = raw_c + (size_t)br * R.branch_size();
     float* grb = g_raw_c + (size_t)br * R.branch_size();
-    const double wa = rb[R.sd0_w() + j], wb = rb[R.sd0_w() + f + j];
+    const int kk = gwtf_pattern_kept(pat);
+    const double wa = rb[R.sd0_w(j, 0, kk)], wb = kk > 1 ? rb[R.sd0_w(j, 1, kk)] : 0.0;
     const double gamma = rb[R.bn0() + j];
     const double mean = wa * e0 + wb * e1;
     double var = wa * wa * c00 + 2.0 * wa * wb * c01 + wb * wb * c11;
@@ -389,8 +391,8 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kerne
     const double g_var = g_s * gamma * (-0.5) * isd * isd * isd;
     const double gwa = g0 * s + g_mean * e0 + g_var * 2.0 * (wa * c00 + wb * c01);
     const double gwb = g1 * s + g_mean * e1 + g_var * 2.0 * (wa * c01 + wb * c11);
-    grb[R.sd0_w() + j] = (float)gwa;
-    grb[R.sd0_w() + f + j] = k1 >= 0 ? (float)gwb : 0.f;
+    grb[R.sd0_w(j, 0, kk)] = (float)gwa;
+    if (kk > 1) grb[R.sd0_w(j, 1, kk)] = (float)gwb;      // k = 1: the second half of the reserved 2f floats stays zero
     grb[R.bn0() + j] = (float)(g_s * isd);       // d gamma
     grb[R.bn0() + f + j] = (float)gc;            // d beta
     red[t][0] = g_mean * wa;

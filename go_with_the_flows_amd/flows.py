@@ -75,14 +75,14 @@ class CondRealNVPFlow3D(nn.Module):
     # -- parameter gathering -------------------------------------------------------------------
     def raw_sources(self):
         """This coupling's record of the raw arena as (tensor, op) pairs in the order fixed by csrc/gwtf_layout.h;
-        op: None = flatten as is, 't' = transpose first, int n = n zeros (padding of the absent kept / warped slot)."""
+        op: None = flatten as is, int n = n zeros (padding of the absent kept / warped slot)."""
         out = []
         k, w = len(self.keep_inds), len(self.warp_inds)
         f = self.f_n_features
         for X in ('logvar', 'mu'):
             t0 = getattr(self, f'T_{X}_0')
             sd0, bn0, sd1, bn1 = t0[0], t0[1], t0[3], t0[4]
-            out += [(sd0.weight, 't')] + ([(None, f)] if k < 2 else [])
+            out += [(sd0.weight, None)] + ([(None, f)] if k < 2 else [])
             out += [(bn0.weight, None), (bn0.bias, None), (bn0.running_mean, None), (bn0.running_var, None),
                     (sd1.weight, None), (bn1.running_mean, None), (bn1.running_var, None)]
             for which in ('w', 'b'):
@@ -98,7 +98,7 @@ class CondRealNVPFlow3D(nn.Module):
     def raw_tensors(self):
         """Flattened tensors of this coupling's raw-arena record (see raw_sources)."""
         dev = self.eps.device
-        return [torch.zeros(op, device=dev) if t is None else (t[0].t().reshape(-1) if op == 't' else t.reshape(-1))
+        return [torch.zeros(op, device=dev) if t is None else t.reshape(-1)
                 for t, op in self.raw_sources()]
 
     def tracked_tensors(self):
@@ -180,8 +180,6 @@ class _ArenaCat(torch.autograd.Function):
             k += 1
             if not ctx.needs_input_grad[k]:
                 grads.append(None)
-            elif op == 't':                                   # stored as weight[0]^T: (k, f) -> (1, f, k)
-                grads.append(piece.view(t.shape[2], t.shape[1]).t().unsqueeze(0))
             else:
                 grads.append(piece.view(t.shape))
         return (None, *grads)
@@ -228,8 +226,7 @@ class StackEngine:
         # +2000 kernels per step).  The autograd link is one custom node instead (_ArenaCat below).
         if self._flat_key is None:
             z = self._zeros
-            self._flat = [z[op] if t is None else (None if op == 't' else t.detach().view(-1)) for t, op in self._srcs]
-            self._transposed = [i for i, (t, op) in enumerate(self._srcs) if op == 't']
+            self._flat = [z[op] if t is None else t.detach().view(-1) for t, op in self._srcs]
             self._sizes = [op if t is None else t.numel() for t, op in self._srcs]
             self._flat_key = True
         if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t, _ in self._srcs):
@@ -237,10 +234,7 @@ class StackEngine:
         return self._cat_detached()
 
     def _cat_detached(self):
-        flat = self._flat
-        for i in self._transposed:          # sd0.weight is stored transposed: a copy, so it is re-made every time
-            flat[i] = self._srcs[i][0].detach()[0].t().reshape(-1)
-        return torch.cat(flat)
+        return torch.cat(self._flat)
 
     def _collect(self):
         self._key(False)
@@ -258,7 +252,7 @@ class StackEngine:
         if key != self._cache_key:
             with torch.no_grad():
                 raw = self.raw_arena()
-                self._packed = _lib.pack_weights(raw, self.C, self.f, self.G, training)
+                self._packed = _lib.pack_weights(raw, self.C, self.f, self.G, training, self.pattern0)
             self._cache_key = key
         return self._packed
 

@@ -43,12 +43,14 @@ size_t gwtf_film_out_floats(int f);                   /* FiLM output per (shape,
  * Replaces the per-call parameter reads of nn.BatchNorm1d + SharedDot in
  * lib/networks/flows.py:25-50,60-85 (module construction) as consumed by :95-107.
  *   raw          [C][gwtf_raw_coupling_floats]   parameters + running statistics, direct order
+ *   pattern0     warp pattern index of coupling 0 (the raw record stores sd0.weight as the module does, [f][k] with
+ *                k = 1 or 2 kept coordinates: the packer needs each coupling's k)
  *   packed_w     [C][gwtf_packed_w_coupling_floats]
  *   packed_film  [C][gwtf_packed_film_coupling_floats]
  *   training     0: fold running statistics (model.eval()); 1: leave the per-shape FiLM BatchNorm
  *                un-folded so gwtf_film_forward takes batch statistics (model.train()). */
 int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film,
-                      int C, int f, int G, int training, void* stream);
+                      int C, int f, int G, int pattern0, int training, void* stream);
 
 /* Per-shape FiLM conditioning for all C couplings: the four Linear->BN->Swish->Linear heads of each
  * coupling applied to the latent g, then a = eps + exp(w(g)), b' = a*c1 + b(g).

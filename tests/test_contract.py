@@ -88,7 +88,7 @@ def test_no_cpu_fallback_and_bad_arguments():
     # bad arguments are rejected by the library itself before anything is launched
     L = _lib.lib()
     assert L.gwtf_stack_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 8, 0, 1e-6, 1, None) == 10001
-    assert L.gwtf_pack_weights(None, None, None, 1, 8, 16, 0, None) == 10001
+    assert L.gwtf_pack_weights(None, None, None, 1, 8, 16, 0, 0, None) == 10001
     assert L.gwtf_mixture_nll(None, None, None, None, None, None, None, 65, 1, 1, None) == 10001
 
 
