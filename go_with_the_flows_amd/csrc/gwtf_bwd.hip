@@ -400,7 +400,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
 #pragma unroll
         for (int mi = 0; mi < MB; ++mi)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) out[(16 * mi + 4 * q + r) * FP + 16 * ni + i16] = dw[mi][r] * down;
+          for (int r = 0; r < 4; ++r)   // streaming store: the partials are read once, by another kernel -- keep them out of L2
+            __builtin_nontemporal_store(dw[mi][r] * down, &out[(16 * mi + 4 * q + r) * FP + 16 * ni + i16]);
       }
     }
   }

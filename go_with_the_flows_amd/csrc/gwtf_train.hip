@@ -219,32 +219,33 @@ __global__ void pack_w1t_kernel(const float* __restrict__ raw, float* __restrict
   }
 }
 
-// thread = (branch, feature); one workgroup.  Writes g_a / g_bsh rows of this coupling, dW2, db2 and gS.
-constexpr int kFoldSlices = 8;   // the single workgroup of the fold backward kernels = 8 slices x (branch, feature)
+// Writes g_a / g_bsh rows of this coupling, dW2, db2 and gS.  Every (branch, feature) is independent: grid = (branch,
+// tile of 16 features), block = 16 slices (over shapes / statistic replicas) x 16 features, so the work that used to sit
+// on one CU (16 wavefronts time-slicing 4 SIMDs: 14 us) is spread over 2 * FP/16 of them.
+constexpr int kFoldSlices = 8;   // fold0_bwd_kernel: one workgroup of 8 slices x (branch, feature)
+constexpr int kF1Slices = 16;
 
-__global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kernel(
+__global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
     const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total, const float* __restrict__ film_raw,
     const float* __restrict__ g_film, const float* __restrict__ g_bias, float* __restrict__ g_film_raw,
     float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G, int FP) {
-  constexpr int TW = 2 * GWTF_MAX_FP;
-  __shared__ float st_part[kFoldSlices][TW][2];
-  __shared__ double acc_part[kFoldSlices][TW][4];
-  __shared__ float bias_part[kFoldSlices][4];
-  const int t = threadIdx.x % TW, sl = threadIdx.x / TW;
-  const bool lane_on = t < 2 * FP;
-  const int br = lane_on ? t / FP : 0, j = lane_on ? t % FP : 0;
-  const bool on = lane_on && j < f;
+  __shared__ float st_part[kF1Slices][16][2];
+  __shared__ double acc_part[kF1Slices][16][4];
+  __shared__ float bias_part[kF1Slices][2];
+  const int t = threadIdx.x % 16, sl = threadIdx.x / 16;
+  const int br = blockIdx.x, j = blockIdx.y * 16 + t;
+  const bool on = j < f;
   const GwtfRaw R(f, G);
   // every global load this thread needs is issued BEFORE the first barrier (one memory round trip instead of three):
   // its statistic replicas, and the FiLM records of its first kPre shapes (covers B <= 64; the rest loops normally)
-  constexpr int kPre = 8;
+  constexpr int kPre = 4;
   float pa[kPre], pb[kPre], pgc[kPre], pg0[kPre], pg1[kPre];
   const float* rb = raw_c + (size_t)br * R.branch_size();
   float* grb = g_raw_c + (size_t)br * R.branch_size();
   const float w20 = on ? rb[R.sd2_w() + j] : 0.f, w21 = on ? rb[R.sd2_w() + f + j] : 0.f;
 #pragma unroll
   for (int i = 0; i < kPre; ++i) {
-    const int b = sl + i * kFoldSlices;
+    const int b = sl + i * kF1Slices;
     const bool ok = on && b < B;
     const float* fr = film_raw + (((size_t)(ok ? b : 0) * C + c) * 2 + br) * 2 * FP;
     const float* gf = g_film + (((size_t)(ok ? b : 0) * C + c) * 2 + br) * 3 * FP;
@@ -254,22 +255,22 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
   {
     float ys = 0.f, yq = 0.f;
     if (on)
-      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) {
+      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) {
         ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
         yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
       }
     st_part[sl][t][0] = ys;
     st_part[sl][t][1] = yq;
-    if (lane_on && j < 2) {
+    if (blockIdx.y == 0 && t < 2) {
       float bsum = 0.f;
-      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) bsum += g_bias[r * 4 + 2 * br + j];
-      bias_part[sl][2 * br + j] = bsum;
+      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) bsum += g_bias[r * 4 + 2 * br + t];
+      bias_part[sl][t] = bsum;
     }
   }
   __syncthreads();
   float ys = 0.f, yq = 0.f;
 #pragma unroll
-  for (int i = 0; i < kFoldSlices; ++i) { ys += st_part[i][t][0]; yq += st_part[i][t][1]; }
+  for (int i = 0; i < kF1Slices; ++i) { ys += st_part[i][t][0]; yq += st_part[i][t][1]; }
   const double mean = ys / n_total;
   double var = yq / n_total - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -288,8 +289,8 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
   if (on) {
 #pragma unroll
     for (int i = 0; i < kPre; ++i)
-      if (sl + i * kFoldSlices < B) one(sl + i * kFoldSlices, pa[i], pb[i], pgc[i], pg0[i], pg1[i]);
-    for (int b = sl + kPre * kFoldSlices; b < B; b += kFoldSlices) {
+      if (sl + i * kF1Slices < B) one(sl + i * kF1Slices, pa[i], pb[i], pgc[i], pg0[i], pg1[i]);
+    for (int b = sl + kPre * kF1Slices; b < B; b += kF1Slices) {
       const float* fr = film_raw + (((size_t)b * C + c) * 2 + br) * 2 * FP;
       const float* gf = g_film + (((size_t)b * C + c) * 2 + br) * 3 * FP;
       one(b, fr[j], fr[FP + j], gf[j], gf[FP + j], gf[2 * FP + j]);
@@ -297,15 +298,15 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
   }
   acc_part[sl][t][0] = g_m1; acc_part[sl][t][1] = g_s1; acc_part[sl][t][2] = gw20; acc_part[sl][t][3] = gw21;
   __syncthreads();
-  if (sl != 0 || !lane_on) return;
-  if (!on) {
+  if (sl != 0) return;
+  if (!on) {                      // padded features of the last tile
     g_stats[(br * 2 + 0) * FP + j] = 0.f;
     g_stats[(br * 2 + 1) * FP + j] = 0.f;
     return;
   }
   g_m1 = g_s1 = gw20 = gw21 = 0.0;
 #pragma unroll
-  for (int i = 0; i < kFoldSlices; ++i) {
+  for (int i = 0; i < kF1Slices; ++i) {
     g_m1 += acc_part[i][t][0]; g_s1 += acc_part[i][t][1]; gw20 += acc_part[i][t][2]; gw21 += acc_part[i][t][3];
   }
   const double g_v1 = -0.5 * g_s1 * (double)s1 * s1 * s1;
@@ -313,11 +314,11 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold1_bwd_kerne
   g_stats[(br * 2 + 1) * FP + j] = (float)(g_v1 / n_total);
   grb[R.sd2_w() + j] = (float)gw20;
   grb[R.sd2_w() + f + j] = (float)gw21;
-  if (j < 2) {
+  if (blockIdx.y == 0 && t < 2) {
     float bsum = 0.f;
 #pragma unroll
-    for (int i = 0; i < kFoldSlices; ++i) bsum += bias_part[i][2 * br + j];
-    grb[R.sd2_b() + j] = bsum;
+    for (int i = 0; i < kF1Slices; ++i) bsum += bias_part[i][t];
+    grb[R.sd2_b() + t] = bsum;
   }
 }
 
@@ -477,7 +478,7 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dw1_ws, g_film, g_sd0,
                                   g_bias, c, B, N, C, f, pattern0, eps, mode, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(fold1_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
+  hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16), dim3(kF1Slices * 16), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
                      g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP);
   rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0, B, N,
                            f, pat, stream);
