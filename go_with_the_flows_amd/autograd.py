@@ -514,7 +514,7 @@ class TrainStackFn(torch.autograd.Function):
         g_sd0 = torch.zeros(C, R * 2 * 3 * FP, device=dev, dtype=torch.float32)
         g_bias = torch.zeros(C, R * 4, device=dev, dtype=torch.float32)
         g_stats = torch.empty(C, 2 * 2 * FP, device=dev, dtype=torch.float32)
-        g_mom = torch.empty(C, 16, device=dev, dtype=torch.float32)
+        g_mom = torch.empty(C, 96, device=dev, dtype=torch.float32)          # scratch: partial sums of the moment gradients
         ws = _lib.dw1_workspace(f, B, N, dev, passes=2)      # dW1 partials of the coupling and the statistics pass
         gxa, gxb = torch.empty_like(p), torch.empty_like(p)
         bufs = torch.empty(2, *p.shape, device=dev, dtype=torch.float32)

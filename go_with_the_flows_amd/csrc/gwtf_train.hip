@@ -222,7 +222,6 @@ __global__ void pack_w1t_kernel(const float* __restrict__ raw, float* __restrict
 // Writes g_a / g_bsh rows of this coupling, dW2, db2 and gS.  Every (branch, feature) is independent: grid = (branch,
 // tile of 16 features), block = 16 slices (over shapes / statistic replicas) x 16 features, so the work that used to sit
 // on one CU (16 wavefronts time-slicing 4 SIMDs: 14 us) is spread over 2 * FP/16 of them.
-constexpr int kFoldSlices = 8;   // fold0_bwd_kernel: one workgroup of 8 slices x (branch, feature)
 constexpr int kF1Slices = 16;
 
 __global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
@@ -322,26 +321,43 @@ __global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
   }
 }
 
-// one workgroup of 8 slices x (branch, feature).  g_sd0 replicas -> dW0, dgamma0, dbeta0 and the 9 moment gradients.
-__global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kernel(
+// moments of the kept coordinates (mean / covariance terms) from the 64 replicas of the 9 raw moments
+struct KeptMoments { double e0, e1, c00, c01, c11; };
+__device__ inline KeptMoments kept_moments(const float (&mom)[9], int k0, int k1, double n_total) {
+  auto M = [&](int i) { float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) v = u == i ? mom[u] : v;
+    return v; };
+  KeptMoments r;
+  r.e0 = M(k0) / n_total;
+  r.e1 = k1 >= 0 ? M(k1) / n_total : 0.0;
+  r.c00 = M(mom2_index(k0, k0)) / n_total - r.e0 * r.e0;
+  r.c11 = k1 >= 0 ? M(mom2_index(k1, k1)) / n_total - r.e1 * r.e1 : 0.0;
+  r.c01 = k1 >= 0 ? M(mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)) / n_total - r.e0 * r.e1 : 0.0;
+  return r;
+}
+
+// g_sd0 replicas -> dW0, dgamma0, dbeta0, and this workgroup's share of the five sums the moment gradients need.
+// Every (branch, feature) is independent up to those sums: grid = (branch, tile of 16 features), block = 16 slices (over
+// the replicas) x 16 features; the partial sums go to `part` [2][FP/16][5] doubles and combine_kernel finishes the job.
+__global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
     const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
-    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, float* __restrict__ g_mom, int f, int G, int FP) {
-  constexpr int TW = 2 * GWTF_MAX_FP;
-  const int t = threadIdx.x % TW, sl = threadIdx.x / TW;
-  __shared__ float mom_part[kFoldSlices][9];
-  __shared__ double gs_part[kFoldSlices][TW][3];
-  __shared__ double red[TW][5];   // per (branch, feature): gE0, gE1, gC00, gC01, gC11 contributions
-  const bool on = t < 2 * f;
-  const int br = on ? t / f : 0, j = on ? t % f : 0;
+    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP) {
+  const int t = threadIdx.x % 16, sl = threadIdx.x / 16;
+  const int br = blockIdx.x, j = blockIdx.y * 16 + t;
+  __shared__ float mom_part[kF1Slices][9];
+  __shared__ double gs_part[kF1Slices][16][3];
+  __shared__ double red[16][5];   // per feature: gE0, gE1, gC00, gC01, gC11 contributions
+  const bool on = j < f;
   if (t < 9) {
     float sacc = 0.f;
-    for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) sacc += mom_rep[r * 16 + t];
+    for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) sacc += mom_rep[r * 16 + t];
     mom_part[sl][t] = sacc;
   }
   {
     double g0 = 0.0, g1 = 0.0, gc = 0.0;
     if (on)
-      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kFoldSlices) {
+      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) {
         const float* gs = g_sd0 + (size_t)r * (2 * 3 * FP) + (size_t)br * 3 * FP;
         g0 += gs[j];
         g1 += gs[FP + j];
@@ -350,29 +366,22 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kerne
     gs_part[sl][t][0] = g0; gs_part[sl][t][1] = g1; gs_part[sl][t][2] = gc;
   }
   __syncthreads();
+  if (sl != 0) return;
   float mom[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     float v = 0.f;
 #pragma unroll
-    for (int r = 0; r < kFoldSlices; ++r) v += mom_part[r][i];
+    for (int r = 0; r < kF1Slices; ++r) v += mom_part[r][i];
     mom[i] = v;
   }
   int k0, k1, w0d, w1d;
   gwtf_pattern_dims(pat, &k0, &k1, &w0d, &w1d);
-  auto M = [&](int i) { float v = 0.f;
+  const KeptMoments km = kept_moments(mom, k0, k1, n_total);
+  const double e0 = km.e0, e1 = km.e1, c00 = km.c00, c01 = km.c01, c11 = km.c11;
 #pragma unroll
-    for (int u = 0; u < 9; ++u) v = u == i ? mom[u] : v;
-    return v; };
-  const double e0 = M(k0) / n_total, e1 = k1 >= 0 ? M(k1) / n_total : 0.0;
-  const double c00 = M(mom2_index(k0, k0)) / n_total - e0 * e0;
-  const double c11 = k1 >= 0 ? M(mom2_index(k1, k1)) / n_total - e1 * e1 : 0.0;
-  const double c01 = k1 >= 0 ? M(mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)) / n_total - e0 * e1 : 0.0;
-  if (sl == 0) {
-#pragma unroll
-    for (int i = 0; i < 5; ++i) red[t][i] = 0.0;
-  }
-  if (on && sl == 0) {
+  for (int i = 0; i < 5; ++i) red[t][i] = 0.0;
+  if (on) {
     const GwtfRaw R(f, G);
     const float* rb = raw_c + (size_t)br * R.branch_size();
     float* grb = g_raw_c + (size_t)br * R.branch_size();
@@ -386,7 +395,7 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kerne
     const double s = gamma * isd;
     double g0 = 0.0, g1 = 0.0, gc = 0.0;
 #pragma unroll
-    for (int r = 0; r < kFoldSlices; ++r) { g0 += gs_part[r][t][0]; g1 += gs_part[r][t][1]; gc += gs_part[r][t][2]; }
+    for (int r = 0; r < kF1Slices; ++r) { g0 += gs_part[r][t][0]; g1 += gs_part[r][t][1]; gc += gs_part[r][t][2]; }
     const double g_s = g0 * wa + g1 * wb - gc * mean;
     const double g_mean = -gc * s;
     const double g_var = g_s * gamma * (-0.5) * isd * isd * isd;
@@ -402,39 +411,60 @@ __global__ __launch_bounds__(kFoldSlices * 2 * GWTF_MAX_FP) void fold0_bwd_kerne
     red[t][3] = g_var * 2.0 * wa * wb;
     red[t][4] = g_var * wb * wb;
   }
-  __syncthreads();
-  __shared__ double r5s[5];
-  if (threadIdx.x < 5) {           // five sums over the 2f rows, four independent accumulators each
-    double a4[4] = {0.0, 0.0, 0.0, 0.0};
-    const int n = 2 * f;
-    int u = 0;
-    for (; u + 3 < n; u += 4) {
-      a4[0] += red[u][threadIdx.x]; a4[1] += red[u + 1][threadIdx.x]; a4[2] += red[u + 2][threadIdx.x]; a4[3] += red[u + 3][threadIdx.x];
-    }
-    for (; u < n; ++u) a4[0] += red[u][threadIdx.x];
-    r5s[threadIdx.x] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const double r5[5] = {r5s[0], r5s[1], r5s[2], r5s[3], r5s[4]};
-    for (int i = 0; i < 16; ++i) g_mom[i] = 0.f;
-    const double gC00 = r5[2], gC01 = r5[3], gC11 = r5[4];
-    const double gE0 = r5[0] - 2.0 * e0 * gC00 - e1 * gC01;
-    const double gE1 = r5[1] - 2.0 * e1 * gC11 - e0 * gC01;
-    g_mom[k0] = (float)(gE0 / n_total);
-    g_mom[mom2_index(k0, k0)] = (float)(gC00 / n_total);
-    if (k1 >= 0) {
-      g_mom[k1] = (float)(gE1 / n_total);
-      g_mom[mom2_index(k1, k1)] = (float)(gC11 / n_total);
-      g_mom[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] = (float)(gC01 / n_total);
-    }
+  // slice 0 is the 16 lanes of one wavefront quarter: LDS writes above are ordered before the reads below by the
+  // wavefront's in-order LDS queue + waitcnt (same wavefront, no barrier needed)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (t < 5) {
+    double acc = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += red[u][t];
+    part[((size_t)br * gridDim.y + blockIdx.y) * 5 + t] = acc;
   }
 }
 
-// g_in = g_a + g_b + d(moments)/dx:  gM_a + sum_b Q_ab x_b,  Q_aa = 2 gM_aa, Q_ab = gM_ab
+// g_in = g_a + g_b + d(moments)/dx:  gM_a + sum_b Q_ab x_b,  Q_aa = 2 gM_aa, Q_ab = gM_ab.  The nine moment gradients gM
+// are finished here from fold0_bwd_kernel's partial sums (every workgroup redoes the ~100 loads: cheaper than one more
+// single-workgroup kernel in the dependency chain).
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ x, const float* __restrict__ ga,
-                                                      const float* __restrict__ gb, const float* __restrict__ gm,
+                                                      const float* __restrict__ gb, const float* __restrict__ mom_rep,
+                                                      const double* __restrict__ part, int n_part, double n_total, int pat,
                                                       float* __restrict__ g_in, int B, int N) {
+  __shared__ float s_mom[9];
+  __shared__ double s_r5[5];
+  __shared__ float s_gm[16];
+  if (threadIdx.x < 9) {
+    float sacc = 0.f;
+    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) sacc += mom_rep[r * 16 + threadIdx.x];
+    s_mom[threadIdx.x] = sacc;
+  } else if (threadIdx.x >= 64 && threadIdx.x < 69) {
+    double acc = 0.0;
+    for (int u = 0; u < n_part; ++u) acc += part[(size_t)u * 5 + (threadIdx.x - 64)];
+    s_r5[threadIdx.x - 64] = acc;
+  }
+  if (threadIdx.x < 16) s_gm[threadIdx.x] = 0.f;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mom[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) mom[i] = s_mom[i];
+    int k0, k1, w0d, w1d;
+    gwtf_pattern_dims(pat, &k0, &k1, &w0d, &w1d);
+    const KeptMoments km = kept_moments(mom, k0, k1, n_total);
+    const double gC00 = s_r5[2], gC01 = s_r5[3], gC11 = s_r5[4];
+    const double gE0 = s_r5[0] - 2.0 * km.e0 * gC00 - km.e1 * gC01;
+    const double gE1 = s_r5[1] - 2.0 * km.e1 * gC11 - km.e0 * gC01;
+    s_gm[k0] = (float)(gE0 / n_total);
+    s_gm[mom2_index(k0, k0)] = (float)(gC00 / n_total);
+    if (k1 >= 0) {
+      s_gm[k1] = (float)(gE1 / n_total);
+      s_gm[mom2_index(k1, k1)] = (float)(gC11 / n_total);
+      s_gm[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] = (float)(gC01 / n_total);
+    }
+  }
+  __syncthreads();
+  const float* gm = s_gm;
   const int b = blockIdx.y;
   const float q00 = 2.f * gm[3], q01 = gm[4], q02 = gm[5], q11 = 2.f * gm[6], q12 = gm[7], q22 = 2.f * gm[8];
   for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
@@ -458,6 +488,7 @@ extern "C" int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, in
 // Backward of one coupling of the train-mode pipeline (single rank): coupling path, fold1, statistics path, fold0,
 // moments path, dW1 reduction.  dw1_ws: 2 * gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f) floats (the two backward
 // passes leave their per-workgroup dW1 partials in consecutive regions; both are summed into g_raw_c's sd1 blocks).
+// g_mom: 96 floats of 8-byte aligned scratch (partial sums of the moment gradients).
 // Workspaces g_sd0 [64][2][3][FP], g_bias [64][4] must be zero on entry; g_film [B][C][2][3][FP] is accumulated for
 // coupling c only (zero on entry).  g_raw_c receives dW0, dgamma0, dbeta0, dW1, dW2, db2 (other entries of the record are
 // left untouched).
@@ -483,10 +514,12 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0, B, N,
                            f, pat, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(fold0_bwd_kernel, dim3(1), dim3(kFoldSlices * 2 * GWTF_MAX_FP), 0, st, raw_c, moments_c, n_total, pat, g_sd0, g_raw_c,
-                     g_mom, f, G, FP);
+  double* part = reinterpret_cast<double*>(g_mom);          // [2][FP/16][5] doubles of scratch (<= 80 floats)
+  hipLaunchKernelGGL(fold0_bwd_kernel, dim3(2, FP / 16), dim3(kF1Slices * 16), 0, st, raw_c, moments_c, n_total, pat, g_sd0,
+                     g_raw_c, part, f, G, FP);
   const int bx = (N + 255) / 256;
-  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B), dim3(256), 0, st, x_in, g_xa, g_xb, g_mom, g_in, B, N);
+  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B), dim3(256), 0, st, x_in, g_xa, g_xb, moments_c, part,
+                     2 * (FP / 16), n_total, pat, g_in, B, N);
   const GwtfRaw R(f, G);
   return gwtf_dw1_reduce(dw1_ws, 2, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, stream);
 }
@@ -495,7 +528,7 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
 // the forward's processing order, ping-ponging dL/dx between the two halves of g_bufs.  Per-coupling slices of the
 // workspaces are addressed here (layouts as allocated by the forward / documented at gwtf_train_coupling_backward):
 //   ps [C][B][3][N] (the forward's list of coupling outputs), moments [C+1][64*16], ystats [C][64*2*FP*2],
-//   g_sd0 [C][64*2*3*FP], g_bias [C][64*4] (both zero on entry), g_stats [C][2*2*FP], g_mom [C][16], g_raw [C][raw record]
+//   g_sd0 [C][64*2*3*FP], g_bias [C][64*4] (both zero on entry), g_stats [C][2*2*FP], g_mom [C][96] (scratch), g_raw [C][raw record]
 // (zero on entry), g_bufs [2][B][3][N].  *final_buf receives the index (0/1) of the half of g_bufs that holds dL/dp.
 extern "C" int gwtf_train_backward(const float* p, const float* ps, const float* g_out, const float* g_ld, const float* raw,
                                    const float* packed_w, const float* packed_b, const float* film_rec, const float* film_raw,
@@ -519,7 +552,7 @@ extern "C" int gwtf_train_backward(const float* p, const float* ps, const float*
     const int rc = gwtf_train_coupling_backward(
         x_in, cur, g_ld, raw + c * RC, packed_w + c * PW, packed_b + c * PB, film_rec, film_raw, moments + (size_t)step * R * 16,
         ystats + (size_t)c * R * 2 * FP * 2, nxt, g_xa, g_xb, dw1_ws, g_film, g_sd0 + (size_t)c * R * 2 * 3 * FP,
-        g_bias + (size_t)c * R * 4, g_stats + (size_t)c * 2 * 2 * FP, g_mom + (size_t)c * 16, g_film_raw, g_raw + c * RC, c, B, N, C, f,
+        g_bias + (size_t)c * R * 4, g_stats + (size_t)c * 2 * 2 * FP, g_mom + (size_t)c * 96, g_film_raw, g_raw + c * RC, c, B, N, C, f,
         G, pattern0, eps, mode, stream);
     if (rc) return rc;
     cur = nxt;
