@@ -125,13 +125,18 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     xa[nb] = sel3(x[nb][0], x[nb][1], x[nb][2], k0);
     xb[nb] = KEEP2 ? sel3(x[nb][0], x[nb][1], x[nb][2], k1) : 0.f;
   }
+  // MERGE: a last k-step with at most 2 valid k-slots per lane (f = 33..40) carries its THREE products in ONE MFMA: the 8
+  // k-slots of a lane hold B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0] (built from
+  // the first dword of the two standard fragment images) -- 4 instead of 6 MFMAs per (m, point block) and 2 instead of 6
+  // filler moves per fragment.  (The legacy K=16 MFMA is no alternative: it costs the same 16 cycles, tools/diag/mfma_k16.hip.)
+  constexpr bool MERGE = KS == 2 && NJL <= 2;
   f16x8 bhi[2][KS][NB], blo[2][KS][NB];
 #pragma unroll
   for (int br = 0; br < 2; ++br)
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int e = 2 * PAIRS_LAST; e < 8; ++e) bhi[br][KS - 1][nb][e] = blo[br][KS - 1][nb][e] = (_Float16)0.f;
+      for (int e = MERGE ? 6 : 2 * PAIRS_LAST; e < 8; ++e) bhi[br][KS - 1][nb][e] = blo[br][KS - 1][nb][e] = (_Float16)0.f;
 
   auto unit = [&](int br, int u) {        // u-th (pair, point block) item of branch br
     const int per_ks = 4 * NB;
@@ -147,6 +152,11 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     pre[1] = fmaxf(pre[1], 0.f);
     f16x2 hi, lo;
     split_pair(pre, hi, lo);
+    if (MERGE && ks == KS - 1) {
+      f16x8& b = bhi[br][ks][nb];
+      b[0] = hi[0]; b[1] = hi[1]; b[2] = lo[0]; b[3] = lo[1]; b[4] = hi[0]; b[5] = hi[1];
+      return;
+    }
     bhi[br][ks][nb][j0] = hi[0]; bhi[br][ks][nb][j0 + 1] = hi[1];
     blo[br][ks][nb][j0] = lo[0]; blo[br][ks][nb][j0 + 1] = lo[1];
   };
@@ -154,6 +164,12 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   auto triple = [&](int br, int t) {      // t-th (ks, m, nb) triplet of branch br
     const int ks = t / (MB * NB), m = (t / NB) % MB, nb = t % NB;
     const float* aimg = L + br * K::A16 + lane * 4;
+    if (MERGE && ks == KS - 1) {
+      const float a_h = aimg[((ks * MB + m) * 2 + 0) * 256], a_l = aimg[((ks * MB + m) * 2 + 1) * 256];
+      const f32x4 am = {a_h, a_h, a_l, 0.f};
+      acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, am), bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
+      return;
+    }
     const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);
     const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 1) * 256);
     const f32x4 cinit = *reinterpret_cast<const f32x4*>(L + K::PW + br * 3 * FP + 4 * q + 16 * m);
