@@ -88,6 +88,33 @@ __device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br
     const float* sd0 = L + 2 * K::A16 + br * K::SD0 + q * 24;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+      if (KS == 2 && ks == 1 && nj_last <= 2) {
+        // a last k-step with at most 2 valid k-slots per lane (f = 33..40): its three products in ONE MFMA, the lane's 8
+        // k-slots holding B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0]
+        const f32x4* sp = reinterpret_cast<const f32x4*>(sd0 + ks * 96);
+        const f32x2 wa2 = {sp[0][0], sp[0][1]}, wb2 = {KEEP2 ? sp[2][0] : 0.f, KEEP2 ? sp[2][1] : 0.f}, cc2 = {sp[4][0], sp[4][1]};
+        f16x8 bm[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
+          f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
+                            : __builtin_elementwise_fma(wa2, xa2, cc2);
+          pre[0] = fmaxf(pre[0], 0.f);
+          pre[1] = fmaxf(pre[1], 0.f);
+          f16x2 hi, lo;
+          split_pair(pre, hi, lo);
+          bm[nb] = f16x8{hi[0], hi[1], lo[0], lo[1], hi[0], hi[1], (_Float16)0.f, (_Float16)0.f};
+        }
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          const float a_h = aimg[((ks * MB + m) * 2 + 0) * 256], a_l = aimg[((ks * MB + m) * 2 + 1) * 256];
+          const f32x4 am = {a_h, a_h, a_l, 0.f};
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb)
+            acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, am), bm[nb], acc[m][nb], 0, 0, 0);
+        }
+        continue;
+      }
       // sd0 + sd0_bn + ReLU for this lane's 8 k positions (features 32*ks + 4*j + q), split into f16 hi/lo
       const f32x4* sp = reinterpret_cast<const f32x4*>(sd0 + ks * 96);
       const f32x4 wa[2] = {sp[0], sp[1]};
