@@ -130,13 +130,20 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   // the first dword of the two standard fragment images) -- 4 instead of 6 MFMAs per (m, point block) and 2 instead of 6
   // filler moves per fragment.  (The legacy K=16 MFMA is no alternative: it costs the same 16 cycles, tools/diag/mfma_k16.hip.)
   constexpr bool MERGE = KS == 2 && NJL <= 2;
+  // PACK5: a single k-step with 5 valid k-slots per lane (f = 17..20) has 15 products for 16 k-slots of TWO MFMAs:
+  //   B1 = [hi01 | hi23 | lo01 | lo23]        against  A1 = [Whi01 | Whi23 | Whi01 | Whi23]
+  //   B2 = [(hi4, lo4) | hi01 | hi23 | (hi4, 0)]  against  A2 = [(Whi4, Whi4) | Wlo01 | Wlo23 | (Wlo4, 0)]
+  // (held in bhi[..] / blo[..]); 2 instead of 3 MFMAs per (m, point block).
+  constexpr bool PACK5 = KS == 1 && NJL == 5;
   f16x8 bhi[2][KS][NB], blo[2][KS][NB];
+  if (!PACK5) {
 #pragma unroll
-  for (int br = 0; br < 2; ++br)
+    for (int br = 0; br < 2; ++br)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb)
+      for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-      for (int e = MERGE ? 6 : 2 * PAIRS_LAST; e < 8; ++e) bhi[br][KS - 1][nb][e] = blo[br][KS - 1][nb][e] = (_Float16)0.f;
+        for (int e = MERGE ? 6 : 2 * PAIRS_LAST; e < 8; ++e) bhi[br][KS - 1][nb][e] = blo[br][KS - 1][nb][e] = (_Float16)0.f;
+  }
 
   auto unit = [&](int br, int u) {        // u-th (pair, point block) item of branch br
     const int per_ks = 4 * NB;
@@ -146,12 +153,30 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     const f32x4 wa = sp[j0 >> 2], wb = KEEP2 ? sp[2 + (j0 >> 2)] : f32x4{0.f, 0.f, 0.f, 0.f}, cc = sp[4 + (j0 >> 2)];
     const f32x2 wa2 = {wa[j0 & 3], wa[(j0 & 3) + 1]}, wb2 = {wb[j0 & 3], wb[(j0 & 3) + 1]}, cc2 = {cc[j0 & 3], cc[(j0 & 3) + 1]};
     const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
+    if (PACK5 && jp == 2) {                // the odd fifth k-slot: (hi4, lo4) and (hi4, 0)
+      const float p4 = fmaxf(KEEP2 ? fmaf(wa2[0], xa[nb], fmaf(wb2[0], xb[nb], cc2[0])) : fmaf(wa2[0], xa[nb], cc2[0]), 0.f);
+      const f32x2 p40 = {p4, 0.f};
+      const f16x2 y = __builtin_convertvector(p40, f16x2);
+      float r4;
+      asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r4) : "v"(__builtin_bit_cast(unsigned, y)), "v"(p4));
+      const f32x2 p4r = {p4, r4};
+      const f16x2 xx = __builtin_convertvector(p4r, f16x2);
+      f16x8& b2 = blo[br][0][nb];
+      b2[0] = xx[0]; b2[1] = xx[1]; b2[6] = y[0]; b2[7] = y[1];
+      return;
+    }
     f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
                       : __builtin_elementwise_fma(wa2, xa2, cc2);
     pre[0] = fmaxf(pre[0], 0.f);
     pre[1] = fmaxf(pre[1], 0.f);
     f16x2 hi, lo;
     split_pair(pre, hi, lo);
+    if (PACK5) {
+      f16x8& b1 = bhi[br][0][nb];
+      f16x8& b2 = blo[br][0][nb];
+      b1[j0] = hi[0]; b1[j0 + 1] = hi[1]; b1[4 + j0] = lo[0]; b1[5 + j0] = lo[1]; b2[2 + j0] = hi[0]; b2[3 + j0] = hi[1];
+      return;
+    }
     if (MERGE && ks == KS - 1) {
       f16x8& b = bhi[br][ks][nb];
       b[0] = hi[0]; b[1] = hi[1]; b[2] = lo[0]; b[3] = lo[1]; b[4] = hi[0]; b[5] = hi[1];
@@ -164,6 +189,18 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   auto triple = [&](int br, int t) {      // t-th (ks, m, nb) triplet of branch br
     const int ks = t / (MB * NB), m = (t / NB) % MB, nb = t % NB;
     const float* aimg = L + br * K::A16 + lane * 4;
+    if (PACK5) {
+      const f32x2 ah = *reinterpret_cast<const f32x2*>(aimg + (m * 2 + 0) * 256);
+      const float ah2 = aimg[(m * 2 + 0) * 256 + 2];   // its own load: with ONE b128 load, hipcc 7.2 built a1 in place over element 2 before this use
+      const f32x4 al = *reinterpret_cast<const f32x4*>(aimg + (m * 2 + 1) * 256);
+      const f32x4 cinit = *reinterpret_cast<const f32x4*>(L + K::PW + br * 3 * FP + 4 * q + 16 * m);
+      const unsigned w4 = __builtin_bit_cast(unsigned, ah2);                      // (Whi4, 0)
+      const unsigned w44 = __builtin_amdgcn_perm(w4, w4, 0x05040100u);            // (Whi4, Whi4)
+      const f32x4 a1 = {ah[0], ah[1], ah[0], ah[1]}, a2 = {__builtin_bit_cast(float, w44), al[0], al[1], al[2]};
+      acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a1), bhi[br][0][nb], cinit, 0, 0, 0);
+      acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a2), blo[br][0][nb], acc[br][m][nb], 0, 0, 0);
+      return;
+    }
     if (MERGE && ks == KS - 1) {
       const float a_h = aimg[((ks * MB + m) * 2 + 0) * 256], a_l = aimg[((ks * MB + m) * 2 + 1) * 256];
       const f32x4 am = {a_h, a_h, a_l, 0.f};

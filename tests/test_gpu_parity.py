@@ -735,8 +735,8 @@ def test_full_size_weight_gradient_directional_derivative(training):
 @pytest.mark.parametrize('mode', ['direct', 'inverse'])
 def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B, N, mode):
     """The software-pipelined body (compile-time k-slot count: the shipped widths) reorders instructions, not arithmetic --
-    except for f = 33..40, where the last k-step's three split-f16 products ride in ONE MFMA (same products, summed in a
-    different order inside the matrix unit): there the two bodies agree to fp32 rounding."""
+    except for f = 33..40 and f = 17..20, where the short k-step's split-f16 products are packed into fewer MFMAs (same
+    products, summed in a different order inside the matrix unit): there the two bodies agree to fp32 rounding."""
     m, _ = decoder_and_state(L, f, G, 77)
     m = m.to(DEV).eval()
     p, g = synth_inputs(B, N, G, 78)
@@ -749,7 +749,7 @@ def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B,
             ps, mus, lvs = m(pd, gd, mode=mode)
         outs.append((z.clone(), ld.clone(), torch.stack(ps), torch.stack(lvs)))
     for a, b in zip(*outs):
-        if 33 <= f <= 40:
+        if 33 <= f <= 40 or 17 <= f <= 20:
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
         else:
             assert torch.equal(a, b)
