@@ -135,6 +135,12 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   //   B2 = [(hi4, lo4) | hi01 | hi23 | (hi4, 0)]  against  A2 = [(Whi4, Whi4) | Wlo01 | Wlo23 | (Wlo4, 0)]
   // (held in bhi[..] / blo[..]); 2 instead of 3 MFMAs per (m, point block).
   constexpr bool PACK5 = KS == 1 && NJL == 5;
+  // RV: the last 16-row tile holds at most 4*RV valid output features (f <= 4*(8*(KS-1)+NJL)).  Its rows are dealt to the
+  // accumulator TRANSPOSED -- the lane with row slot (q', r) reads the fragment image of row 4r+q' -- so that features
+  // 16m+4r+q' land in register r of quarter q' and registers r >= RV are padding in EVERY lane: the epilogue skips them.
+  constexpr int RV = (4 * (8 * (KS - 1) + NJL) - 16 * (MB - 1) + 3) / 4 < 4 ? (4 * (8 * (KS - 1) + NJL) - 16 * (MB - 1) + 3) / 4 : 4;
+  static_assert(RV >= 1, "the last row tile would be empty");
+  const int lane_t = (lane & 48) | ((lane & 3) << 2) | ((lane >> 2) & 3);
   f16x8 bhi[2][KS][NB], blo[2][KS][NB];
   if (!PACK5) {
 #pragma unroll
@@ -188,12 +194,14 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   f32x4 acc[2][MB][NB];
   auto triple = [&](int br, int t) {      // t-th (ks, m, nb) triplet of branch br
     const int ks = t / (MB * NB), m = (t / NB) % MB, nb = t % NB;
-    const float* aimg = L + br * K::A16 + lane * 4;
+    const bool tr = RV < 4 && m == MB - 1;                       // transposed row tile
+    const float* aimg = L + br * K::A16 + (tr ? lane_t : lane) * 4;
+    const float* cb = L + K::PW + br * 3 * FP + 16 * m;
+    const f32x4 cinit = tr ? f32x4{cb[q], cb[4 + q], cb[8 + q], cb[12 + q]} : *reinterpret_cast<const f32x4*>(cb + 4 * q);
     if (PACK5) {
       const f32x2 ah = *reinterpret_cast<const f32x2*>(aimg + (m * 2 + 0) * 256);
       const float ah2 = aimg[(m * 2 + 0) * 256 + 2];   // its own load: with ONE b128 load, hipcc 7.2 built a1 in place over element 2 before this use
       const f32x4 al = *reinterpret_cast<const f32x4*>(aimg + (m * 2 + 1) * 256);
-      const f32x4 cinit = *reinterpret_cast<const f32x4*>(L + K::PW + br * 3 * FP + 4 * q + 16 * m);
       const unsigned w4 = __builtin_bit_cast(unsigned, ah2);                      // (Whi4, 0)
       const unsigned w44 = __builtin_amdgcn_perm(w4, w4, 0x05040100u);            // (Whi4, Whi4)
       const f32x4 a1 = {ah[0], ah[1], ah[0], ah[1]}, a2 = {__builtin_bit_cast(float, w44), al[0], al[1], al[2]};
@@ -209,7 +217,6 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     }
     const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);
     const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 1) * 256);
-    const f32x4 cinit = *reinterpret_cast<const f32x4*>(L + K::PW + br * 3 * FP + 4 * q + 16 * m);
     acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[br][ks][nb], ks == 0 ? cinit : acc[br][m][nb], 0, 0, 0);
     acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[br][ks][nb], acc[br][m][nb], 0, 0, 0);
     acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
@@ -221,8 +228,10 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     for (int nb = 0; nb < NB; ++nb) o0[br][nb] = o1[br][nb] = 0.f;
   auto dot_piece = [&](int br, int pc) {  // ReLU + sd2 dot for accumulator row (m, r) and HALF of the point blocks: pc = ((m*4+r)*2+h)
     const int m = pc / 8, r = (pc / 2) % 4, h = pc % 2;
-    const float* fe = L + K::PW + br * 3 * FP + 4 * q;
-    const float u0 = fe[FP + 16 * m + r], u1 = KEEP2 ? 0.f : fe[2 * FP + 16 * m + r];
+    const bool tr = RV < 4 && m == MB - 1;
+    if (tr && r >= RV) return;                                   // padding in every lane
+    const float* fe = L + K::PW + br * 3 * FP + 16 * m + (tr ? 4 * r + q : 4 * q + r);
+    const float u0 = fe[FP], u1 = KEEP2 ? 0.f : fe[2 * FP];
 #pragma unroll
     for (int nb = h * (NB / 2 > 0 ? NB / 2 : 1); nb < (NB >= 2 ? (h + 1) * (NB / 2) : (h == 0 ? 1 : 0)); ++nb) {
       const float v = fmaxf(acc[br][m][nb][r], 0.f);
@@ -274,6 +283,14 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   // stage D: what is left of branch 1's dot
 #pragma unroll
   for (int pc = (EARLYDOT ? (MB - 1) * 8 : 0); pc < PIECES; ++pc) dot_piece(1, pc);
+  if (RV < 4) {
+    // The skipped registers of the transposed tiles are dead MFMA outputs: keep the whole tuples allocated until here, or
+    // the register allocator hands them to other values while the MFMA that still writes them is in flight.
+#pragma unroll
+    for (int br = 0; br < 2; ++br)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(acc[br][MB - 1][nb]));
+  }
   float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
   for (int br = 0; br < 2; ++br) {
