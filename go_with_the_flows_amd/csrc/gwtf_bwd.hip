@@ -450,11 +450,12 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
         const int jo = 16 * m + (lane & 15);
         _Float16 e[2] = {(_Float16)0.f, (_Float16)0.f};
         if (ks < KS && jo < f) {
+          const GwtfA16Slot sl = gwtf_a16_slot(f, KS, ks, part, jp);
           for (int t = 0; t < 2; ++t) {
-            const int ji = 32 * ks + 4 * (2 * jp + t) + (lane >> 4);
-            const float w = ji < f ? W1p[(((size_t)c * 2 + br) * f + jo) * f + ji] : 0.f;
+            const int ji = 32 * ks + 4 * (2 * sl.jsrc + t) + (lane >> 4);
+            const float w = (ji < f && !sl.zero) ? W1p[(((size_t)c * 2 + br) * f + jo) * f + ji] : 0.f;
             const _Float16 hi = (_Float16)w;
-            e[t] = part == 0 ? hi : (_Float16)(w - (float)hi);
+            e[t] = sl.lo ? (_Float16)(w - (float)hi) : hi;
           }
         }
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));

@@ -90,7 +90,8 @@ __device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br
     for (int ks = 0; ks < KS; ++ks) {
       if (KS == 2 && ks == 1 && nj_last <= 2) {
         // a last k-step with at most 2 valid k-slots per lane (f = 33..40): its three products in ONE MFMA, the lane's 8
-        // k-slots holding B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0]
+        // k-slots holding B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0] (the hi image of
+        // this k-step as gwtf_pack.hip writes it for these widths)
         const f32x4* sp = reinterpret_cast<const f32x4*>(sd0 + ks * 96);
         const f32x2 wa2 = {sp[0][0], sp[0][1]}, wb2 = {KEEP2 ? sp[2][0] : 0.f, KEEP2 ? sp[2][1] : 0.f}, cc2 = {sp[4][0], sp[4][1]};
         f16x8 bm[NB];
@@ -107,11 +108,9 @@ __device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
-          const float a_h = aimg[((ks * MB + m) * 2 + 0) * 256], a_l = aimg[((ks * MB + m) * 2 + 1) * 256];
-          const f32x4 am = {a_h, a_h, a_l, 0.f};
+          const f16x8 am = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);   // A', written by the packer
 #pragma unroll
-          for (int nb = 0; nb < NB; ++nb)
-            acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, am), bm[nb], acc[m][nb], 0, 0, 0);
+          for (int nb = 0; nb < NB; ++nb) acc[m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bm[nb], acc[m][nb], 0, 0, 0);
         }
         continue;
       }

@@ -59,7 +59,20 @@ struct GwtfRaw {  // offsets inside one branch record
 //                                           W = sd1.weight with sd1_bn's 1/sqrt(var+eps) folded into its rows
 //   SD0[branch][ks][q][3][8] f32          : {w0[.][0]*s, w0[.][1]*s, beta - mean*s} for features 32*ks + 4*j + q,
 //                                           s = gamma/sqrt(var+eps) of sd0_bn
+// Exception (f = 33..40: the second k-step has at most two valid k positions per lane): that k-step is contracted by ONE
+// MFMA against B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0], and its hi image holds A' = [W_hi (2) | W_hi (2) | W_lo (2) | 0 0]
+// -- slot pair 0 as above, pairs 1-2 in place of the zeros that pad a short k-step; the lo image is unchanged.
 // The record is padded to a whole number of 1-KiB LDS-DMA pieces.
+struct GwtfA16Slot { int jsrc; bool lo, zero; };
+// float slot jp (= k positions 2jp, 2jp+1) of image `part` of k-step ks: which pair of k positions, and which f16 part, it holds
+GWTF_HD inline GwtfA16Slot gwtf_a16_slot(int f, int KS, int ks, int part, int jp) {
+  const bool merged = KS == 2 && ks == 1 && (f + 3) / 4 - 8 <= 2 && part == 0;
+  GwtfA16Slot s;
+  s.jsrc = merged ? 0 : jp;
+  s.lo = merged ? jp == 2 : part == 1;
+  s.zero = merged && jp == 3;
+  return s;
+}
 struct GwtfPackW {
   int FP;
   GWTF_HD GwtfPackW(int FP_) : FP(FP_) {}

@@ -37,13 +37,14 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__
       __half2 pk = __floats2half2_rn(0.f, 0.f);
       if (ks < KS && jo < f) {
         const float sc = training ? 1.0f : inv_std(rb[R.bn1() + f + jo]);   // train: sd1_bn is applied via fold1
+        const GwtfA16Slot sl = gwtf_a16_slot(f, KS, ks, part, jp);   // f = 33..40: merged image of the short k-step
         float e[2];
         for (int t = 0; t < 2; ++t) {
-          const int ji = 32 * ks + 4 * (2 * jp + t) + (lane >> 4);  // input feature
+          const int ji = 32 * ks + 4 * (2 * sl.jsrc + t) + (lane >> 4);  // input feature
           float w = 0.f;
-          if (ji < f) w = rb[R.sd1_w() + (size_t)jo * f + ji] * sc;
+          if (ji < f && !sl.zero) w = rb[R.sd1_w() + (size_t)jo * f + ji] * sc;
           const float hi = __half2float(__float2half_rn(w));
-          e[t] = part == 0 ? hi : (w - hi);
+          e[t] = sl.lo ? (w - hi) : hi;
         }
         pk = __floats2half2_rn(e[0], e[1]);
       }

@@ -126,9 +126,9 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     xb[nb] = KEEP2 ? sel3(x[nb][0], x[nb][1], x[nb][2], k1) : 0.f;
   }
   // MERGE: a last k-step with at most 2 valid k-slots per lane (f = 33..40) carries its THREE products in ONE MFMA: the 8
-  // k-slots of a lane hold B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0] (built from
-  // the first dword of the two standard fragment images) -- 4 instead of 6 MFMAs per (m, point block) and 2 instead of 6
-  // filler moves per fragment.  (The legacy K=16 MFMA is no alternative: it costs the same 16 cycles, tools/diag/mfma_k16.hip.)
+  // k-slots of a lane hold B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0] (the hi image
+  // of that k-step as gwtf_pack.hip writes it for these widths) -- 4 instead of 6 MFMAs per (m, point block) and 2 instead
+  // of 6 filler moves per fragment.  (The legacy K=16 MFMA is no alternative: it costs the same 16 cycles, tools/diag/mfma_k16.hip.)
   constexpr bool MERGE = KS == 2 && NJL <= 2;
   // PACK5: a single k-step with 5 valid k-slots per lane (f = 17..20) has 15 products for 16 k-slots of TWO MFMAs:
   //   B1 = [hi01 | hi23 | lo01 | lo23]        against  A1 = [Whi01 | Whi23 | Whi01 | Whi23]
@@ -210,9 +210,8 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
       return;
     }
     if (MERGE && ks == KS - 1) {
-      const float a_h = aimg[((ks * MB + m) * 2 + 0) * 256], a_l = aimg[((ks * MB + m) * 2 + 1) * 256];
-      const f32x4 am = {a_h, a_h, a_l, 0.f};
-      acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, am), bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
+      const f16x8 am = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);   // A', written by the packer
+      acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
       return;
     }
     const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);
