@@ -135,6 +135,7 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   //   B2 = [(hi4, lo4) | hi01 | hi23 | (hi4, 0)]  against  A2 = [(Whi4, Whi4) | Wlo01 | Wlo23 | (Wlo4, 0)]
   // (held in bhi[..] / blo[..]); 2 instead of 3 MFMAs per (m, point block).
   constexpr bool PACK5 = KS == 1 && NJL == 5;
+  constexpr bool PKDOT = true;
   // RV: the last 16-row tile holds at most 4*RV valid output features (f <= 4*(8*(KS-1)+NJL)).  Its rows are dealt to the
   // accumulator TRANSPOSED -- the lane with row slot (q', r) reads the fragment image of row 4r+q' -- so that features
   // 16m+4r+q' land in register r of quarter q' and registers r >= RV are padding in EVERY lane: the epilogue skips them.
@@ -221,10 +222,14 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
   };
   float o0[2][NB], o1[2][NB];
+  f32x2 o01[2][NB];                       // !KEEP2: both warped coordinates' sums as one packed-FMA chain
 #pragma unroll
   for (int br = 0; br < 2; ++br)
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) o0[br][nb] = o1[br][nb] = 0.f;
+    for (int nb = 0; nb < NB; ++nb) {
+      o0[br][nb] = o1[br][nb] = 0.f;
+      o01[br][nb] = f32x2{0.f, 0.f};
+    }
   auto dot_piece = [&](int br, int pc) {  // ReLU + sd2 dot for accumulator row (m, r) and HALF of the point blocks: pc = ((m*4+r)*2+h)
     const int m = pc / 8, r = (pc / 2) % 4, h = pc % 2;
     const bool tr = RV < 4 && m == MB - 1;
@@ -234,8 +239,15 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
 #pragma unroll
     for (int nb = h * (NB / 2 > 0 ? NB / 2 : 1); nb < (NB >= 2 ? (h + 1) * (NB / 2) : (h == 0 ? 1 : 0)); ++nb) {
       const float v = fmaxf(acc[br][m][nb][r], 0.f);
-      o0[br][nb] = fmaf(u0, v, o0[br][nb]);
-      if (!KEEP2) o1[br][nb] = fmaf(u1, v, o1[br][nb]);
+      if (KEEP2) {
+        o0[br][nb] = fmaf(u0, v, o0[br][nb]);
+      } else if (PKDOT && br == 1) {        // stage D has no MFMAs beside it: only there is v_pk_fma_f32 cheaper than two v_fma (tools/diag/pkfma.hip)
+        const f32x2 uu = {u0, u1}, vv = {v, v};
+        o01[br][nb] = __builtin_elementwise_fma(uu, vv, o01[br][nb]);
+      } else {
+        o0[br][nb] = fmaf(u0, v, o0[br][nb]);
+        o1[br][nb] = fmaf(u1, v, o1[br][nb]);
+      }
     }
   };
 
@@ -293,6 +305,10 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   float res[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
 #pragma unroll
   for (int br = 0; br < 2; ++br) {
+    if (!KEEP2 && PKDOT && br == 1) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) { o0[br][nb] = o01[br][nb][0]; o1[br][nb] = o01[br][nb][1]; }
+    }
     res[br][0] = quarter_reduce<NB>(o0[br], q);
     if (!KEEP2) res[br][1] = quarter_reduce<NB>(o1[br], q);
   }
