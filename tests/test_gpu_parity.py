@@ -139,6 +139,26 @@ def test_ragged_shapes_vs_oracle(B, N, f):
             assert maxabs(host(ld), ref_ld) < TOL_LOGDET, (mode, ppw)
 
 
+@pytest.mark.parametrize('f', [17, 20, 34, 36, 37, 40, 41, 61])
+def test_specialised_width_edges_vs_oracle(f):
+    """Both ends of the width ranges with their own contraction packing (17-20: two MFMAs per k-step, 33-40: merged last
+    k-step, transposed last row tile) and their neighbours, against the oracle, both warp-pattern families (L=2)."""
+    L, G = 2, 24
+    m, st = decoder_and_state(L, f, G, 1900 + f)
+    m = m.to(DEV).eval()
+    for B, N in [(2, 65), (3, 200)]:
+        p, g = synth_inputs(B, N, G, 2000 + B * 7 + N)
+        for mode in ('direct', 'inverse'):
+            ref_out, ref_ld = fo.decoder_fused(p, g, st, L, mode)
+            for ppw in (16, 32, 64):
+                _lib.lib().gwtf_debug_set_points_per_wave(ppw)
+                with torch.no_grad():
+                    out, ld = m.forward_fused(dev(p), dev(g), mode=mode)
+                assert maxabs(host(out), ref_out) < TOL_COORD, (mode, ppw)
+                assert maxabs(host(ld), ref_ld) < TOL_LOGDET, (mode, ppw)
+    _lib.lib().gwtf_debug_set_points_per_wave(0)
+
+
 def test_noncontiguous_and_cache_invalidation():
     L, f, G, B, N = 1, 16, 8, 2, 40
     m, st = decoder_and_state(L, f, G, 77)
@@ -731,7 +751,8 @@ def test_full_size_weight_gradient_directional_derivative(training):
 
 
 @pytest.mark.parametrize('L,f,G,B,N', [(2, 64, 32, 16, 2048), (2, 37, 32, 8, 1024), (2, 37, 32, 64, 2048), (2, 33, 64, 32, 2048),
-                                       (3, 19, 32, 32, 2048), (1, 19, 16, 2, 100), (1, 40, 16, 3, 700)])
+                                       (3, 19, 32, 32, 2048), (1, 19, 16, 2, 100), (1, 40, 16, 3, 700)] +
+                         [(2, f, 16, 5, 777) for f in (17, 18, 20, 34, 35, 36, 38, 39, 61, 62, 63)])
 @pytest.mark.parametrize('mode', ['direct', 'inverse'])
 def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B, N, mode):
     """The software-pipelined body (compile-time k-slot count: the shipped widths) reorders instructions, not arithmetic --
