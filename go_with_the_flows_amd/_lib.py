@@ -52,6 +52,9 @@ _SIGNATURES = {
     'gwtf_mixture_nll_backward': (ctypes.c_int, [_c_fp] * 12 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_adam_step': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_double,
                                        ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_adam_chunk_elems': (ctypes.c_int, []),
+    'gwtf_adam_step_table': (ctypes.c_int, [_c_fp] * 3 + [ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_double,
+                                             ctypes.c_float, ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_nn_distance': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_nn_distance_grad': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_approx_match': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int] * 3 + [_c_fp]),

@@ -73,7 +73,81 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float lr, 
   }
 }
 
+// Any number of tensors in ONE launch: the pointer table lives in device memory (a model has ~1200 parameter tensors, most
+// of them a few dozen floats: 25 dependent 48-tensor launches cost 13 us each, one table launch streams at HBM rate).
+//   table [n_tensors][5] u64 = {param, exp_avg, exp_avg_sq, max_exp_avg_sq or 0, numel}     grads [n_tensors] u64
+//   chunk_map [n_chunks][2] i32 = {tensor index, chunk index within the tensor}
+template <bool AMS>
+__global__ __launch_bounds__(256) void adam_table_kernel(const unsigned long long* __restrict__ table,
+                                                         const unsigned long long* __restrict__ grads,
+                                                         const int* __restrict__ chunk_map, float lr, float b1, float b2,
+                                                         float omb1, float omb2, float eps, float wd, float bc1, float bc2s) {
+  const int ti = chunk_map[2 * blockIdx.x];
+  const size_t base = (size_t)chunk_map[2 * blockIdx.x + 1] * kChunk;
+  const unsigned long long* row = table + (size_t)ti * 5;
+  float* __restrict__ p = reinterpret_cast<float*>(row[0]);
+  float* __restrict__ m = reinterpret_cast<float*>(row[1]);
+  float* __restrict__ v = reinterpret_cast<float*>(row[2]);
+  float* __restrict__ vm = reinterpret_cast<float*>(row[3]);
+  const size_t n = row[4];
+  const float* __restrict__ g = reinterpret_cast<const float*>(grads[ti]);
+  auto upd = [&](float& pp, float gg, float& mm, float& vv, float& vx) {   // same arithmetic as adam_kernel
+    mm = mm * b1 + omb1 * gg;
+    vv = vv * b2 + omb2 * gg * gg;
+    float den;
+    if (AMS) {
+      vx = fmaxf(vx, vv);
+      den = sqrtf(vx);
+    } else {
+      den = sqrtf(vv);
+    }
+    const float step = (mm / bc1) / (den / bc2s + eps);
+    pp = pp - (pp * wd + lr * step);
+  };
+  const bool vec = (((size_t)p | (size_t)g | (size_t)m | (size_t)v | (size_t)(AMS ? vm : p)) & 15) == 0;
+  for (size_t i = base + (size_t)threadIdx.x * 4; i < base + kChunk && i < n; i += 256 * 4) {
+    if (vec && i + 4 <= n) {
+      float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
+      const float4 gg = *reinterpret_cast<const float4*>(g + i);
+      float4 vx = AMS ? *reinterpret_cast<float4*>(vm + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      upd(pp.x, gg.x, mm.x, vv.x, vx.x);
+      upd(pp.y, gg.y, mm.y, vv.y, vx.y);
+      upd(pp.z, gg.z, mm.z, vv.z, vx.z);
+      upd(pp.w, gg.w, mm.w, vv.w, vx.w);
+      *reinterpret_cast<float4*>(p + i) = pp;
+      *reinterpret_cast<float4*>(m + i) = mm;
+      *reinterpret_cast<float4*>(v + i) = vv;
+      if (AMS) *reinterpret_cast<float4*>(vm + i) = vx;
+    } else {
+      for (size_t k = i; k < i + 4 && k < n; ++k) {
+        float pp = p[k], mm = m[k], vv = v[k], vx = AMS ? vm[k] : 0.f;
+        upd(pp, g[k], mm, vv, vx);
+        p[k] = pp; m[k] = mm; v[k] = vv;
+        if (AMS) vm[k] = vx;
+      }
+    }
+  }
+}
+
 }  // namespace
+
+// Table variant of gwtf_adam_step (layouts above; all three arrays in DEVICE memory, built by the caller once per set of
+// tensors -- only `grads` changes from step to step).  gwtf_adam_chunk_elems() is the chunk size the map must use.
+extern "C" int gwtf_adam_chunk_elems(void) { return kChunk; }
+
+extern "C" int gwtf_adam_step_table(const unsigned long long* table, const unsigned long long* grads, const int* chunk_map,
+                                    int n_chunks, float lr, double beta1, double beta2, float eps, float weight_decay,
+                                    int step, int amsgrad, void* stream) {
+  if (!table || !grads || !chunk_map || n_chunks < 0 || step < 1) return GWTF_E_BADARG;
+  if (n_chunks == 0) return 0;
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+  hipStream_t st = (hipStream_t)stream;
+  if (amsgrad) hipLaunchKernelGGL(adam_table_kernel<true>, dim3(n_chunks), dim3(256), 0, st, table, grads, chunk_map, lr, (float)beta1, (float)beta2, omb1, omb2, eps, weight_decay, bc1, bc2s);
+  else hipLaunchKernelGGL(adam_table_kernel<false>, dim3(n_chunks), dim3(256), 0, st, table, grads, chunk_map, lr, (float)beta1, (float)beta2, omb1, omb2, eps, weight_decay, bc1, bc2s);
+  return (int)hipGetLastError();
+}
 
 // Host arrays of n_tensors device pointers (max_exp_avg_sq may be NULL when amsgrad == 0).  `step` is the 1-based step
 // count AFTER this update (the reference increments before using it, optimizers.py:47).

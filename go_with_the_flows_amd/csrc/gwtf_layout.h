@@ -65,7 +65,7 @@ struct GwtfRaw {  // offsets inside one branch record
 // The record is padded to a whole number of 1-KiB LDS-DMA pieces.
 struct GwtfA16Slot { int jsrc; bool lo, zero; };
 // float slot jp (= k positions 2jp, 2jp+1) of image `part` of k-step ks: which pair of k positions, and which f16 part, it holds
-GWTF_HD inline GwtfA16Slot gwtf_a16_slot(int f, int KS, int ks, int part, int jp) {
+GWTF_HD GwtfA16Slot gwtf_a16_slot(int f, int KS, int ks, int part, int jp) {
   const bool merged = KS == 2 && ks == 1 && (f + 3) / 4 - 8 <= 2 && part == 0;
   GwtfA16Slot s;
   s.jsrc = merged ? 0 : jp;

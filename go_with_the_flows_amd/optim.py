@@ -3,8 +3,8 @@
 Same constructor, same ``state`` entries ('step', 'exp_avg', 'exp_avg_sq', 'max_exp_avg_sq') -- so
 ``optimizer_state`` checkpoints written by the reference (training.py:76-81) load with ``load_state_dict`` -- and the
 same update, including its un-scaled decoupled weight decay ``p -= wd*p + lr*m_hat/(sqrt(v_hat)+eps)``.  The
-per-parameter Python loop (about a dozen tiny launches per tensor) becomes one HIP launch per 48 tensors
-(csrc/gwtf_adam.hip).  ``LRUpdater`` (optimizers.py:79-97) works unchanged: it only edits ``param_groups``.
+per-parameter Python loop (about a dozen tiny launches per tensor) becomes ONE HIP launch for all tensors of a parameter
+group (csrc/gwtf_adam.hip: pointer table in device memory; up to 48 tensors ride in the kernel arguments instead).  ``LRUpdater`` (optimizers.py:79-97) works unchanged: it only edits ``param_groups``.
 """
 import ctypes
 
@@ -29,16 +29,55 @@ class Adam(Optimizer):
         arr = ctypes.c_void_p * n
         sts = [self.state[p] for p in plist]
         ptr = lambda ts: arr(*[t.data_ptr() for t in ts])
-        return {'n': n, 'arr': arr, 'dev': dev, 'step': step, 'ams': ams, 'states': sts, 'p0': plist[0].data_ptr(),
+        plan = {'n': n, 'arr': arr, 'dev': dev, 'step': step, 'ams': ams, 'states': sts, 'p0': plist[0].data_ptr(),
                 'p': ptr(plist), 'm': ptr([s['exp_avg'] for s in sts]), 'v': ptr([s['exp_avg_sq'] for s in sts]),
                 'vmax': ptr([s['max_exp_avg_sq'] for s in sts]) if ams else None,
                 'numel': (ctypes.c_size_t * n)(*[p.numel() for p in plist])}
+        if n > self._TABLE_ABOVE:
+            # many tensors: ONE launch with the pointer table in device memory (built once; only the gradient pointers are
+            # re-uploaded, and only when they moved)
+            chunk = _lib.lib().gwtf_adam_chunk_elems()
+            rows = [[p.data_ptr(), s['exp_avg'].data_ptr(), s['exp_avg_sq'].data_ptr(),
+                     s['max_exp_avg_sq'].data_ptr() if ams else 0, p.numel()] for p, s in zip(plist, sts)]
+            cmap = [(i, c) for i, p in enumerate(plist) for c in range((p.numel() + chunk - 1) // chunk)]
+            plan['table'] = torch.tensor(rows, dtype=torch.int64).to(dev)
+            plan['cmap'] = torch.tensor(cmap, dtype=torch.int32).reshape(-1, 2).to(dev)
+            plan['n_chunks'] = len(cmap)
+            plan['gtab'] = torch.zeros(n, dtype=torch.int64, device=dev)
+            plan['gptrs'] = None
+            # pinned staging (two buffers, an event each): the upload must not synchronise the host with the stream
+            plan['gstage'] = [torch.zeros(n, dtype=torch.int64).pin_memory() for _ in range(2)]
+            plan['gevent'] = [None, None]
+            plan['gflip'] = 0
+        return plan
+
+    _TABLE_ABOVE = 48   # tensors per launch of the pointer-argument kernel (csrc/gwtf_adam.hip kMaxT)
 
     @staticmethod
     def _launch(L, group, plan, grads, step):
-        gptr = plan['arr'](*[(g if g.is_contiguous() else g.contiguous()).data_ptr() for g in grads])
         b1, b2 = group['betas']
         dev = plan['dev']
+        grads = [g if g.is_contiguous() else g.contiguous() for g in grads]   # copies stay alive until the launch is enqueued
+        if 'table' in plan:
+            gp = [g.data_ptr() for g in grads]
+            if gp != plan['gptrs']:
+                k = plan['gflip'] = plan['gflip'] ^ 1
+                if plan['gevent'][k] is not None:
+                    plan['gevent'][k].synchronize()          # the copy that last read this staging buffer (two steps ago)
+                plan['gstage'][k].numpy()[:] = gp
+                with torch.cuda.device(dev):
+                    plan['gtab'].copy_(plan['gstage'][k], non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                plan['gevent'][k] = ev
+                plan['gptrs'] = gp
+            with torch.cuda.device(dev):
+                _lib.check(L.gwtf_adam_step_table(plan['table'].data_ptr(), plan['gtab'].data_ptr(), plan['cmap'].data_ptr(),
+                                                  plan['n_chunks'], float(group['lr']), float(b1), float(b2),
+                                                  float(group['eps']), float(group['weight_decay']), step, int(plan['ams']),
+                                                  torch.cuda.current_stream(dev).cuda_stream))
+            return
+        gptr = plan['arr'](*[g.data_ptr() for g in grads])
         with torch.cuda.device(dev):
             _lib.check(L.gwtf_adam_step(plan['p'], gptr, plan['m'], plan['v'], plan['vmax'], plan['numel'], plan['n'],
                                         float(group['lr']), float(b1), float(b2), float(group['eps']),

@@ -210,6 +210,15 @@ int gwtf_adam_step(float* const* params, const float* const* grads, float* const
                    float* const* max_exp_avg_sq, const size_t* numel, int n_tensors, float lr, double beta1, double beta2,
                    float eps, float weight_decay, int step, int amsgrad, void* stream);
 
+/* The same update for ANY number of tensors in one launch, the pointer table in DEVICE memory (a model has ~1200 tensors):
+ *   table [n_tensors][5] u64 = {param, exp_avg, exp_avg_sq, max_exp_avg_sq or 0, numel}    grads [n_tensors] u64
+ *   chunk_map [n_chunks][2] i32 = {tensor index, chunk index within that tensor}, chunks of gwtf_adam_chunk_elems() elements
+ * Only `grads` changes from step to step. */
+int gwtf_adam_chunk_elems(void);
+int gwtf_adam_step_table(const unsigned long long* table, const unsigned long long* grads, const int* chunk_map, int n_chunks,
+                         float lr, double beta1, double beta2, float eps, float weight_decay, int step, int amsgrad,
+                         void* stream);
+
 /* Structural losses between point sets -- the reference's only native code (CUDA extension
  * lib/metrics/pytorch_structural_losses, bound in pybind/bind.cpp:9-15).  Point sets are [b][n][3] / [b][m][3].
  *
