@@ -55,6 +55,11 @@ class RealNVPFlow(nn.Module):
         return g[:, sl] if sl is not None else g[:, inds]
 
     def _scatter(self, like, values):
+        sl = self._warp_sl
+        if sl is not None and sl.step in (None, 1):
+            # a contiguous block of warped indices: zero padding = one kernel forward, a narrow backward (an in-place slice
+            # assignment costs zeros + copy forward and a clone + copy in its CopySlices backward)
+            return torch.nn.functional.pad(values, (sl.start, like.shape[1] - sl.stop))
         out = torch.zeros_like(like)
         if self._warp_sl is not None:
             out[:, self._warp_sl] = values
