@@ -38,6 +38,9 @@ WORKLOADS = {
                name='north-star shape: single flow, 12 couplings, f=64, G=128, B=32 x N=2048, inverse + sum(logvars)'),
     'ae': dict(K=4, L=11, f=33, G=512, B=16, N=2048, mode='inverse',
                name='configs[2] autoencoding per-GPU shard: K=4 x 33 couplings, f=33, G=512, B=16 x N=2048'),
+    'svr': dict(K=4, L=11, f=33, G=512, B=16, N=2500, mode='inverse',
+                name='configs[4] single-view reconstruction per-GPU shard (decoder side; the image encoder is out of scope): '
+                     'K=4 x 33 couplings, f=33, G=512, B=16 x N=2500'),
     'k16': dict(K=16, L=6, f=19, G=128, B=32, N=2048, mode='direct',
                 name='configs[3] K=16 mixture sampling, batched: each point visits one of 16 flows, 18 couplings, f=19'),
 }

@@ -184,7 +184,7 @@ def test_noncontiguous_and_cache_invalidation():
     assert np.array_equal(host(out3), host(out))
 
 
-@pytest.mark.parametrize('cfg', [(4, 64, 128, 32, 2048), (11, 37, 128, 8, 2048), (6, 19, 128, 32, 2048)])
+@pytest.mark.parametrize('cfg', [(4, 64, 128, 32, 2048), (11, 37, 128, 8, 2048), (6, 19, 128, 32, 2048), (11, 33, 512, 4, 2500)])
 def test_full_size_properties(cfg):
     """BASELINE.json sizes: too slow for the python oracle on every run, so check size-independent properties:
     inverse(direct(x)) round trip, log-det antisymmetry along the round trip, per-shape independence
