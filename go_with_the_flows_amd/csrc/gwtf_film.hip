@@ -184,7 +184,6 @@ __global__ __launch_bounds__(256) void film_kernel(const float* __restrict__ g, 
 // L2 inside the dot-product loop took 89 us for 66 workgroups; VALU from LDS 24 us; MFMA with LDS-staged
 // operands and a barrier per chunk 15-18 us -- every phase was a dependent load->sync->compute step.)
 constexpr int kBTe = 16;   // shapes per workgroup = one MFMA M tile
-constexpr int kGCH = 128;  // latent columns per register-resident chunk
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -194,7 +193,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // and out-of-range latent columns / shapes are clamped, their products land on zero weights or discarded
 // rows), the layer-2 weights are prefetched before layer 1 starts, and the only LDS traffic is the 16 x FP
 // transpose of the hidden activations between the two layers.
-template <int MB>
+// kGCH = latent columns per register-resident chunk: 128 keeps a G = 128 head in ONE load round (shortest chain; 150 VGPRs,
+// 3 workgroups per CU), 64 takes two rounds but 4-5 workgroups fit a CU -- chosen when the grid exceeds one round of the
+// former (K x C couplings of a mixture: 27 -> measured below).
+template <int MB, int kGCH>
 __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict__ g, const float* __restrict__ pf,
                                                         float* __restrict__ out, int B, int G, int C, int f, float eps) {
   constexpr int FP = 16 * MB;
@@ -210,8 +212,9 @@ __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict_
   const int ft = 16 * wave + i16;                    // output feature owned by this lane (both heads)
   const int brow = b0 + i16;                         // shape whose latent row this lane feeds to the A operand
   const float* grow = g + (size_t)(brow < B ? brow : B - 1) * G;
-  const float* l0 = w + P.l0t(0) + ft;
-  const float* l1 = w + P.l0t(1) + ft;
+  const float* l0 = w + P.l0t(0) + 4 * ft;           // L0Q[col/4][ft][col%4] (gwtf_layout.h)
+  const float* l1 = w + P.l0t(1) + 4 * ft;
+  const bool gvec = (G & 3) == 0;                    // latent rows are 16-byte aligned and whole quads
 
   f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   f32x4 w1[2][MB];                                   // layer-2 B operands (prefetched)
@@ -221,19 +224,21 @@ __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict_
 #pragma unroll
       for (int which = 0; which < 2; ++which)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) w1[which][kg][t] = w[P.l1t(which) + (size_t)(16 * kg + 4 * q + t) * FP + ft];
+        for (int t = 0; t < 4; ++t) w1[which][kg][t] = w[P.l1t(which) + ((size_t)(4 * kg + q) * FP + ft) * 4 + t];   // L1Q: one dwordx4
     for (int i0 = 0; i0 < GP; i0 += kGCH) {
       f32x4 a4[kGCH / 16], b4[2][kGCH / 16];
 #pragma unroll
       for (int kg = 0; kg < kGCH / 16; ++kg) {
         if (i0 + 16 * kg < GP) {                     // wave-uniform
           const int col = i0 + 16 * kg + 4 * q;      // k-slot (4*kg + t, q) <-> latent column col + t
+          if (gvec) {
+            a4[kg] = *reinterpret_cast<const f32x4*>(grow + (col < G ? col : G - 4));
+          } else {
 #pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            a4[kg][t] = grow[col + t < G ? col + t : G - 1];
-            b4[0][kg][t] = l0[(size_t)(col + t) * FP];
-            b4[1][kg][t] = l1[(size_t)(col + t) * FP];
+            for (int t = 0; t < 4; ++t) a4[kg][t] = grow[col + t < G ? col + t : G - 1];
           }
+          b4[0][kg] = *reinterpret_cast<const f32x4*>(l0 + (size_t)col * FP);   // (col/4) * FP * 4
+          b4[1][kg] = *reinterpret_cast<const f32x4*>(l1 + (size_t)col * FP);
         }
       }
 #pragma unroll
@@ -316,12 +321,17 @@ extern "C" int gwtf_film_forward(const float* g, const float* packed_film, float
                        f, FP, eps);
   } else {
     const dim3 grid(C, 2, (B + kBTe - 1) / kBTe);
+    const bool many = (long)grid.x * grid.y * grid.z > 768;   // more than one round of 256 CUs x 3 resident workgroups
+#define GWTF_FILM_EVAL(MB_)                                                                                                  \
+  if (many) hipLaunchKernelGGL((film_eval_kernel<MB_, 64>), grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); \
+  else hipLaunchKernelGGL((film_eval_kernel<MB_, 128>), grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps)
     switch (FP / 16) {
-      case 1: hipLaunchKernelGGL(film_eval_kernel<1>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
-      case 2: hipLaunchKernelGGL(film_eval_kernel<2>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
-      case 3: hipLaunchKernelGGL(film_eval_kernel<3>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
-      default: hipLaunchKernelGGL(film_eval_kernel<4>, grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); break;
+      case 1: GWTF_FILM_EVAL(1); break;
+      case 2: GWTF_FILM_EVAL(2); break;
+      case 3: GWTF_FILM_EVAL(3); break;
+      default: GWTF_FILM_EVAL(4); break;
     }
+#undef GWTF_FILM_EVAL
   }
   return (int)hipGetLastError();
 }

@@ -125,6 +125,9 @@ GWTF_HD float gwtf_w1t_slot(const GwtfPackB& P, size_t o /* offset inside one br
 // PACKED FILM WEIGHTS (read by gwtf_film_forward), per coupling, per branch:
 //   for which in {w,b}: L0T[GP][FP] (GP = G rounded up to 16, zero rows beyond G) | S[FP] | T[FP] | L1T[FP][FP] | L1B[FP]
 //   C1[FP] (sd1_bn shift: -mean/sqrt(var+eps)) | W2[2][FP] | B2[4] (sd2 bias, 2 used)
+// eval packing stores L0T and L1T with four input columns interleaved, L0Q[GP/4][FP][4] / L1Q[FP/4][FP][4] (same sizes):
+// film_eval_kernel's lane owns
+// one feature and reads its four k-slots of an MFMA k-group with one 16-byte load, 16 lanes = 256 contiguous bytes.
 // eval: S = gamma/sqrt(var+eps), T = beta - mean*S (running statistics)
 // train: S = gamma, T = beta (batch statistics are taken inside the FiLM kernel)
 struct GwtfPackF {

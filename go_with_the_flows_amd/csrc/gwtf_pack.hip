@@ -82,8 +82,12 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
       const int which = (int)(o / P.mlp_size());
       o -= (size_t)which * P.mlp_size();
       const float* bn = rb + R.film_bn(which);
-      if (o < (size_t)P.GP() * FP) {  // L0T[i][j] = L0[j][i], rows G..GP-1 zero
-        const int i = (int)(o / FP), j = (int)(o % FP);
+      if (o < (size_t)P.GP() * FP) {  // L0T[i][j] = L0[j][i], rows G..GP-1 zero; eval: four latent columns interleaved
+        int i = (int)(o / FP), j = (int)(o % FP);
+        if (!training) {               // L0Q[i/4][j][i%4]: the eval kernel's lane (feature j) reads 4 k-slots with one dwordx4
+          i = 4 * (int)(o / (4 * (size_t)FP)) + (int)(o % 4);
+          j = (int)((o / 4) % FP);
+        }
         if (j < f && i < G) v = rb[R.film_l0(which) + (size_t)j * G + i];
       } else if ((o -= (size_t)P.GP() * FP) < (size_t)FP) {  // S
         const int j = (int)o;
@@ -91,8 +95,12 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
       } else if ((o -= FP) < (size_t)FP) {  // T
         const int j = (int)o;
         if (j < f) v = training ? bn[f + j] : bn[f + j] - bn[2 * f + j] * (bn[j] * inv_std(bn[3 * f + j]));
-      } else if ((o -= FP) < (size_t)FP * FP) {  // L1T[i][j] = L1[j][i]
-        const int i = (int)(o / FP), j = (int)(o % FP);
+      } else if ((o -= FP) < (size_t)FP * FP) {  // L1T[i][j] = L1[j][i]; eval: L1Q[i/4][j][i%4] like L0Q
+        int i = (int)(o / FP), j = (int)(o % FP);
+        if (!training) {
+          i = 4 * (int)(o / (4 * (size_t)FP)) + (int)(o % 4);
+          j = (int)((o / 4) % FP);
+        }
         if (i < f && j < f) v = rb[R.film_l1(which) + (size_t)j * f + i];
       } else {  // L1B
         const int j = (int)(o - (size_t)FP * FP);
