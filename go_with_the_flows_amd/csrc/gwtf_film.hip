@@ -195,7 +195,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // transpose of the hidden activations between the two layers.
 // kGCH = latent columns per register-resident chunk: 128 keeps a G = 128 head in ONE load round (shortest chain; 150 VGPRs,
 // 3 workgroups per CU), 64 takes two rounds but 4-5 workgroups fit a CU -- chosen when the grid exceeds one round of the
-// former (K x C couplings of a mixture: 27 -> measured below).
+// former (the K x C couplings of a mixture: 19.8 -> 17.1 us on the airplane grid of 1056 workgroups).
 template <int MB, int kGCH>
 __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict__ g, const float* __restrict__ pf,
                                                         float* __restrict__ out, int B, int G, int C, int f, float eps) {
