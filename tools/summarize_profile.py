@@ -11,7 +11,8 @@ for w in ('airplane', 'm1'):
     print(f'===== workload {w} =====')
     st = glob.glob(os.path.join(root, f'trace_{w}', '*kernel_stats.csv'))
     if st:
-        print('-- rocprofv3 --kernel-trace --stats (top kernels) --')
+        print('-- rocprofv3 --kernel-trace --stats (top kernels; __amd_rocclr_copyBuffer = start-up uploads of the synthetic parameters, '
+              'one per tensor, none inside a step) --')
         for i, r in enumerate(csv.DictReader(open(st[0]))):
             if i < 6:
                 print(f"{r['Name'][:90]:90s} calls={r['Calls']:>6s} avg_ns={float(r['AverageNs']):>12.1f} pct={r['Percentage']}")
