@@ -26,6 +26,16 @@ namespace {
 
 using namespace gwtf_dev;
 
+// The per-point tail (softsign, scale = sqrt(eps + exp(logvar)), inverse affine) on the hardware's reciprocal, square root
+// and exp2 units (each within 1-2 ulp) instead of correctly rounded division / sqrtf / libm expf: 2 + 1 + 2 instructions
+// against ~11 + ~12 + ~10 per use, 40-75 VALU per coupling and wave.  Operand ranges make the fast forms safe (divisors
+// >= ~0.6, logvar in (-1, 1) by the softsign).  Measured against the reference's own fp64 evaluation on the golden decoder
+// cases (tools/diag/err_vs_fp64.py): mean coordinate error 3.97e-7 / 3.94e-7 (direct / inverse) against 3.75e-7 / 3.95e-7
+// with the correctly rounded forms and 2.81e-7 / 3.36e-7 for the reference's fp32 evaluation itself -- inside the
+// noise of fp32 evaluation order, far inside the stated tolerance (2e-5); airplane kernel 0.522 -> 0.498 ms.
+__device__ __forceinline__ float tail_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float tail_scale(float eps, float logvar) { return __builtin_amdgcn_sqrtf(eps + __expf(logvar)); }
+
 // One elementary coupling on the wave's tile.  KEEP2 = two kept coordinates / one warped (patterns 0-2),
 // otherwise one kept / two warped (patterns 3-5).  Every VALU instruction here costs the SIMD 4 cycles that
 // the matrix pipe cannot use (measured: MFMA and VALU of two waves on one SIMD do not overlap,
@@ -83,9 +93,9 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
 #pragma unroll
   for (int s = 0; s < (KEEP2 ? 1 : 2); ++s) {
     const float t = res[0][s] + bias[s];
-    lv_w[s] = t / (1.0f + fabsf(t));                 // softsign (flows.py:99)
+    lv_w[s] = tail_div(t, 1.0f + fabsf(t));          // softsign (flows.py:99)
     mu_w[s] = res[1][s] + bias[2 + s];
-    sc_w[s] = sqrtf(eps + expf(lv_w[s]));            // flows.py:113,115
+    sc_w[s] = tail_scale(eps, lv_w[s]);              // flows.py:113,115
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -96,7 +106,7 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
     if (MODE == GWTF_MODE_DIRECT)
       xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
     else
-      xo[d] = __fdiv_rn(__fsub_rn(xo[d], mu_d[d]), sc);
+      xo[d] = tail_div(__fsub_rn(xo[d], mu_d[d]), sc);
   }
 }
 
@@ -317,9 +327,9 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
 #pragma unroll
   for (int s = 0; s < (KEEP2 ? 1 : 2); ++s) {
     const float t = res[0][s] + bias[s];
-    lv_w[s] = t / (1.0f + fabsf(t));
+    lv_w[s] = tail_div(t, 1.0f + fabsf(t));
     mu_w[s] = res[1][s] + bias[2 + s];
-    sc_w[s] = sqrtf(eps + expf(lv_w[s]));
+    sc_w[s] = tail_scale(eps, lv_w[s]);
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
@@ -330,7 +340,7 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     if (MODE == GWTF_MODE_DIRECT)
       xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
     else
-      xo[d] = __fdiv_rn(__fsub_rn(xo[d], mu_d[d]), sc);
+      xo[d] = tail_div(__fsub_rn(xo[d], mu_d[d]), sc);
   }
 }
 
