@@ -167,23 +167,25 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     if (!STATS && s < nw) {
       const float t = res[0][s] + bias[s];
       const float den = 1.0f + fabsf(t);
-      const float lv = t / den;
+      const float rden = __builtin_amdgcn_rcpf(den);   // hardware rcp / sqrt / exp2 like the forward tail (gwtf_stack.hip)
+      const float lv = t * rden;
       const float mu = res[1][s] + bias[2 + s];
-      const float e = expf(lv);
-      const float sc = sqrtf(eps + e);
+      const float e = __expf(lv);
+      const float sc = __builtin_amdgcn_sqrtf(eps + e);
+      const float rsc = __builtin_amdgcn_rcpf(sc);
       float dsc;
       if (mode == GWTF_MODE_INVERSE) {       // out = (x - mu)/s
-        const float outw = (xw[s] - mu) / sc;
-        gx[s] = gow[s] / sc;
-        dsc = -gow[s] * outw / sc;
+        const float outw = (xw[s] - mu) * rsc;
+        gx[s] = gow[s] * rsc;
+        dsc = -gow[s] * outw * rsc;
         dt[1][s] = -gx[s];
       } else {                                // out = s*x + mu
         gx[s] = gow[s] * sc;
         dsc = gow[s] * xw[s];
         dt[1][s] = gow[s];
       }
-      const float dlv = glw[s] + dsc * e / (2.0f * sc);
-      dt[0][s] = dlv / (den * den);
+      const float dlv = glw[s] + dsc * e * (0.5f * rsc);
+      dt[0][s] = dlv * (rden * rden);
     }
   }
   const float keep_scale = mode == GWTF_MODE_INVERSE ? 1.0f / s_keep : s_keep;
