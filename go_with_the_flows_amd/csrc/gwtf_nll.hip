@@ -39,7 +39,7 @@ __global__ __launch_bounds__(1024) void nll_kernel(const float* __restrict__ z, 
     const float l = lv0[((size_t)k * B + b) * 3 + d];
     s_mu[k][d] = mu0[((size_t)k * B + b) * 3 + d];
     s_lv[k][d] = l;
-    s_iv[k][d] = expf(l);
+    s_iv[k][d] = 1.0f / expf(l);      // the points multiply by 1/exp(lv0): one division per (component, dim), not per point
   }
   __syncthreads();
   const float half_log2pi3 = 0.5f * 3.0f * 1.8378770664093453f;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(1024) void nll_kernel(const float* __restrict__ z, 
       for (int d = 0; d < 3; ++d) {
         const size_t o = (((size_t)k * B + b) * 3 + d) * N + n;
         const float diff = z[o] - s_mu[k][d];
-        qsum += (s_lv[k][d] + logdet[o]) + diff * diff / s_iv[k][d];
+        qsum += (s_lv[k][d] + logdet[o]) + diff * diff * s_iv[k][d];
       }
       const float lp = -0.5f * qsum - half_log2pi3 + s_logw[k];
       if (lp > m || k == 0) {
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kThreads) void nll_bwd_kernel(const float* __restri
     const float l = lv0[((size_t)k * B + b) * 3 + d];
     s_mu[k][d] = mu0[((size_t)k * B + b) * 3 + d];
     s_lv[k][d] = l;
-    s_iv[k][d] = expf(l);
+    s_iv[k][d] = 1.0f / expf(l);      // the points multiply by 1/exp(lv0): one division per (component, dim), not per point
   }
   for (int t = threadIdx.x; t < K * 7; t += blockDim.x) (&s_acc[0][0])[t] = 0.f;
   __syncthreads();
@@ -127,13 +127,13 @@ __global__ __launch_bounds__(kThreads) void nll_bwd_kernel(const float* __restri
       for (int d = 0; d < 3; ++d) {
         const size_t o = (((size_t)k * B + b) * 3 + d) * N + n;
         diff[d] = z[o] - s_mu[k][d];
-        qsum += (s_lv[k][d] + logdet[o]) + diff[d] * diff[d] / s_iv[k][d];
+        qsum += (s_lv[k][d] + logdet[o]) + diff[d] * diff[d] * s_iv[k][d];
       }
       const float r = expf(-0.5f * qsum - half_log2pi3 + s_logw[k] - point_lse[(size_t)b * N + n]) * gb;
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const size_t o = (((size_t)k * B + b) * 3 + d) * N + n;
-        const float w = diff[d] / s_iv[k][d];
+        const float w = diff[d] * s_iv[k][d];
         g_z[o] = r * w;
         g_ld[o] = 0.5f * r;
         a[d] -= r * w;
