@@ -1,6 +1,7 @@
 """CPU restatement of the reference's structural-loss CUDA extension.  TEST INFRASTRUCTURE ONLY.
 
-PARITY UNPINNED for this file: the reference implements these operators only as CUDA sources
+PARITY UNPINNED for the approximate-EMD functions of this file (the nearest-neighbour / Chamfer functions are pinned to the
+reference's own pure-torch distChamfer through tests/golden/g14_evaluation.npz): the reference implements these operators only as CUDA sources
 (lib/metrics/pytorch_structural_losses/src/{nndistance.cu, approxmatch.cu}; nvcc is not in this image, so the extension
 is unbuildable here) and holds no golden vectors or tests for them.  The functions below restate the published
 algorithm of those kernels in float32 numpy, each citing the lines it follows; tests additionally anchor them on

@@ -450,6 +450,73 @@ def g13_full_model():
     print('contract_model.json', len(keys), 'entries')
 
 
+def _pure_functions(relpath, names):
+    """Execute the named top-level functions of a reference file from its own source, skipping the imports of the
+    un-built CUDA extension (lib/metrics/StructuralLosses: nvcc-only) that keep the whole module from importing here.
+    Nothing is stubbed: a function that reaches the extension simply is not exercised."""
+    import ast
+    import types
+    path = os.path.join(REF, relpath)
+    tree = ast.parse(open(path).read(), path)
+    body = []
+    for node in tree.body:
+        if isinstance(node, (ast.Import, ast.ImportFrom)):
+            text = ast.unparse(node)
+            if 'StructuralLosses' in text or 'sklearn' in text:
+                continue
+            body.append(node)
+        elif isinstance(node, ast.FunctionDef) and node.name in names:
+            body.append(node)
+    mod = types.ModuleType('ref_' + os.path.basename(relpath)[:-3])
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, 'exec'), mod.__dict__)
+    return mod
+
+
+def g14_evaluation_metrics():
+    """Host-side evaluation metrics of the reference (lib/metrics/evaluation_metrics.py, lib/networks/utils.py) on the
+    paths that do not enter its CUDA extension: pure-torch Chamfer, F1, MMD / coverage / 1-NN bookkeeping, occupancy JSD."""
+    em = _pure_functions('lib/metrics/evaluation_metrics.py',
+                         {'distChamfer', 'EMD_CD_F1', '_pairwise_EMD_CD_F1_SCORE', 'knn', 'lgan_mmd_cov', 'compute_all_metrics',
+                          'distChamferCUDA', 'emd_approx'})
+    ut = _pure_functions('lib/networks/utils.py', {'get_voxel_occ_dist', 'JSD'})
+    rng = np.random.default_rng(1400)
+    a = (0.3 * rng.standard_normal((3, 40, 3))).astype(np.float32)
+    b = (0.3 * rng.standard_normal((3, 40, 3))).astype(np.float32)
+    out = dict(a=a, b=b)
+    first, second = em.distChamfer(T(a), T(b))
+    out.update(chamfer_first=npy(first), chamfer_second=npy(second))
+    smp = (rng.random((6, 48, 3)) - 0.5).astype(np.float32)
+    ref = (rng.random((6, 48, 3)) - 0.5).astype(np.float32)
+    out.update(smp=smp, ref=ref)
+    r = em.EMD_CD_F1(T(smp), T(ref), 4, accelerated_cd=False, reduced=False, cd_option=True, one_part_of_cd=True,
+                     f1_option=True, f1_threshold=0.01)
+    out.update(pair_CD=npy(r['CD']), pair_CDL=npy(r['CDL']), pair_CDR=npy(r['CDR']), pair_F1=npy(r['F1']))
+    r = em.EMD_CD_F1(T(smp), T(ref), 4, accelerated_cd=False, reduced=True, cd_option=True, f1_option=True, f1_threshold=0.01)
+    out.update(pair_CD_mean=npy(r['CD']), pair_F1_mean=npy(r['F1']))
+    Mxx, Mxy, Myy = (torch.from_numpy(rng.random((5, 5)).astype(np.float32)) for _ in range(3))
+    Mxx, Myy = Mxx + Mxx.t(), Myy + Myy.t()
+    out.update(Mxx=npy(Mxx), Mxy=npy(Mxy), Myy=npy(Myy))
+    for k, sq in ((1, False), (3, True)):
+        res = em.knn(Mxx, Mxy, Myy, k, sqrt=sq)
+        out.update({f'knn{k}_{key}': npy(v) for key, v in res.items()})
+    D = torch.from_numpy(rng.random((6, 4)).astype(np.float32))
+    out['lgan_in'] = npy(D)
+    for mode in ('min', 'max'):
+        res = em.lgan_mmd_cov(D, mode)
+        out.update({f'lgan_{mode}_{key}': npy(v) for key, v in res.items()})
+    res = em.compute_all_metrics(T(smp), T(ref[:5]), 4, accelerated_cd=False, f1_threshold=0.01, cd_option=True,
+                                 one_part_of_cd=True, f1_option=True, emd_option=False)
+    names = sorted(res)
+    out['all_names'] = np.array(names)
+    for key in names:
+        out['all_' + key] = npy(res[key]) if torch.is_tensor(res[key]) else np.asarray(res[key])
+    c1 = (rng.random((9, 64, 3)) - 0.5).astype(np.float32) * 0.98
+    c2 = (0.25 * rng.standard_normal((7, 64, 3))).astype(np.float32).clip(-0.6, 0.6)   # some points outside the cube
+    out.update(c1=c1, c2=c2, occ1=ut.get_voxel_occ_dist(c1, warning=False), occ2=ut.get_voxel_occ_dist(c2, warning=False),
+               jsd=np.float64(ut.JSD(c1, c2, warning=False)))
+    save('g14_evaluation', **out)
+
+
 def contract():
     """Reference state_dict keys/shapes for a small decoder, as JSON (checkpoint contract)."""
     ref = rdec.LocalCondRNVPDecoder(2, 8, 16)
@@ -477,3 +544,4 @@ if __name__ == '__main__':
     g11_encoder()
     g12_prior()
     g13_full_model()
+    g14_evaluation_metrics()

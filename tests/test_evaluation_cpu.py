@@ -88,3 +88,46 @@ def test_jsd_follows_the_reference_binning_rule():
     want = entropy((h1 + h2).flatten() / 2, base=2) - 0.5 * (entropy(h1.flatten(), base=2) + entropy(h2.flatten(), base=2))
     assert abs(ev.JSD(c1, c2, warning=False) - want) < 1e-12
     assert ev.JSD(c1, c1, warning=False) < 1e-12
+
+
+def _g14():
+    import os
+    return np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g14_evaluation.npz'))
+
+
+def _close(a, b, tol=1e-6):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    return np.allclose(a, b, rtol=tol, atol=tol)
+
+
+def test_g14_host_metrics_match_the_reference():
+    """Vectors produced by the reference's own functions (lib/metrics/evaluation_metrics.py, lib/networks/utils.py), on every
+    path that does not enter its CUDA extension (tests/golden/make_golden.py::g14_evaluation_metrics)."""
+    D = _g14()
+    T = torch.from_numpy
+    first, second = ev.distChamfer(T(D['a']), T(D['b']))
+    assert _close(first, D['chamfer_first'], 1e-5) and _close(second, D['chamfer_second'], 1e-5)
+    smp, ref = T(D['smp']), T(D['ref'])
+    r = ev.EMD_CD_F1(smp, ref, 4, accelerated_cd=False, reduced=False, cd_option=True, one_part_of_cd=True, f1_option=True,
+                     f1_threshold=0.01)
+    for ours, theirs in (('CD', 'pair_CD'), ('CDL', 'pair_CDL'), ('CDR', 'pair_CDR'), ('F1', 'pair_F1')):
+        assert _close(r[ours], D[theirs], 1e-5), ours
+    r = ev.EMD_CD_F1(smp, ref, 4, accelerated_cd=False, reduced=True, cd_option=True, f1_option=True, f1_threshold=0.01)
+    assert _close(r['CD'], D['pair_CD_mean'], 1e-5) and _close(r['F1'], D['pair_F1_mean'], 1e-4)
+    Mxx, Mxy, Myy = T(D['Mxx']), T(D['Mxy']), T(D['Myy'])
+    for k, sq in ((1, False), (3, True)):
+        res = ev.knn(Mxx, Mxy, Myy, k, sqrt=sq)
+        for key, v in res.items():
+            assert _close(v, D[f'knn{k}_{key}']), (k, key)
+    for mode in ('min', 'max'):
+        res = ev.lgan_mmd_cov(T(D['lgan_in']), mode)
+        for key, v in res.items():
+            assert _close(v, D[f'lgan_{mode}_{key}']), (mode, key)
+    res = ev.compute_all_metrics(smp, ref[:5], 4, accelerated_cd=False, f1_threshold=0.01, cd_option=True, one_part_of_cd=True,
+                                 f1_option=True, emd_option=False)
+    assert sorted(res) == list(D['all_names'])
+    for key in res:
+        assert _close(res[key], D['all_' + key], 1e-5), key
+    assert np.array_equal(ev.get_voxel_occ_dist(D['c1'], warning=False), D['occ1'])
+    assert np.array_equal(ev.get_voxel_occ_dist(D['c2'], warning=False), D['occ2'])
+    assert abs(ev.JSD(D['c1'], D['c2'], warning=False) - float(D['jsd'])) < 1e-12

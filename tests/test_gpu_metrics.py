@@ -146,3 +146,21 @@ def test_evaluation_metrics_accelerated_path_matches_torch_path_and_oracle():
         assert abs(float(res[key]) - float(res_t[key])) < 1e-5 * max(1.0, abs(float(res_t[key]))), key
     assert '1-NN-EMD-acc' in res and 0.0 <= float(res['lgan_cov-EMD']) <= 1.0
     assert float(ev.compute_all_metrics(s, s.clone(), 4, accelerated_cd=True, cd_option=True, emd_option=True)['lgan_mmd-EMD']) < 1e-3
+
+
+def test_g14_hip_chamfer_matches_the_references_torch_chamfer():
+    """The reference treats its CUDA nn_distance and its pure-torch distChamfer as interchangeable (evaluation_metrics.py:
+    66-69).  The torch one runs here, so its outputs (golden g14) pin the HIP kernel's semantics -- squared distances, which
+    output belongs to which cloud -- to the reference itself, not only to our restatement.  Note distChamfer returns (per point
+    of b, per point of a) while nn_distance returns (per point of a, per point of b)."""
+    import os
+    from go_with_the_flows_amd import evaluation as ev
+    D = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g14_evaluation.npz'))
+    d1, d2 = metrics.distChamferCUDA(dev(D['a']), dev(D['b']))
+    assert np.allclose(d1.cpu().numpy(), D['chamfer_second'], atol=2e-6)
+    assert np.allclose(d2.cpu().numpy(), D['chamfer_first'], atol=2e-6)
+    # the evaluation entry points give the same numbers on the accelerated path as the reference's torch path does
+    # (the Chamfer SUM, F1's precision/recall pairing and the MMD/COV/1-NN bookkeeping do not depend on the order)
+    smp, ref = dev(D['smp']), dev(D['ref'])
+    r = ev.EMD_CD_F1(smp, ref, 4, accelerated_cd=True, reduced=False, cd_option=True, f1_option=True, f1_threshold=0.01)
+    assert np.allclose(r['CD'].cpu().numpy(), D['pair_CD'], atol=1e-5)

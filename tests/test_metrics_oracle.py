@@ -1,7 +1,7 @@
 """CPU checks of oracle/metrics_oracle.py (Chamfer / approximate EMD restatement) against independent facts.
 
-The reference has no fixtures for its CUDA structural losses (oracle header: parity unpinned), so the oracle is anchored
-on: float64 brute force, the reference's own pure-torch Chamfer formula (evaluation_metrics.py:35-45), exact optimal
+The reference has no fixtures for its CUDA structural losses; the Chamfer half is pinned through the reference's pure-torch
+distChamfer (golden g14), the approximate-EMD half stays unpinned (oracle header).  Further anchors: float64 brute force, the reference's own pure-torch Chamfer formula (evaluation_metrics.py:35-45), exact optimal
 transport for small sets, conservation of mass in the auction, and finite differences.
 """
 import numpy as np
@@ -14,6 +14,15 @@ from oracle import metrics_oracle as mo
 def clouds(seed, b, n, m, scale=0.5):
     r = np.random.default_rng(seed)
     return (r.standard_normal((b, n, 3)) * scale).astype(np.float32), (r.standard_normal((b, m, 3)) * scale).astype(np.float32)
+
+
+def test_nn_distance_oracle_matches_the_references_torch_chamfer_g14():
+    """Outputs of the reference's own distChamfer (golden g14): distChamfer returns (per point of b, per point of a)."""
+    import os
+    D = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'g14_evaluation.npz'))
+    d1, _, d2, _ = mo.nn_distance(D['a'], D['b'])
+    np.testing.assert_allclose(d1, D['chamfer_second'], atol=2e-6)
+    np.testing.assert_allclose(d2, D['chamfer_first'], atol=2e-6)
 
 
 @pytest.mark.parametrize('b,n,m', [(2, 64, 64), (3, 100, 37), (1, 5, 300)])
