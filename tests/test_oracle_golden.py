@@ -215,3 +215,18 @@ def test_g10_adam_oracle(ams):
             p, m, v, vmax = fo.adam_step(p, D[f'g_{ams}_{step}_{i}'], m, v, vmax, step + 1, lr, b1, b2, 1e-8, 1e-3, bool(ams))
             assert maxabs(p, D[f'p_{ams}_{step}_{i}']) < 2e-6
         assert maxabs(m, D[f'm_{ams}_{i}']) < 1e-6 and maxabs(vmax if ams else v, D[f'v_{ams}_{i}']) < 1e-6
+
+
+def test_lr_updater_class_follows_the_pinned_schedule():
+    """gw.optim.LRUpdater (the drop-in for optimizers.py:79-97) against the restatement that reproduces golden g10."""
+    from go_with_the_flows_amd.optim import LRUpdater
+
+    class Dummy:
+        param_groups = [dict(lr=0.0, betas=(0.0, 0.0)), dict(lr=0.0, betas=(0.0, 0.0))]
+
+    up = LRUpdater(10, **SCHED)
+    for epoch, it in [(0, 0), (0, 3), (1, 9), (3, 5), (4, 0), (7, 2), (11, 9)]:
+        up(Dummy, epoch, it)
+        lr, betas = lr_updater(10, epoch, it, **SCHED)
+        for grp in Dummy.param_groups:
+            assert abs(grp['lr'] - lr) < 1e-15 and grp['betas'][0] == betas[0] and abs(grp['betas'][1] - betas[1]) < 1e-15
