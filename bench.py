@@ -93,7 +93,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--workload', default='airplane', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--eager', action='store_true', help='launch through the eager module path instead of one hipGraph per step')
