@@ -200,6 +200,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    probe = []
+    if graph is not None:
+        # per-kernel duration of the dominant kernel: same launches, same inputs, eager, HIP events around each stack launch
+        # on the launch stream (a graph replay cannot be bracketed per kernel).  Runs BEFORE the warm-up and the timed
+        # region, so the timed steps also start from settled clocks whatever --warmup is.
+        with torch.no_grad():
+            for _ in range(100):            # ~50 ms of load: clocks settle before anything is measured
+                eager_step()
+            for _ in range(max(10, args.steps // 2)):
+                eager_step(probe)
+        torch.cuda.synchronize(dev)
+
     with torch.no_grad():
         for _ in range(args.warmup):
             step()
@@ -207,7 +219,7 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            # graph mode: no event records inside the timed region (the per-kernel probe runs afterwards, eagerly)
+            # graph mode: no event records inside the timed region (the per-kernel probe ran before, eagerly)
             step(timers if graph is None else None)
         sync_all()
         elapsed = time.perf_counter() - t0
@@ -220,15 +232,7 @@ def main():
     pts_per_step_per_gpu = B * N * comp_passes
     value = world * pts_per_step_per_gpu * args.steps / elapsed / 1e6
     if graph is not None:
-        # per-kernel duration of the dominant kernel: same launches, same inputs, eager, HIP events around each
-        # stack launch on the launch stream (a graph replay cannot be bracketed per kernel)
-        timers = []
-        with torch.no_grad():
-            for _ in range(3):
-                eager_step()
-            for _ in range(max(10, args.steps // 2)):
-                eager_step(timers)
-        torch.cuda.synchronize(dev)
+        timers = probe
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in timers]))           # one stack launch, HIP events
     pts_per_launch = B * N * comp_passes                                         # all components in one launch
     achieved = flops_per_point(L, f) * pts_per_launch / (kern_ms * 1e-3) / 1e12
