@@ -8,10 +8,14 @@ HBM: for every mixture component, the FiLM kernel + the fused coupling-stack ker
 eval-mode BatchNorm), producing the base-space coordinates and the per-coordinate sum of logvars.
 Weight packing is module preparation (cached while parameters are unchanged) and is outside the step,
 like BatchNorm folding for inference.  Metric (BASELINE.json): Mpoints/s, one "point" = one 3-D point
-pushed through one component's full stack.  N>1: one process per GPU (torch.distributed.run),
-batch of shapes sharded, per-GPU batch fixed (weak scaling), no data-path collective.
+pushed through one component's full stack.  N>1: one process per GPU, batch of shapes sharded, per-GPU batch
+fixed (weak scaling), no data-path collective; started either by the driver's `python -m
+torch.distributed.run ... bench.py --gpus N` or, when no launcher environment is present, by bench.py itself
+(`python bench.py --gpus N` spawns the N ranks before touching the GPU, like the reference's mp.spawn in train_ae.py:183-193).
 
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0: the BASELINE metric on configs[1] (`value`), `roofline` of the dominant kernel against
+the unit that executes it, `also.m1` = the metric's own B=32 x 2048 shape timed by the same protocol in the same run,
+and `cpu_baseline`.
 """
 import argparse
 import json
@@ -66,6 +70,16 @@ def host_cores():
     return max(1, min(n, 16))
 
 
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.lower().startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(cfg, budget_s=15.0):
     """PyTorch-CPU port of the reference forward (oracle/torch_port.py) on a bounded sample of the workload."""
     from oracle import torch_port as tp
@@ -83,42 +97,36 @@ def cpu_baseline(cfg, budget_s=15.0):
         tp.decoder_fused(pt, gt, tst, cfg['L'], cfg['mode'])
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {'value': round(bs * cfg['N'] / med / 1e6, 4), 'unit': 'Mpoints/s', 'cores': torch.get_num_threads(),
-            'kind': 'port',
+    rate = lambda t: round(bs * cfg['N'] / t / 1e6, 4)
+    return {'value': rate(med), 'unit': 'Mpoints/s', 'cores': torch.get_num_threads(),
+            'kind': 'port', 'cpu_model': cpu_model(), 'min': rate(max(times)), 'max': rate(min(times)), 'reps': len(times),
             'sample': f'oracle/torch_port.py (PyTorch-CPU restatement of the reference forward, pinned to its golden '
-                      f'vectors), one component, {bs} shapes x {cfg["N"]} points, median of {len(times)} reps'}
+                      f'vectors), one component, {bs} shapes x {cfg["N"]} points, median of {len(times)} reps '
+                      f'(min / max = slowest / fastest rep)'}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--workload', default='airplane', choices=sorted(WORKLOADS))
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--eager', action='store_true', help='launch through the eager module path instead of one hipGraph per step')
-    ap.add_argument('--points-per-wave', type=int, default=0, help='tuning hook: 16/32/64, 0 = library default')
-    args = ap.parse_args()
+def spawn_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through torch.distributed.run,
+    as the reference's train_ae.py:183-193 spawns its own workers.  The parent never touches the GPU (no HIP call before
+    or after the children start); the children's rank 0 prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    if args.dry_run_spawn:
+        print(json.dumps({'spawn': cmd}), flush=True)
+        return 0
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit(f'--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`')
-        args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)   # RCCL; used only for the barrier + max-over-ranks
 
-    cfg = WORKLOADS[args.workload]
+def run_workload(name, args, dev, rank, world, sync_all, reduce_max):
+    """Build one workload, time `args.steps` steps of it after `args.warmup` warm-up steps; -> dict of measurements."""
+    cfg = WORKLOADS[name]
     K, L, f, G, B, N, mode = (cfg[k] for k in ('K', 'L', 'f', 'G', 'B', 'N', 'mode'))
-    _lib.lib().gwtf_debug_set_points_per_wave(args.points_per_wave)
-
     decoders = []
     for k in range(K):
         d = gw.LocalCondRNVPDecoder(L, f, G)
@@ -126,7 +134,6 @@ def main():
         decoders.append(d.to(dev).eval())
     p, g = synth_inputs(B, N, G, 1000 * rank)          # every rank owns its own shard of shapes
     pd, gd = torch.from_numpy(p).to(dev), torch.from_numpy(g).to(dev)
-    engines = [d.engine() for d in decoders]
     eps = decoders[0].flows[0].nvp1._eps_value
     sideways = mode == 'direct' and K > 1                # sampling: each point visits ONE component
     stack = gw.MixtureStack(decoders)                    # K components: one FiLM launch + one stack launch
@@ -194,12 +201,6 @@ def main():
         def step(timers=None):                      # noqa: F811
             return eager_step(timers) if timers is not None else launch_step()
 
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
     probe = []
     if graph is not None:
         # per-kernel duration of the dominant kernel: same launches, same inputs, eager, HIP events around each stack launch
@@ -223,45 +224,113 @@ def main():
             step(timers if graph is None else None)
         sync_all()
         elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = reduce_max(elapsed)
 
     comp_passes = 1 if sideways else K
-    pts_per_step_per_gpu = B * N * comp_passes
-    value = world * pts_per_step_per_gpu * args.steps / elapsed / 1e6
+    pts_per_launch = B * N * comp_passes                                         # all components in one launch
     if graph is not None:
         timers = probe
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in timers]))           # one stack launch, HIP events
-    pts_per_launch = B * N * comp_passes                                         # all components in one launch
-    achieved = flops_per_point(L, f) * pts_per_launch / (kern_ms * 1e-3) / 1e12
+    return dict(cfg=cfg, value=world * pts_per_launch * args.steps / elapsed / 1e6, elapsed=elapsed, kern_ms=kern_ms,
+                pts_per_launch=pts_per_launch, with_nll=with_nll,
+                achieved=flops_per_point(L, f) * pts_per_launch / (kern_ms * 1e-3) / 1e12)
+
+
+def roofline_record(name, m):
+    """`roofline` object of the JSON line.  The unit that executes the f x f contraction is the f16 matrix pipe (three
+    f16 MFMA products per fp32 product, fp32 accumulate): its dense peak / 3 is the fp32-equivalent roof `frac` is
+    quoted against.  The fp32-MFMA roof (the dtype of the result) is kept as a secondary pair; against it the ratio can
+    exceed 1 because that unit is not the one doing the work."""
+    cfg = m['cfg']
+    peak = MFMA_F16_PEAK_TFLOPS / 3
+    traffic = None
+    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
+    if os.path.exists(tfile):
+        traffic = json.load(open(tfile)).get(name)
+    return {'bound': 'mfma', 'achieved': round(m['achieved'], 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
+            'frac': round(m['achieved'] / peak, 4), 'traffic': traffic,
+            'peak_basis': 'dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 product (the executing unit)',
+            'peak_fp32_mfma': MFMA_F32_PEAK_TFLOPS, 'ratio_vs_fp32_mfma': round(m['achieved'] / MFMA_F32_PEAK_TFLOPS, 4),
+            'kernel': 'stack_kernel (fused coupling stack)', 'kernel_ms': round(m['kern_ms'], 4),
+            'flop_per_point': flops_per_point(cfg['L'], cfg['f']), 'points_per_launch': m['pts_per_launch']}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--workload', default='airplane', choices=sorted(WORKLOADS))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-also', action='store_true', help='skip the secondary M1 (north-star shape) measurement')
+    ap.add_argument('--eager', action='store_true', help='launch through the eager module path instead of one hipGraph per step')
+    ap.add_argument('--points-per-wave', type=int, default=0, help='tuning hook: 16/32/64, 0 = library default')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help='process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo: rehearsal on one GPU)')
+    ap.add_argument('--share-device', action='store_true',
+                    help='rehearsal: every rank uses cuda:0 (RCCL refuses two ranks on one device, so use --backend gloo)')
+    ap.add_argument('--dry-run-spawn', action='store_true', help='print the launcher command instead of running it')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))        # before any GPU call in this process
+    args.gpus = world
+    dev_index = 0 if args.share_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)   # RCCL; used only for the barrier + max-over-ranks
+        else:
+            dist.init_process_group('gloo')
+    _lib.lib().gwtf_debug_set_points_per_wave(args.points_per_wave)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def reduce_max(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], device=dev if args.backend == 'nccl' else 'cpu', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    m = run_workload(args.workload, args, dev, rank, world, sync_all, reduce_max)
+    also = None
+    if args.workload != 'm1' and not args.no_also:
+        # the metric's own shape (B=32 x N=2048, the north-star module) timed by the same protocol in the same run
+        a = run_workload('m1', args, dev, rank, world, sync_all, reduce_max)
+        also = {'m1': {'value': round(a['value'], 3), 'unit': 'Mpoints/s', 'ms_per_step': round(a['elapsed'] / args.steps * 1e3, 4),
+                       'steps': args.steps, 'warmup': args.warmup, 'workload': a['cfg']['name'],
+                       'roofline': roofline_record('m1', a)}}
 
     if rank == 0:
-        traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-        if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get(args.workload)
+        cfg = m['cfg']
+        K, L, f, G, B, N, mode = (cfg[k] for k in ('K', 'L', 'f', 'G', 'B', 'N', 'mode'))
         line = {
-            'metric': 'point-flow fwd+logdet Mpoints/sec (B x 2048 pts)', 'value': round(value, 3), 'unit': 'Mpoints/s',
+            'metric': 'point-flow fwd+logdet Mpoints/sec (B x 2048 pts)', 'value': round(m['value'], 3), 'unit': 'Mpoints/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(elapsed / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'ms_per_step': round(m['elapsed'] / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': cfg['name'], 'per_gpu_batch': B, 'points_per_shape': N, 'components': K,
                        'couplings_per_component': 3 * L, 'f': f, 'G': G, 'direction': mode,
                        'point_definition': 'one 3-D point through one component stack (coords + sum logvars)',
                        'sharding': f'batch of shapes over {world} rank(s), no data-path collective',
                        'launch': ('eager: ' if args.eager else 'one hipGraph replay per step: ') + '1 FiLM + 1 stack launch for all components'
-                                 + (' + 1 mixture-NLL launch (per-shape NLL over K components)' if with_nll else '')},
-            'roofline': {'bound': 'mfma', 'achieved': round(achieved, 3), 'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4), 'traffic': traffic,
-                         'peak_split_f16': round(MFMA_F16_PEAK_TFLOPS / 3, 1),
-                         'frac_split_f16': round(achieved / (MFMA_F16_PEAK_TFLOPS / 3), 4),
-                         'note': 'fp32 result; sd1 contraction = 3 f16 MFMA products of hi/lo-split operands, fp32 '
-                                 'accumulate (fp32-grade accuracy), so frac vs the fp32 MFMA peak can exceed 1',
-                         'kernel': 'stack_kernel (fused coupling stack)', 'kernel_ms': round(kern_ms, 4),
-                         'flop_per_point': flops_per_point(L, f), 'points_per_launch': pts_per_launch},
+                                 + (' + 1 mixture-NLL launch (per-shape NLL over K components)' if m['with_nll'] else '')},
+            'roofline': roofline_record(args.workload, m),
         }
+        if also is not None:
+            line['also'] = also
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)

@@ -43,7 +43,7 @@ class PointNetCloudEncoder(nn.Module):
         for name, mod in self.features.named_children():
             if isinstance(mod, SharedDot):
                 out.append(mod.weight)
-            elif isinstance(mod, nn.BatchNorm1d):
+            elif isinstance(mod, nn.modules.batchnorm._BatchNorm):   # BatchNorm1d, or SyncBatchNorm after train_ae.py:152
                 out += [mod.weight, mod.bias, mod.running_mean, mod.running_var]
         return out
 

@@ -273,6 +273,12 @@ class StackEngine:
             raise ValueError(f"mode must be 'direct' or 'inverse', got {mode!r}")
         self._check(p, g)
         c0 = self.couplings[0]
+        if p.shape[2] == 0:
+            # an empty cloud (the sampling draw of flow_mixture.py:153 gave this component no point): the reference's torch ops
+            # pass empty tensors through; no launch here
+            B = p.shape[0]
+            lists = p.new_zeros(3, self.C, B, 3, 0, dtype=torch.float32) if want_lists else None
+            return p.new_zeros(B, 3, 0, dtype=torch.float32), p.new_zeros(B, 3, 0, dtype=torch.float32), lists
         needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
                                                   any(t.requires_grad for t in self._tracked or self._collect()))
         if needs_grad and c0.training:
@@ -330,7 +336,10 @@ class StackEngine:
             groups = {}
             for i, m in enumerate(mods):
                 if m.track_running_stats and m.running_mean is not None:
-                    groups.setdefault(0.1 if m.momentum is None else float(m.momentum), []).append(i)
+                    if m.momentum is None:
+                        raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported by the fused '
+                                                  'running-statistic update; the reference never sets it (flows.py:27-42)')
+                    groups.setdefault(float(m.momentum), []).append(i)
             plan = [(mom, idx, [mods[i].running_mean for i in idx], [mods[i].running_var for i in idx])
                     for mom, idx in groups.items()]
             self._bn_cache = (stamp, len(mods), plan, [m.num_batches_tracked for m in mods if m.num_batches_tracked is not None])

@@ -29,7 +29,8 @@ class Adam(Optimizer):
         arr = ctypes.c_void_p * n
         sts = [self.state[p] for p in plist]
         ptr = lambda ts: arr(*[t.data_ptr() for t in ts])
-        plan = {'n': n, 'arr': arr, 'dev': dev, 'step': step, 'ams': ams, 'states': sts, 'p0': plist[0].data_ptr(),
+        plan = {'n': n, 'arr': arr, 'dev': dev, 'step': step, 'ams': ams, 'states': sts, 'p0': plist[0].data_ptr(), 'plist': plist,
+                'ptrs': tuple(t.data_ptr() for t in plist),
                 'p': ptr(plist), 'm': ptr([s['exp_avg'] for s in sts]), 'v': ptr([s['exp_avg_sq'] for s in sts]),
                 'vmax': ptr([s['max_exp_avg_sq'] for s in sts]) if ams else None,
                 'numel': (ctypes.c_size_t * n)(*[p.numel() for p in plist])}
@@ -52,6 +53,17 @@ class Adam(Optimizer):
         return plan
 
     _TABLE_ABOVE = 48   # tensors per launch of the pointer-argument kernel (csrc/gwtf_adam.hip kMaxT)
+
+    @staticmethod
+    def _bump_versions(plist):
+        """The kernels write parameters through raw pointers: tell autograd / the packed-weight caches (which key on tensor
+        version counters, flows.StackEngine._key, encoders.packed) that the values changed.  No kernel is launched."""
+        bump = torch._C._increment_version
+        try:
+            bump(plist)                    # torch >= 2.4 takes an iterable
+        except TypeError:
+            for p in plist:
+                bump(p)
 
     @staticmethod
     def _launch(L, group, plan, grads, step):
@@ -97,7 +109,8 @@ class Adam(Optimizer):
             plan = self._plans.get(gi)
             # fast path: the same parameters as last step carry gradients (and only those), one common step count -> reuse
             # the pointer tables; only the step counters and the gradient pointers are touched
-            if plan is not None and plan['ams'] == ams and plan['n_group'] == len(params) and plan['p0'] == params[0].data_ptr():
+            if plan is not None and plan['ams'] == ams and plan['n_group'] == len(params) and \
+                    plan['ptrs'] == tuple(params[i].data_ptr() for i in plan['idx']):
                 all_grads = [p.grad for p in params]
                 grads = [all_grads[i] for i in plan['idx']]
                 if all(g is not None for g in grads) and sum(g is not None for g in all_grads) == plan['n']:
@@ -105,6 +118,7 @@ class Adam(Optimizer):
                     for st in plan['states']:
                         st['step'] = step
                     self._launch(L, group, plan, grads, step)
+                    self._bump_versions(plan['plist'])
                     continue
             self._plans.pop(gi, None)
             by_step = {}
@@ -129,6 +143,7 @@ class Adam(Optimizer):
                 plan = self._make_plan(plist, dev, step, ams)
                 plan['idx'], plan['n_group'], plan['p0'] = idx, len(params), params[0].data_ptr()
                 self._launch(L, group, plan, [p.grad for p in plist], step)
+                self._bump_versions(plist)
                 if len(by_step) == 1:
                     self._plans[gi] = plan
         return loss

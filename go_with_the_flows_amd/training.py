@@ -24,10 +24,23 @@ class GraphedTrainStep:
         self.use_warmup_weights = warmup
         side = torch.cuda.Stream(device=g_example.device)
         side.wait_stream(torch.cuda.current_stream(g_example.device))
+        # The warm-up iterations run forward + backward with no optimiser step in between: they must not leave a trace in the
+        # model (BatchNorm running statistics / num_batches_tracked) or in the random-number stream, or the state after
+        # construction would differ from the reference loop's (training.py:25-60) by `warmup_iters` phantom batches.
+        bn_state = [(b, b.detach().clone()) for b in model.buffers()]
+        rng_cpu, rng_dev = torch.get_rng_state(), torch.cuda.get_rng_state(g_example.device)
         with torch.cuda.stream(side):
             for _ in range(warmup_iters):              # allocator + lazy initialisation outside the capture
                 self._fwd_bwd()
+            with torch.no_grad():
+                for b, saved in bn_state:
+                    b.copy_(saved)
         torch.cuda.current_stream(g_example.device).wait_stream(side)
+        torch.set_rng_state(rng_cpu)
+        torch.cuda.set_rng_state(rng_dev, g_example.device)
+        for mod in model.modules():                    # restored buffers: drop every packed-weight cache keyed on them
+            if hasattr(mod, 'invalidate_packed_weights'):
+                mod.invalidate_packed_weights()
         # no autograd graph of an earlier iteration may be alive during capture (hipStreamEndCapture crashes otherwise)
         self.terms = None
         optimizer.zero_grad(set_to_none=True)

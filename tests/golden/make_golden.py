@@ -526,22 +526,32 @@ def contract():
     print('contract.json', len(spec), 'entries')
 
 
+CASES = {
+    'contract': contract,
+    'g1': g1_single_couplings,
+    'g2': g2_triples,
+    'g3': lambda: decoder_case('g3_decoder_4x64x128', 4, 64, 128, 4, 512, 400, full_lists=False, train_too=True),
+    'g3s': lambda: decoder_case('g3s_decoder_lists', 2, 8, 16, 2, 24, 410, full_lists=True, train_too=True),
+    'g4_37': lambda: decoder_case('g4_width37', 2, 37, 128, 2, 64, 420, full_lists=False, train_too=False),
+    'g4_33': lambda: decoder_case('g4_width33', 2, 33, 512, 2, 64, 430, full_lists=False, train_too=False),
+    'g4_19': lambda: decoder_case('g4_width19', 2, 19, 128, 2, 64, 440, full_lists=False, train_too=False),
+    'g5': g5_losses,
+    'g6': g6_keep_drift,
+    'g7': g7_model_training_forward,
+    'g8': g8_gradients,
+    'g9': g9_train_gradients,
+    'g10': g10_optimizer,
+    'g11': g11_encoder,
+    'g12': g12_prior,
+    'g13': g13_full_model,
+    'g14': g14_evaluation_metrics,
+    # the decoders of BASELINE.json's configs at their FULL depth (33 / 33 / 18 couplings), genuine reference, fp32 + fp64
+    'g15_airplane': lambda: decoder_case('g15_depth_11x37x128', 11, 37, 128, 2, 256, 1500, full_lists=False, train_too=False),
+    'g15_ae': lambda: decoder_case('g15_depth_11x33x512', 11, 33, 512, 2, 128, 1510, full_lists=False, train_too=False),
+    'g15_k16': lambda: decoder_case('g15_depth_6x19x128', 6, 19, 128, 2, 256, 1520, full_lists=False, train_too=False),
+}
+
 if __name__ == '__main__':
-    contract()
-    g1_single_couplings()
-    g2_triples()
-    decoder_case('g3_decoder_4x64x128', 4, 64, 128, 4, 512, 400, full_lists=False, train_too=True)
-    decoder_case('g3s_decoder_lists', 2, 8, 16, 2, 24, 410, full_lists=True, train_too=True)
-    decoder_case('g4_width37', 2, 37, 128, 2, 64, 420, full_lists=False, train_too=False)
-    decoder_case('g4_width33', 2, 33, 512, 2, 64, 430, full_lists=False, train_too=False)
-    decoder_case('g4_width19', 2, 19, 128, 2, 64, 440, full_lists=False, train_too=False)
-    g5_losses()
-    g6_keep_drift()
-    g7_model_training_forward()
-    g8_gradients()
-    g9_train_gradients()
-    g10_optimizer()
-    g11_encoder()
-    g12_prior()
-    g13_full_model()
-    g14_evaluation_metrics()
+    # no arguments: regenerate everything; otherwise only the named cases (see CASES)
+    for name in (sys.argv[1:] or list(CASES)):
+        CASES[name]()

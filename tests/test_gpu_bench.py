@@ -1,0 +1,37 @@
+"""bench.py end to end on the GPU box: the single-GPU line and the self-spawned 2-rank rehearsal (two processes on the one
+card, gloo for the barrier / max-over-ranks because RCCL refuses two ranks on one device)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '5', '--warmup', '3', '--no-cpu-baseline'] + extra,
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_roofline_and_m1():
+    line = _run([])
+    assert line['n_gpus'] == 1 and line['value'] > 0 and line['scaling'] == 'weak'
+    r = line['roofline']
+    assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert line['also']['m1']['value'] > 0 and 0 < line['also']['m1']['roofline']['frac'] < 1
+
+
+def test_gpus_2_spawns_itself_and_reports_the_aggregate():
+    line = _run(['--gpus', '2', '--backend', 'gloo', '--share-device', '--no-also'])
+    assert line['n_gpus'] == 2 and line['value'] > 0
+    # value = points of BOTH ranks / max-over-ranks time
+    pts = 2 * line['config']['per_gpu_batch'] * line['config']['points_per_shape'] * line['config']['components']
+    assert abs(line['value'] - pts / (line['ms_per_step'] * 1e-3) / 1e6) / line['value'] < 1e-2

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import golden, TOL_COORD, TOL_LOGDET, TOL_NLL_REL
+from conftest import golden, TOL_COORD, TOL_LOGDET, TOL_NLL_REL, tol_at_depth, record_parity
 from helpers import decoder_and_state, coupling_and_state, triple_and_state, state64, maxabs
 import go_with_the_flows_amd as gw
 from go_with_the_flows_amd import _lib
@@ -98,6 +98,108 @@ def test_decoder_golden(name, mode, pts_per_wave):
     ref64 = D['first64_' + tag] if mode == 'inverse' else D['last64_' + tag]
     assert maxabs(host(out), ref64) < TOL_COORD
     assert maxabs(host(logdet), D['logdet64_' + tag]) < TOL_LOGDET
+
+
+DEPTH_CASES = ['g15_depth_11x37x128', 'g15_depth_11x33x512', 'g15_depth_6x19x128']
+
+
+@pytest.mark.parametrize('name', DEPTH_CASES)
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+@pytest.mark.parametrize('pts_per_wave', [0, 64])
+def test_decoder_at_config_depth_golden(name, mode, pts_per_wave):
+    """The decoders of BASELINE.json's configs at their FULL depth (33 / 33 / 18 couplings, f = 37 / 33 / 19) against the
+    genuine reference's fp32 and fp64 runs (reference decoders.py:61-79), tolerance of conftest.tol_at_depth (BASELINE.md 4);
+    the measured errors are recorded."""
+    D = golden(name)
+    L, f, G, B, N, seed = D['dims']
+    m, _ = decoder_and_state(L, f, G, seed)
+    m = m.to(DEV).eval()
+    _lib.lib().gwtf_debug_set_points_per_wave(pts_per_wave)
+    tag = f'eval_{mode}'
+    with torch.no_grad():
+        out, logdet = m.forward_fused(dev(D['p']), dev(D['g']), mode=mode)
+        ps, _, lvs = m(dev(D['p']), dev(D['g']), mode=mode)
+    assert torch.equal(out, ps[0] if mode == 'inverse' else ps[-1])
+    ref32 = D[('first_' if mode == 'inverse' else 'last_') + tag]
+    ref64 = D[('first64_' if mode == 'inverse' else 'last64_') + tag]
+    tol_c, tol_l = tol_at_depth(3 * L, max(np.abs(ref64).max(), np.abs(D['p']).max()))
+    errs = dict(hip_vs_ref64_coord=maxabs(host(out), ref64), hip_vs_ref64_logdet=maxabs(host(logdet), D['logdet64_' + tag]),
+                hip_vs_ref32_coord=maxabs(host(out), ref32), hip_vs_ref32_logdet=maxabs(host(logdet), D['logdet_' + tag]),
+                ref32_vs_ref64_coord=maxabs(ref32, ref64), ref32_vs_ref64_logdet=maxabs(D['logdet_' + tag], D['logdet64_' + tag]),
+                tol_coord=tol_c, tol_logdet=tol_l)
+    record_parity(f'gpu:{name}:{mode}:ppw{pts_per_wave}', **errs)
+    assert errs['hip_vs_ref64_coord'] < tol_c and errs['hip_vs_ref64_logdet'] < tol_l
+    assert errs['hip_vs_ref32_coord'] < tol_c and errs['hip_vs_ref32_logdet'] < tol_l
+    assert maxabs(host(sum(lvs)), D['logdet64_' + tag]) < tol_l
+    # and no worse than a small multiple of the reference's own fp32 rounding noise
+    assert errs['hip_vs_ref64_coord'] < 3 * errs['ref32_vs_ref64_coord'] + TOL_COORD / 4
+    assert errs['hip_vs_ref64_logdet'] < 3 * errs['ref32_vs_ref64_logdet'] + TOL_LOGDET / 4
+
+
+def test_k16_partitioned_sampling_at_config_size():
+    """BASELINE configs[3]: K=16 components of 6 Triples, f=19, G=128; ONE shape of N=2048 points split among the components
+    by the reference's multinomial draw (flow_mixture.py:146-160), each segment through its own component in ONE partitioned
+    launch, against the oracle per segment; plus a batched B=3 variant with the same counts."""
+    K, L, f, G, N = 16, 6, 19, 128, 2048
+    pairs = [decoder_and_state(L, f, G, 3000 + k) for k in range(K)]
+    ms = gw.MixtureStack([m.to(DEV).eval() for m, _ in pairs])
+    rng = np.random.default_rng(3100)
+    logits = rng.standard_normal(K)
+    probs = np.exp(logits) / np.exp(logits).sum()
+    np.random.seed(3101)
+    flows_idx = np.random.choice(range(K), size=N, p=probs)
+    counts = [int((flows_idx == t).sum()) for t in range(K)]
+    assert sum(counts) == N
+    worst_c = worst_l = 0.0
+    for B in (1, 3):
+        zin, g = synth_inputs(B, N, G, 3200 + B)
+        zin = (zin / 0.3).astype(np.float32)                 # base-space samples ~ N(0, 1)
+        with torch.no_grad():
+            x, ld = ms.forward_partition(dev(zin), dev(g), counts, 'direct')
+        off = 0
+        tol_c, tol_l = tol_at_depth(3 * L, np.abs(host(x)).max())
+        for k, cnt in enumerate(counts):
+            if cnt:
+                ref_x, ref_ld = fo.decoder_fused(zin[:, :, off:off + cnt], g, pairs[k][1], L, 'direct')
+                ec, el = maxabs(host(x)[:, :, off:off + cnt], ref_x), maxabs(host(ld)[:, :, off:off + cnt], ref_ld)
+                worst_c, worst_l = max(worst_c, ec), max(worst_l, el)
+                assert ec < tol_c and el < tol_l, (B, k, cnt, ec, el)
+            off += cnt
+    record_parity('gpu:k16_partition_f19_N2048', coord=worst_c, logdet=worst_l, tol_coord=tol_c, tol_logdet=tol_l)
+
+
+def test_airplane_batched_launch_and_mixture_nll_at_config_size():
+    """BASELINE configs[1] exactly as bench.py launches it: K=4 components x 33 couplings, f=37, G=128, B=64 x N=2048, one
+    batched inverse launch + the fused mixture NLL; three shapes of the batch against the oracle (all K components)."""
+    K, L, f, G, B, N = 4, 11, 37, 128, 64, 2048
+    pairs = [decoder_and_state(L, f, G, 3300 + k) for k in range(K)]
+    ms = gw.MixtureStack([m.to(DEV).eval() for m, _ in pairs])
+    p, g = synth_inputs(B, N, G, 3400)
+    rng = np.random.default_rng(3401)
+    mu0 = (0.05 * rng.standard_normal((K, B, 3))).astype(np.float32)
+    lv0 = (0.2 * rng.standard_normal((K, B, 3))).astype(np.float32)
+    logits = rng.standard_normal((B, K)).astype(np.float32)
+    with torch.no_grad():
+        z, ld = ms.forward_all(dev(p), dev(g), 'inverse')
+        nll = _lib.mixture_nll(z, ld, dev(mu0), dev(lv0), dev(logits))
+    assert z.shape == (K, B, 3, N)
+    shapes = [0, 31, 63]
+    zr = np.zeros((K, len(shapes), 3, N), np.float32)
+    lr = np.zeros_like(zr)
+    for k in range(K):
+        zr[k], lr[k] = fo.decoder_fused(p[shapes], g[shapes], pairs[k][1], L, 'inverse')
+    tol_c, tol_l = tol_at_depth(3 * L, max(np.abs(zr).max(), np.abs(p).max()))
+    ec, el = maxabs(host(z)[:, shapes], zr), maxabs(host(ld)[:, shapes], lr)
+    _, per_shape = fo.mixture_nll_fused(zr, lr, mu0[:, shapes], lv0[:, shapes], logits[shapes])
+    en = float(np.max(np.abs(host(nll)[shapes] - per_shape) / np.abs(per_shape)))
+    # the NLL kernel itself on the HIP z / logdet: isolates its own error from the stack's
+    _, per_shape_hip_in = fo.mixture_nll_fused(host(z)[:, shapes], host(ld)[:, shapes], mu0[:, shapes], lv0[:, shapes], logits[shapes])
+    en_kernel = float(np.max(np.abs(host(nll)[shapes] - per_shape_hip_in) / np.abs(per_shape_hip_in)))
+    record_parity('gpu:airplane_K4_f37_64x2048', coord=ec, logdet=el, nll_rel=en, nll_rel_kernel_only=en_kernel,
+                  tol_coord=tol_c, tol_logdet=tol_l)
+    assert ec < tol_c and el < tol_l
+    assert en_kernel < TOL_NLL_REL and en < 3 * TOL_NLL_REL
+    assert np.isfinite(host(nll)).all()
 
 
 def test_g6_kept_coordinate_drift():

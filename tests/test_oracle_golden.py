@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden, TOL_COORD, TOL_LOGDET
+from conftest import golden, TOL_COORD, TOL_LOGDET, tol_at_depth, record_parity
 from helpers import decoder_and_state, coupling_and_state, triple_and_state, state64, maxabs
 import go_with_the_flows_amd as gw
 from oracle import flow_oracle as fo
@@ -74,6 +74,34 @@ def test_decoder_eval(name, mode):
     ref32 = D['first_' + tag] if mode == 'inverse' else D['last_' + tag]
     assert maxabs(ref32, ref_out) < TOL_COORD
     assert maxabs(D['logdet_' + tag], D['logdet64_' + tag]) < TOL_LOGDET
+
+
+DEPTH_CASES = ['g15_depth_11x37x128', 'g15_depth_11x33x512', 'g15_depth_6x19x128']
+
+
+@pytest.mark.parametrize('name', DEPTH_CASES)
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+def test_decoder_at_config_depth(name, mode):
+    """The decoders of BASELINE.json's configs at their full depth (33 / 33 / 18 couplings): genuine reference, fp32 and fp64."""
+    D = golden(name)
+    L, f, G, B, N, seed = D['dims']
+    _, st = decoder_and_state(L, f, G, seed)
+    tag = f'eval_{mode}'
+    ref32 = D[('first_' if mode == 'inverse' else 'last_') + tag]
+    ref64 = D[('first64_' if mode == 'inverse' else 'last64_') + tag]
+    # restatement error (fp64 oracle against the reference's fp64 run): exact up to summation order
+    p64, g64 = fo.cast_inputs(np.float64, D['p'], D['g'])
+    out64, ld64 = fo.decoder_fused(p64, g64, state64(st), L, mode)
+    assert maxabs(out64, ref64) < 1e-9 and maxabs(ld64, D['logdet64_' + tag]) < 1e-9
+    # fp32 oracle and the reference's own fp32 run against the fp64 run: inside the depth-scaled tolerance
+    tol_c, tol_l = tol_at_depth(3 * L, max(np.abs(ref64).max(), np.abs(D['p']).max()))
+    out32, ld32 = fo.decoder_fused(D['p'], D['g'], st, L, mode)
+    errs = dict(oracle32_vs_ref64_coord=maxabs(out32, ref64), oracle32_vs_ref64_logdet=maxabs(ld32, D['logdet64_' + tag]),
+                ref32_vs_ref64_coord=maxabs(ref32, ref64), ref32_vs_ref64_logdet=maxabs(D['logdet_' + tag], D['logdet64_' + tag]),
+                tol_coord=tol_c, tol_logdet=tol_l)
+    record_parity(f'cpu:{name}:{mode}', **errs)
+    assert errs['oracle32_vs_ref64_coord'] < tol_c and errs['oracle32_vs_ref64_logdet'] < tol_l
+    assert errs['ref32_vs_ref64_coord'] < tol_c and errs['ref32_vs_ref64_logdet'] < tol_l
 
 
 @pytest.mark.parametrize('name', ['g3_decoder_4x64x128', 'g3s_decoder_lists'])
