@@ -184,10 +184,13 @@ def test_airplane_batched_launch_and_mixture_nll_at_config_size():
         nll = _lib.mixture_nll(z, ld, dev(mu0), dev(lv0), dev(logits))
     assert z.shape == (K, B, 3, N)
     shapes = [0, 31, 63]
-    zr = np.zeros((K, len(shapes), 3, N), np.float32)
+    zr = np.zeros((K, len(shapes), 3, N), np.float64)            # fp64 oracle: the fp32 one carries its own rounding noise
     lr = np.zeros_like(zr)
+    e32c = e32l = 0.0
     for k in range(K):
-        zr[k], lr[k] = fo.decoder_fused(p[shapes], g[shapes], pairs[k][1], L, 'inverse')
+        zr[k], lr[k] = fo.decoder_fused(p[shapes].astype(np.float64), g[shapes].astype(np.float64), state64(pairs[k][1]), L, 'inverse')
+        z32, l32 = fo.decoder_fused(p[shapes], g[shapes], pairs[k][1], L, 'inverse')
+        e32c, e32l = max(e32c, maxabs(z32, zr[k])), max(e32l, maxabs(l32, lr[k]))
     tol_c, tol_l = tol_at_depth(3 * L, max(np.abs(zr).max(), np.abs(p).max()))
     ec, el = maxabs(host(z)[:, shapes], zr), maxabs(host(ld)[:, shapes], lr)
     _, per_shape = fo.mixture_nll_fused(zr, lr, mu0[:, shapes], lv0[:, shapes], logits[shapes])
@@ -195,9 +198,11 @@ def test_airplane_batched_launch_and_mixture_nll_at_config_size():
     # the NLL kernel itself on the HIP z / logdet: isolates its own error from the stack's
     _, per_shape_hip_in = fo.mixture_nll_fused(host(z)[:, shapes], host(ld)[:, shapes], mu0[:, shapes], lv0[:, shapes], logits[shapes])
     en_kernel = float(np.max(np.abs(host(nll)[shapes] - per_shape_hip_in) / np.abs(per_shape_hip_in)))
-    record_parity('gpu:airplane_K4_f37_64x2048', coord=ec, logdet=el, nll_rel=en, nll_rel_kernel_only=en_kernel,
+    record_parity('gpu:airplane_K4_f37_64x2048', hip_vs_oracle64_coord=ec, hip_vs_oracle64_logdet=el,
+                  oracle32_vs_oracle64_coord=e32c, oracle32_vs_oracle64_logdet=e32l, nll_rel=en, nll_rel_kernel_only=en_kernel,
                   tol_coord=tol_c, tol_logdet=tol_l)
     assert ec < tol_c and el < tol_l
+    assert ec < 3 * e32c + TOL_COORD / 4 and el < 3 * e32l + TOL_LOGDET / 4      # no worse than fp32 evaluation noise
     assert en_kernel < TOL_NLL_REL and en < 3 * TOL_NLL_REL
     assert np.isfinite(host(nll)).all()
 
