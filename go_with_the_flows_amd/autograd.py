@@ -93,6 +93,20 @@ def fold(engine, g, eps):
     a = eps + torch.exp(o[:, :, :, 0])
     cvec = c1 + o[:, :, :, 1] / a
     u = P['W2'].unsqueeze(0) * a.unsqueeze(3)
+    # Range scaling of the split-f16 contraction's operands, as the eval packer applies it (csrc/gwtf_layout.h, RANGE SCALING):
+    # exact powers of two -- constants for autograd, which un-scales every gradient by the chain rule.
+    with torch.no_grad():
+        def floor_log2(t, lo, hi, shift=0):
+            e = torch.frexp(t)[1].to(torch.float32) - 1.0 - shift
+            ok = (t > 0) & torch.isfinite(t)
+            return torch.where(ok, e.clamp(lo, hi), torch.zeros_like(e))
+        cs = floor_log2(W0f.abs().sum(-1) + c0f.abs(), -40, 40)                       # (C,2,f)  per sd1 input feature
+        rs = floor_log2((W1p * torch.exp2(cs).unsqueeze(-2)).abs().amax(-1), -50, 50, shift=12)   # (C,2,f)  per sd1 output row
+        up_c, dn_c, up_r, dn_r = torch.exp2(cs), torch.exp2(-cs), torch.exp2(rs), torch.exp2(-rs)
+    W0f, c0f = W0f * dn_c.unsqueeze(-1), c0f * dn_c
+    W1p = W1p * (up_c.unsqueeze(-2) * dn_r.unsqueeze(-1))
+    cvec = cvec * dn_r
+    u = u * up_r.unsqueeze(0).unsqueeze(3)
     return W0f, c0f, W1p, cvec, u, P['b2']
 
 

@@ -282,6 +282,12 @@ __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict_
     }
   }
   const float c1 = w[P.c1() + ft], w20 = w[P.w2() + ft], w21 = w[P.w2() + FP + ft];
+  // NaN / Inf must reach the outputs (the reference aborts on a non-finite loss, training.py:43-46) although the stack
+  // kernel's ReLU is a v_max that returns 0 for a NaN accumulator: a non-finite head output (non-finite latent or FiLM
+  // weight) turns the whole record entry into NaN -- u = NaN survives the ReLU as relu(acc) * NaN -- and POISON (NaN when
+  // any weight of the coupling is non-finite, gwtf_pack.hip) is added to the sd2 biases.  Bit tests: -fno-honor-nans.
+  const float qnan = __builtin_bit_cast(float, 0x7fc00000u);
+  const float poison = w[P.poison()];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int b = b0 + 4 * q + r;
@@ -292,12 +298,14 @@ __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict_
         cv = c1 + o[1][r] / a;
         u0 = w20 * a;
         u1 = w21 * a;
+        const unsigned bits = __builtin_bit_cast(unsigned, o[0][r]) | __builtin_bit_cast(unsigned, o[1][r]);
+        if ((bits & 0x7f800000u) == 0x7f800000u) cv = u0 = u1 = qnan;
       }
       float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + ft;
       ob[0] = cv;
       ob[FP] = u0;
       ob[2 * FP] = u1;
-      if (ft < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + ft] = w[P.b2() + ft];
+      if (ft < 2) out[((size_t)b * C + c) * FS + 6 * FP + 2 * br + ft] = w[P.b2() + ft] + poison;
     }
   }
 }

@@ -124,7 +124,16 @@ GWTF_HD float gwtf_w1t_slot(const GwtfPackB& P, size_t o /* offset inside one br
 
 // PACKED FILM WEIGHTS (read by gwtf_film_forward), per coupling, per branch:
 //   for which in {w,b}: L0T[GP][FP] (GP = G rounded up to 16, zero rows beyond G) | S[FP] | T[FP] | L1T[FP][FP] | L1B[FP]
-//   C1[FP] (sd1_bn shift: -mean/sqrt(var+eps)) | W2[2][FP] | B2[4] (sd2 bias, 2 used)
+//   C1[FP] (sd1_bn shift: -mean/sqrt(var+eps)) | W2[2][FP] | B2[4] (sd2 bias, 2 used; slot 2 = POISON: 0, or NaN when the
+//   coupling's raw record holds a non-finite value -- added to both biases by the FiLM kernel so that diverged weights reach
+//   every output, reference training.py:43-46) | RS[FP] | CS[FP]
+// RANGE SCALING (eval packing; exact, powers of two only).  The split-f16 contraction needs its operands inside the f16
+// range: CS[j] = floor(log2(|w0a_j| + |w0b_j| + |c0_j|)) of the folded sd0 -- the sd0 record is stored times 2^-CS[j], so
+// h'_j = relu(pre_j) 2^-CS[j] < 2 max(1, |x|) and f16 overflows only beyond |x| ~ 3e4 (the stack kernel flags that) --
+// and RS[i] = floor(log2(max_j |W1'_ij| 2^CS[j])) - 12: the A images hold W1'_ij 2^(CS[j] - RS[i]) (row maximum in [2^12, 2^13):
+// hi and lo parts both normal for every entry within 2^-14 of it).  The accumulators then carry 2^-RS[i] (y_i + c_i): RS is
+// folded into the FiLM weights that produce c (C1, the b head's second Linear) and, inversely, into W2 (u = W2 a), so the
+// FiLM and stack kernels are unchanged.  Train packing stores zeros (batch statistics normalise the activations).
 // eval packing stores L0T and L1T with four input columns interleaved, L0Q[GP/4][FP][4] / L1Q[FP/4][FP][4] (same sizes):
 // film_eval_kernel's lane owns
 // one feature and reads its four k-slots of an MFMA k-group with one 16-byte load, 16 lanes = 256 contiguous bytes.
@@ -143,9 +152,13 @@ struct GwtfPackF {
   GWTF_HD size_t c1() const { return 2 * mlp_size(); }
   GWTF_HD size_t w2() const { return c1() + FP; }
   GWTF_HD size_t b2() const { return w2() + 2 * (size_t)FP; }
-  GWTF_HD size_t branch_size() const { return b2() + 4; }
+  GWTF_HD size_t poison() const { return b2() + 2; }
+  GWTF_HD size_t rs() const { return b2() + 4; }
+  GWTF_HD size_t cs() const { return rs() + FP; }
+  GWTF_HD size_t branch_size() const { return cs() + FP; }
   GWTF_HD size_t coupling_size() const { return 2 * branch_size(); }
 };
+#define GWTF_X_LIMIT 3.0e4f   // |coordinate| beyond which the f16 image of sd0's activations may overflow: results are NaN
 
 // FILM OUTPUT (written by gwtf_film_forward, read by the fused kernel through LDS), per (shape b, coupling c):
 //   for branch in {logvar, mu}:  c[FP] | w20a[FP] | w21a[FP]   with a = eps + exp(cond_w(g)) > 0, b = cond_b(g):

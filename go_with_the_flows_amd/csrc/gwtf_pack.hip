@@ -11,11 +11,65 @@ namespace {
 
 __device__ __forceinline__ float inv_std(float var) { return 1.0f / sqrtf(var + GWTF_BN_EPS); }
 
+// bit tests: the library is built with -fno-honor-nans, under which x != x or isfinite(x) may be folded away
+__device__ __forceinline__ bool nonfinite(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ int floor_log2(float x) {   // x > 0, finite
+  int e;
+  frexpf(x, &e);
+  return e - 1;
+}
+
+// Range scaling exponents + poison of every (coupling, branch) -> packed_film's RS / CS / POISON slots (gwtf_layout.h).
+// One workgroup per branch record; runs before the two gather kernels below, which read the exponents.
+__global__ __launch_bounds__(256) void pack_scales_kernel(const float* __restrict__ raw, float* __restrict__ pf, int C, int f,
+                                                          int G, int FP, int training, int pattern0) {
+  const GwtfRaw R(f, G);
+  const GwtfPackF P(FP, G);
+  const int cb = blockIdx.x, c = cb >> 1, t = threadIdx.x;
+  const float* rb = raw + (size_t)cb * R.branch_size();
+  float* w = pf + (size_t)cb * P.branch_size();
+  __shared__ int s_cs[GWTF_MAX_FP], s_bad;
+  if (t == 0) s_bad = 0;
+  __syncthreads();
+  bool bad = false;
+  for (size_t i = t; i < R.branch_size(); i += blockDim.x) bad |= nonfinite(rb[i]);
+  if (bad) s_bad = 1;
+  if (t < FP) {
+    int cs = 0;
+    if (!training && t < f) {
+      const float* bn = rb + R.bn0();
+      const float s = bn[t] * inv_std(bn[3 * f + t]);
+      const int k = gwtf_pattern_kept((pattern0 + c) % 6);
+      const float wa = rb[R.sd0_w(t, 0, k)] * s, wb = k > 1 ? rb[R.sd0_w(t, 1, k)] * s : 0.f, c0 = bn[f + t] - bn[2 * f + t] * s;
+      const float T = fabsf(wa) + fabsf(wb) + fabsf(c0);
+      if (T > 0.f && !nonfinite(T)) cs = min(40, max(-40, floor_log2(T)));
+    }
+    s_cs[t] = cs;
+    w[P.cs() + t] = (float)cs;
+  }
+  __syncthreads();
+  if (t < FP) {
+    int rs = 0;
+    if (!training && t < f) {
+      const float sc = inv_std(rb[R.bn1() + f + t]);
+      float m = 0.f;
+      for (int j = 0; j < f; ++j) m = fmaxf(m, fabsf(ldexpf(rb[R.sd1_w() + (size_t)t * f + j] * sc, s_cs[j])));
+      if (m > 0.f && !nonfinite(m)) rs = min(50, max(-50, floor_log2(m) - 12));
+    }
+    w[P.rs() + t] = (float)rs;
+  }
+  if (t == 0) {
+    w[P.poison()] = s_bad ? __builtin_bit_cast(float, 0x7fc00000u) : 0.f;
+    w[P.poison() + 1] = 0.f;
+  }
+}
+
 // packed stack weights (split-f16 fragment images + sd0 parameters), see gwtf_layout.h
-__global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__ out, int C, int f, int G, int FP,
-                              int training, int pattern0) {
+__global__ void pack_w_kernel(const float* __restrict__ raw, const float* __restrict__ pf, float* __restrict__ out, int C,
+                              int f, int G, int FP, int training, int pattern0) {
   const GwtfRaw R(f, G);
   const GwtfPackW P(FP);
+  const GwtfPackF PF(FP, G);
   const size_t per = P.coupling_size();
   const size_t total = per * (size_t)C;
   const int MB = P.MB(), KS = P.KS();
@@ -36,13 +90,15 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__
       const int jo = 16 * m + (lane & 15);  // output feature (row of sd1.weight)
       __half2 pk = __floats2half2_rn(0.f, 0.f);
       if (ks < KS && jo < f) {
+        const float* ex = pf + ((size_t)c * 2 + br) * PF.branch_size();     // range-scaling exponents (pack_scales_kernel)
+        const int rs = (int)ex[PF.rs() + jo];
         const float sc = training ? 1.0f : inv_std(rb[R.bn1() + f + jo]);   // train: sd1_bn is applied via fold1
         const GwtfA16Slot sl = gwtf_a16_slot(f, KS, ks, part, jp);   // f = 33..40: merged image of the short k-step
         float e[2];
         for (int t = 0; t < 2; ++t) {
           const int ji = 32 * ks + 4 * (2 * sl.jsrc + t) + (lane >> 4);  // input feature
           float w = 0.f;
-          if (ji < f && !sl.zero) w = rb[R.sd1_w() + (size_t)jo * f + ji] * sc;
+          if (ji < f && !sl.zero) w = ldexpf(rb[R.sd1_w() + (size_t)jo * f + ji] * sc, (int)ex[PF.cs() + ji] - rs);
           const float hi = __half2float(__float2half_rn(w));
           e[t] = sl.lo ? (w - hi) : hi;
         }
@@ -60,6 +116,7 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, float* __restrict__
         const float s = bn[ft] * inv_std(bn[3 * f + ft]);
         const int k = gwtf_pattern_kept((pattern0 + c) % 6);
         v = e < 2 ? (e < k ? rb[R.sd0_w(ft, e, k)] * s : 0.f) : bn[f + ft] - bn[2 * f + ft] * s;
+        v = ldexpf(v, -(int)pf[((size_t)c * 2 + br) * PF.branch_size() + PF.cs() + ft]);
       }
     }
     out[idx] = v;
@@ -77,7 +134,9 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
     const int cb = (int)(idx / perb);  // coupling*2 + branch
     size_t o = idx - (size_t)cb * perb;
     const float* rb = raw + (size_t)cb * R.branch_size();  // coupling_size == 2*branch_size
+    const float* rsx = out + (size_t)cb * perb + P.rs();   // row exponents, written by pack_scales_kernel (zeros in train packing)
     float v = 0.f;
+    if (o >= P.poison()) continue;                         // POISON, RS, CS: pack_scales_kernel's
     if (o < P.c1()) {
       const int which = (int)(o / P.mlp_size());
       o -= (size_t)which * P.mlp_size();
@@ -102,16 +161,18 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
           j = (int)((o / 4) % FP);
         }
         if (i < f && j < f) v = rb[R.film_l1(which) + (size_t)j * f + i];
+        if (which == 1 && j < f) v = ldexpf(v, -(int)rsx[j]);   // the b head produces b 2^-RS: c = C1' + b'/a = 2^-RS (c1 + b/a)
       } else {  // L1B
         const int j = (int)(o - (size_t)FP * FP);
         if (j < f) v = rb[R.film_l1b(which) + j];
+        if (which == 1 && j < f) v = ldexpf(v, -(int)rsx[j]);
       }
     } else if ((o -= P.c1()) < (size_t)FP) {  // C1 = -mean/sqrt(var+eps) of sd1_bn
       const int j = (int)o;
-      if (j < f) v = -rb[R.bn1() + j] * inv_std(rb[R.bn1() + f + j]);
+      if (j < f) v = ldexpf(-rb[R.bn1() + j] * inv_std(rb[R.bn1() + f + j]), -(int)rsx[j]);
     } else if ((o -= FP) < 2 * (size_t)FP) {  // W2[w][j]
       const int w = (int)(o / FP), j = (int)(o % FP);
-      if (j < f) v = rb[R.sd2_w() + (size_t)w * f + j];
+      if (j < f) v = ldexpf(rb[R.sd2_w() + (size_t)w * f + j], (int)rsx[j]);
     } else {  // B2
       const int e = (int)(o - 2 * (size_t)FP);
       if (e < 2) v = rb[R.sd2_b() + e];
@@ -129,10 +190,12 @@ extern "C" int gwtf_pack_weights(const float* raw, float* packed_w, float* packe
   const int FP = gwtf_padded_width(f);
   hipStream_t st = (hipStream_t)stream;
   const int threads = 256;
+  hipLaunchKernelGGL(pack_scales_kernel, dim3(2 * C), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training, pattern0);
   {
     const size_t total = GwtfPackW(FP).coupling_size() * (size_t)C;
     const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
-    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_w, C, f, G, FP, training, pattern0);
+    hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_film, packed_w, C, f, G, FP, training,
+                       pattern0);
   }
   {
     const size_t total = GwtfPackF(FP, G).coupling_size() * (size_t)C;

@@ -499,6 +499,11 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
 
   stage(0, c_start);
   const float s_keep = sqrtf(eps + 1.0f);  // scale applied to un-warped coordinates (reference quirk)
+  // largest |coordinate| this lane's point had at the input of any coupling: beyond GWTF_X_LIMIT the f16 image of sd0's
+  // activations can overflow (gwtf_layout.h, range scaling) and the ReLU's v_max would turn the resulting NaN accumulators
+  // into zeros -- such a point is flagged instead (NaN result below).  v_max ignores NaN operands: a NaN coordinate is
+  // caught by the bit test at the end (NaN and Inf coordinates stay non-finite through every later coupling).
+  float xmax = fmaxf(fabsf(xo[0]), fmaxf(fabsf(xo[1]), fabsf(xo[2])));
 
   for (int step = 0; step < n_steps; ++step) {
     const int c = MODE == GWTF_MODE_INVERSE ? c_start - step : c_start + step;
@@ -524,6 +529,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     }
 #pragma unroll
     for (int d = 0; d < 3; ++d) ld[d] += lv_d[d];
+    if (step + 1 < n_steps) xmax = fmaxf(xmax, fmaxf(fabsf(xo[0]), fmaxf(fabsf(xo[1]), fabsf(xo[2]))));
     if (LISTS && own_valid) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
@@ -539,6 +545,18 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
       for (int d = 0; d < 3; ++d) x[nb][d] = __shfl(xo[d], 16 * nb + i16);
   }
 
+  {
+    // non-finite or out-of-range point -> NaN coordinates AND log-det (integer tests: the library is built -fno-honor-nans)
+    const unsigned any = __builtin_bit_cast(unsigned, xo[0]) | __builtin_bit_cast(unsigned, xo[1]) |
+                         __builtin_bit_cast(unsigned, xo[2]) | __builtin_bit_cast(unsigned, ld[0]) |
+                         __builtin_bit_cast(unsigned, ld[1]) | __builtin_bit_cast(unsigned, ld[2]);
+    const bool bad = (any & 0x7f800000u) == 0x7f800000u || __builtin_bit_cast(unsigned, xmax) > __builtin_bit_cast(unsigned, GWTF_X_LIMIT);
+    if (bad) {
+      const float qnan = __builtin_bit_cast(float, 0x7fc00000u);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) xo[d] = ld[d] = qnan;
+    }
+  }
   if (own_valid) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
