@@ -50,8 +50,9 @@ def adversarial_state(st, p, g, L, seed, gain_max=50.0, decades=3.0, a_floor=-16
             st[k] = (v * rows * cols).astype(np.float32)
         elif k.endswith('sd0_bn.weight'):
             st[k] = (rng.uniform(0.5, gain_max, v.shape) * rng.choice([-1.0, 1.0], v.shape)).astype(np.float32)
-        elif k.endswith('film_w1.bias'):                                   # a = eps + exp(.) from ~1e-7 + eps up to 1
-            st[k] = rng.uniform(a_floor, 0.0, v.shape).astype(np.float32)
+        elif k.endswith('film_w1.bias'):                  # a = eps + exp(.): half the features ~1e-7 + eps .. 3e-4, half O(1)
+            tiny = rng.random(v.shape) < 0.5
+            st[k] = np.where(tiny, rng.uniform(a_floor, a_floor / 2, v.shape), rng.uniform(-2.0, 0.5, v.shape)).astype(np.float32)
     # calibrate: batch statistics of one train-mode pass become the running statistics (momentum 0.1 -> solve for the batch values)
     new = {}
     fo.decoder_forward(p.astype(np.float64), g.astype(np.float64), state64(st), L, 'direct', training=True, new_stats=new)
