@@ -246,6 +246,9 @@ def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum
         pw, pf = pack_weights(raw, C, f, G, True, pattern0)
         film_all, fstats = film_forward(gfull, pf, C, f, eps, True, want_stats=True)
         film_raw = film_all[row0:row0 + B].contiguous()
+        # a non-finite parameter anywhere in a branch record -> NaN FiLM scale -> NaN outputs (the kernels' v_max ReLU alone
+        # would turn e.g. a NaN sd0 weight into a zero activation; reference training.py:43-46 aborts on a NaN loss)
+        film_raw[:, :, :, 0] += (raw.view(C, 2, -1).sum(-1) * 0.0).view(1, C, 2, 1)
         mom = torch.zeros(C + 1, STAT_REPLICAS * 16, device=dev, dtype=torch.float32)
         ystats = torch.zeros(C, STAT_REPLICAS * 2 * FP * 2, device=dev, dtype=torch.float32)
         bn_batch = torch.zeros(C, 2, 4, 2, f, device=dev, dtype=torch.float32)

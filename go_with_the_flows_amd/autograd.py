@@ -71,6 +71,11 @@ def _gather(engine, raw=None):
     }
 
 
+def branch_poison(raw, C):
+    """(C,2): 0 for a branch record whose parameters / buffers are all finite, NaN otherwise (0 * sum)."""
+    return raw.detach().view(C, 2, -1).sum(-1) * 0.0
+
+
 def fold(engine, g, eps):
     """Parameters + g -> folded tensors (all differentiable): W0f (C,2,f,2), c0f (C,2,f), W1p (C,2,f,f),
     cvec (B,C,2,f), u (B,C,2,2,f), b2 (C,2,2)."""
@@ -107,7 +112,9 @@ def fold(engine, g, eps):
     W1p = W1p * (up_c.unsqueeze(-2) * dn_r.unsqueeze(-1))
     cvec = cvec * dn_r
     u = u * up_r.unsqueeze(0).unsqueeze(3)
-    return W0f, c0f, W1p, cvec, u, P['b2']
+    # a non-finite value anywhere in a branch record poisons that branch's sd2 biases (0 * sum = NaN), like the packer's POISON
+    # slot: the kernels' v_max ReLU would otherwise turn e.g. a NaN sd0 weight into a zero activation
+    return W0f, c0f, W1p, cvec, u, P['b2'] + branch_poison(P['raw'], W0f.shape[0]).unsqueeze(-1)
 
 
 def film_record(cvec, u, b2, FP):
@@ -329,7 +336,9 @@ def _film_train(P, g, eps):
     hbn = (hraw - mean) / torch.sqrt(var + BN_EPS) * hg + hb
     hn = hbn * torch.sigmoid(hbn)
     o = torch.einsum('bcxhi,cxhji->bcxhj', hn, P['L1']) + P['b1']
-    a = eps + torch.exp(o[:, :, :, 0])
+    # + poison: a non-finite parameter anywhere in the branch makes the FiLM scale NaN, hence u = W2 a s1 and every output
+    # (the kernels' v_max ReLU alone would turn e.g. a NaN sd0 weight into a zero activation)
+    a = eps + torch.exp(o[:, :, :, 0]) + branch_poison(P['raw'], hraw.shape[1]).unsqueeze(0).unsqueeze(-1)
     return a, o[:, :, :, 1], mean.detach(), (var * (Bn / max(Bn - 1.0, 1.0))).detach()
 
 

@@ -298,8 +298,7 @@ __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict_
         cv = c1 + o[1][r] / a;
         u0 = w20 * a;
         u1 = w21 * a;
-        const unsigned bits = __builtin_bit_cast(unsigned, o[0][r]) | __builtin_bit_cast(unsigned, o[1][r]);
-        if ((bits & 0x7f800000u) == 0x7f800000u) cv = u0 = u1 = qnan;
+        if (gwtf_nonfinite(o[0][r]) || gwtf_nonfinite(o[1][r])) cv = u0 = u1 = qnan;
       }
       float* ob = out + ((size_t)b * C + c) * FS + (size_t)br * 3 * FP + ft;
       ob[0] = cv;

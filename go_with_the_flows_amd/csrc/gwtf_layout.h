@@ -160,6 +160,18 @@ struct GwtfPackF {
 };
 #define GWTF_X_LIMIT 3.0e4f   // |coordinate| beyond which the f16 image of sd0's activations may overflow: results are NaN
 
+#ifdef __HIPCC__
+// Bit pattern of a float for NaN / Inf tests.  The library is built with -fno-honor-nans: the compiler recognises integer
+// idioms such as (bits & 0x7f800000) == 0x7f800000 as floating-point class tests and, allowed to assume that no value is a
+// NaN, drops their NaN half (measured: the packer's poison never fired).  The empty asm makes the bits opaque.
+__device__ __forceinline__ unsigned gwtf_float_bits(float x) {
+  unsigned b = __builtin_bit_cast(unsigned, x);
+  asm volatile("" : "+v"(b));
+  return b;
+}
+__device__ __forceinline__ bool gwtf_nonfinite(float x) { return (gwtf_float_bits(x) & 0x7f800000u) == 0x7f800000u; }
+#endif
+
 // FILM OUTPUT (written by gwtf_film_forward, read by the fused kernel through LDS), per (shape b, coupling c):
 //   for branch in {logvar, mu}:  c[FP] | w20a[FP] | w21a[FP]   with a = eps + exp(cond_w(g)) > 0, b = cond_b(g):
 //       c = C1 + b/a   (start value of the sd1 accumulators:  relu(a*(y + C1) + b) = a * relu(y + c))

@@ -11,8 +11,7 @@ namespace {
 
 __device__ __forceinline__ float inv_std(float var) { return 1.0f / sqrtf(var + GWTF_BN_EPS); }
 
-// bit tests: the library is built with -fno-honor-nans, under which x != x or isfinite(x) may be folded away
-__device__ __forceinline__ bool nonfinite(float x) { return (__builtin_bit_cast(unsigned, x) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ bool nonfinite(float x) { return gwtf_nonfinite(x); }   // opaque bit test, see gwtf_layout.h
 __device__ __forceinline__ int floor_log2(float x) {   // x > 0, finite
   int e;
   frexpf(x, &e);

@@ -504,6 +504,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   // into zeros -- such a point is flagged instead (NaN result below).  v_max ignores NaN operands: a NaN coordinate is
   // caught by the bit test at the end (NaN and Inf coordinates stay non-finite through every later coupling).
   float xmax = fmaxf(fabsf(xo[0]), fmaxf(fabsf(xo[1]), fabsf(xo[2])));
+  float mu_last[3] = {0.f, 0.f, 0.f}, lv_last[3] = {0.f, 0.f, 0.f};
 
   for (int step = 0; step < n_steps; ++step) {
     const int c = MODE == GWTF_MODE_INVERSE ? c_start - step : c_start + step;
@@ -530,7 +531,10 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
 #pragma unroll
     for (int d = 0; d < 3; ++d) ld[d] += lv_d[d];
     if (step + 1 < n_steps) xmax = fmaxf(xmax, fmaxf(fabsf(xo[0]), fmaxf(fabsf(xo[1]), fabsf(xo[2]))));
-    if (LISTS && own_valid) {
+    if (LISTS && step + 1 == n_steps) {      // the last slot is written after the non-finite / range check below
+#pragma unroll
+      for (int d = 0; d < 3; ++d) { mu_last[d] = mu_d[d]; lv_last[d] = lv_d[d]; }
+    } else if (LISTS && own_valid) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const size_t o = (((size_t)c * B + b) * 3 + d) * N + n_own;
@@ -547,14 +551,28 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
 
   {
     // non-finite or out-of-range point -> NaN coordinates AND log-det (integer tests: the library is built -fno-honor-nans)
-    const unsigned any = __builtin_bit_cast(unsigned, xo[0]) | __builtin_bit_cast(unsigned, xo[1]) |
-                         __builtin_bit_cast(unsigned, xo[2]) | __builtin_bit_cast(unsigned, ld[0]) |
-                         __builtin_bit_cast(unsigned, ld[1]) | __builtin_bit_cast(unsigned, ld[2]);
-    const bool bad = (any & 0x7f800000u) == 0x7f800000u || __builtin_bit_cast(unsigned, xmax) > __builtin_bit_cast(unsigned, GWTF_X_LIMIT);
+    unsigned worst = gwtf_float_bits(xmax);                   // magnitudes compare like their bit patterns (sign cleared)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      worst = max(worst, gwtf_float_bits(xo[d]) & 0x7fffffffu);
+      const unsigned lb = gwtf_float_bits(ld[d]) & 0x7fffffffu;
+      worst = max(worst, lb >= 0x7f800000u ? lb : 0u);          // the log-det only when it is itself Inf / NaN
+    }
+    const bool bad = worst > __builtin_bit_cast(unsigned, GWTF_X_LIMIT);
     if (bad) {
       const float qnan = __builtin_bit_cast(float, 0x7fc00000u);
 #pragma unroll
-      for (int d = 0; d < 3; ++d) xo[d] = ld[d] = qnan;
+      for (int d = 0; d < 3; ++d) xo[d] = ld[d] = mu_last[d] = lv_last[d] = qnan;
+    }
+  }
+  if (LISTS && own_valid) {
+    const int c_last = MODE == GWTF_MODE_INVERSE ? c_start - (n_steps - 1) : c_start + (n_steps - 1);
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const size_t o = (((size_t)c_last * B + b) * 3 + d) * N + n_own;
+      ps[o] = xo[d];
+      mus[o] = mu_last[d];
+      lvs[o] = lv_last[d];
     }
   }
   if (own_valid) {

@@ -105,7 +105,7 @@ def test_adversarial_ranges_gradients():
     tst = {k: torch.from_numpy(v).double().requires_grad_(v.dtype == np.float32 and 'running' not in k and not k.endswith('eps'))
            for k, v in st.items()}
     pt, gt = torch.from_numpy(p).double().requires_grad_(True), torch.from_numpy(g).double().requires_grad_(True)
-    o_ref, l_ref = tp.decoder_fused(pt, gt, tst, L, 'inverse')
+    o_ref, l_ref = tp.decoder_fused(pt, gt, tst, L, 'inverse', grad=True)
     (0.5 * (o_ref ** 2).sum() / B + 0.5 * l_ref.sum() / B).backward()
     worst = 0.0
     named = dict(m.named_parameters())
@@ -149,7 +149,10 @@ def test_nonfinite_or_out_of_range_points_reach_out_and_logdet(mode, bad):
         out_ok, ld_ok = m.forward_fused(dev(p_ok), dev(g), mode)
     assert np.array_equal(o[:, :, ][np.broadcast_to(~mask[:, None, :], o.shape)], host(out_ok)[np.broadcast_to(~mask[:, None, :], o.shape)])
     assert np.isfinite(l[np.broadcast_to(~mask[:, None, :], l.shape)]).all()
-    assert not np.isfinite(host(sum(lvs))[0, :, 5]).all() or not np.isfinite(host(ps[0] if mode == 'inverse' else ps[-1])[0, :, 5]).any()
+    # the list API (what the reference's loss reads: ps[0] / ps[-1] and sum(logvars)) carries the flag too
+    fin = ps[0] if mode == 'inverse' else ps[-1]
+    assert torch.equal(torch.isnan(fin), torch.isnan(out)) and not np.isfinite(host(fin)[0, :, 5]).any()
+    assert not np.isfinite(host(sum(lvs))[0, :, 5]).any()
 
 
 @pytest.mark.parametrize('bad', [np.nan, np.inf])
