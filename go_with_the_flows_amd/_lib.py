@@ -26,6 +26,7 @@ _SIGNATURES = {
     'gwtf_packed_film_coupling_floats': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'gwtf_film_out_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_pack_weights': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
+    'gwtf_pack_weights_k': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 6 + [_c_fp]),
     'gwtf_film_forward': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, _c_fp]),
@@ -66,7 +67,25 @@ _SIGNATURES = {
     'gwtf_encoder_pack': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_encoder_forward': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int, ctypes.c_int, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
+    'gwtf_mtrain_dw1_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'gwtf_mtrain_phase': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
+    'gwtf_mtrain_forward': (ctypes.c_int, [ctypes.c_void_p]),
+    'gwtf_mtrain_backward': (ctypes.c_int, [ctypes.c_void_p]),
+    'gwtf_mtrain_final_forward_half': (ctypes.c_int, [ctypes.c_int]),
+    'gwtf_mtrain_final_backward_half': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
 }
+
+PHASE_FWD_INIT, PHASE_FWD_A, PHASE_FWD_B, PHASE_BWD_A, PHASE_BWD_B, PHASE_BWD_C = range(6)
+
+
+class TrainCtx(ctypes.Structure):
+    """GwtfTrainCtx of include/gwtf.h (K-batched, phase-split train pipeline): same field order."""
+    _fields_ = ([(n, ctypes.c_int) for n in ('K', 'B', 'N', 'C', 'f', 'G', 'pattern0', 'mode')] +
+                [('eps', ctypes.c_float), ('n_total', ctypes.c_double)] +
+                [(n, ctypes.c_void_p) for n in (
+                    'p', 'raw', 'packed_w', 'packed_b', 'film_raw', 'film_rec', 'moments', 'ystats', 'bn_batch', 'xbuf',
+                    'logdet', 'ps', 'mus', 'logvars', 'g_out', 'g_ld', 'g_bufs', 'g_xa', 'g_xb', 'dw1_ws', 'g_film', 'g_sd0',
+                    'g_bias', 'g_stats', 'g_mom', 'g_film_raw', 'g_raw', 'stream')])
 EXPORTS = tuple(_SIGNATURES)
 
 _lib = None
@@ -120,15 +139,16 @@ def padded_width(f):
     return lib().gwtf_padded_width(f)
 
 
-def pack_weights(raw, C, f, G, training, pattern0=0):
+def pack_weights(raw, C, f, G, training, pattern0=0, K=1):
+    """Packed stack / FiLM weights of K concatenated stacks of C couplings each (raw: K*C coupling records)."""
     L = lib()
-    pw = torch.empty(C * L.gwtf_packed_w_coupling_floats(f), device=raw.device, dtype=torch.float32)
-    pf = torch.empty(C * L.gwtf_packed_film_coupling_floats(f, G), device=raw.device, dtype=torch.float32)
-    if raw.numel() != C * L.gwtf_raw_coupling_floats(f, G):
-        raise GwtfError(f'raw arena has {raw.numel()} floats, expected {C * L.gwtf_raw_coupling_floats(f, G)}')
+    pw = torch.empty(K * C * L.gwtf_packed_w_coupling_floats(f), device=raw.device, dtype=torch.float32)
+    pf = torch.empty(K * C * L.gwtf_packed_film_coupling_floats(f, G), device=raw.device, dtype=torch.float32)
+    if raw.numel() != K * C * L.gwtf_raw_coupling_floats(f, G):
+        raise GwtfError(f'raw arena has {raw.numel()} floats, expected {K * C * L.gwtf_raw_coupling_floats(f, G)}')
     with torch.cuda.device(raw.device):
-        check(L.gwtf_pack_weights(_ptr(raw, 'raw'), _ptr(pw, 'packed_w'), _ptr(pf, 'packed_film'), C, f, G, int(pattern0),
-                                  int(bool(training)), _stream(raw)))
+        check(L.gwtf_pack_weights_k(_ptr(raw, 'raw'), _ptr(pw, 'packed_w'), _ptr(pf, 'packed_film'), K, C, f, G, int(pattern0),
+                                    int(bool(training)), _stream(raw)))
     return pw, pf
 
 

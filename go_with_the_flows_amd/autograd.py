@@ -477,15 +477,31 @@ def train_density_forward(engine, p, g, distributed=False, mode='inverse'):
 
 
 # ======================================================================================================================
-# Single-rank fast path of the train-mode density pass: the whole per-coupling chain of the section above inside two C
-# entry points (gwtf_train_forward / gwtf_train_coupling_backward: folds and their backward are HIP kernels), so a train
-# step costs ~6 host-level ops per coupling instead of ~300 tiny torch ops.  Only the FiLM heads (O(B f G), vectorised
-# over all couplings) stay a torch graph.  The chain of autograd nodes above remains the multi-rank implementation and
-# the cross-check of this one (tests/test_gpu_parity.py::test_train_fast_path_equals_autograd_chain).
+# The train-mode density pass of K stacks at once through the K-batched, phase-split C pipeline (csrc/gwtf_train.hip,
+# include/gwtf.h GwtfTrainCtx): every kernel of the per-coupling chain above (folds and their backward included) takes all K
+# mixture components in one launch, and the chain is cut exactly where a data-parallel run sums BatchNorm statistics over
+# the ranks -- TWO collectives per depth level and direction for all K components and both branches (66 per forward of a
+# 33-coupling config; reference: SyncBatchNorm, train_ae.py:152, 8 layers x 33 couplings x K collectives).  A single rank
+# runs everything from two C calls.  Only the FiLM heads (O(B f G), vectorised over couplings) stay a torch graph.  The
+# chain of autograd nodes above remains as the cross-check (tests: test_train_fast_path_equals_autograd_chain and the
+# 2-rank test).
 # ======================================================================================================================
-class TrainStackFn(torch.autograd.Function):
+COLLECTIVES = {'n': 0}        # statistic all-reduces issued by TrainMixtureFn (tests assert the count)
+
+
+def _stat_sum(t):
+    import torch.distributed as dist
+    COLLECTIVES['n'] += 1
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+class TrainMixtureFn(torch.autograd.Function):
+    """out, logdet (K,B,3,N), lists (3,K,C,B,3,N), bn_batch (K,C,2,4,2,f) of K stacks with batch-statistic BatchNorm.
+    raw (K, C*R): the stacks' raw arenas; a, bsh (B, K*C, 2, f): raw FiLM scale / shift of this rank's shapes.
+    n_total: number of points the statistics cover over all ranks; sharded: statistics are all-reduced between phases."""
+
     @staticmethod
-    def forward(ctx, p, raw, a, bsh, C, f, G, pattern0, eps, mode):
+    def forward(ctx, p, raw, a, bsh, K, C, f, G, pattern0, eps, mode, n_total, sharded):
         L = _lib.lib()
         p, raw = p.contiguous(), raw.contiguous()
         B, _, N = p.shape
@@ -493,75 +509,130 @@ class TrainStackFn(torch.autograd.Function):
         FP = L.gwtf_padded_width(f)
         FS, PB = L.gwtf_film_out_floats(f), L.gwtf_packed_b_coupling_floats(f)
         R = _lib.STAT_REPLICAS
-        film_raw = torch.zeros(B, C, 2, 2, FP, device=dev, dtype=torch.float32)
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        zeros = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
+        film_raw = zeros(B, K * C, 2, 2, FP)
         film_raw[:, :, :, 0, :f] = a
         film_raw[:, :, :, 1, :f] = bsh
-        st = _lib._stream(p)
         with torch.cuda.device(dev):
-            pw, _pf = _lib.pack_weights(raw, C, f, G, True, pattern0)
-            pb = torch.zeros(C * PB, device=dev, dtype=torch.float32)
-            _lib.check(L.gwtf_pack_w1t(raw.data_ptr(), pb.data_ptr(), C, f, G, st))
-            mom = torch.zeros(C + 1, R * 16, device=dev, dtype=torch.float32)
-            ystats = torch.zeros(C, R * 2 * FP * 2, device=dev, dtype=torch.float32)
-            bn_batch = torch.zeros(C, 2, 4, 2, f, device=dev, dtype=torch.float32)
-            film_rec = torch.empty(B, C, FS, device=dev, dtype=torch.float32)
-            xbuf = torch.empty(2, B, 3, N, device=dev, dtype=torch.float32)
-            logdet = torch.empty_like(p)
-            lists = torch.empty(3, C, B, 3, N, device=dev, dtype=torch.float32)
-            _lib.check(L.gwtf_train_forward(p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr(), film_raw.data_ptr(),
-                                            mom.data_ptr(), ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(),
-                                            xbuf.data_ptr(), logdet.data_ptr(), lists[0].data_ptr(), lists[1].data_ptr(),
-                                            lists[2].data_ptr(), B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], st))
-        out = xbuf[(C - 1) & 1].clone()     # the pipeline ping-pongs between the two buffers in both directions
-        ctx.save_for_backward(p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats)
-        ctx.meta = (C, f, G, FP, pattern0, eps, mode)
-        ctx.mark_non_differentiable(lists, bn_batch)
-        return out, logdet, lists, bn_batch
+            pw, _pf = _lib.pack_weights(raw.view(-1), C, f, G, True, pattern0, K=K)
+            pb = zeros(K * C * PB)
+            _lib.check(L.gwtf_pack_w1t(raw.data_ptr(), pb.data_ptr(), K * C, f, G, _lib._stream(p)))
+        t = _lib.TrainCtx()
+        t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
+        t.eps, t.n_total = float(eps), float(n_total)
+        bufs = dict(moments=zeros(C + 1, K, R * 16), ystats=zeros(C, K, R * 2 * FP * 2), bn_batch=zeros(K, C, 2, 4, 2, f),
+                    film_rec=new(B, K * C, FS), xbuf=new(2, K, B, 3, N), logdet=new(K, B, 3, N), lists=new(3, K, C, B, 3, N))
+        t.p, t.raw, t.packed_w, t.packed_b, t.film_raw = p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr(), film_raw.data_ptr()
+        for name in ('moments', 'ystats', 'bn_batch', 'film_rec', 'xbuf', 'logdet'):
+            setattr(t, name, bufs[name].data_ptr())
+        lists = bufs['lists']
+        t.ps, t.mus, t.logvars = lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr()
+        t.stream = _lib._stream(p)
+        with torch.cuda.device(dev):
+            if not sharded:
+                _lib.check(L.gwtf_mtrain_forward(ctypes.addressof(t)))
+            else:
+                mom, ys = bufs['moments'], bufs['ystats']
+                _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_INIT, 0))
+                _stat_sum(mom[0, 0])
+                for step in range(C):
+                    c = step if mode == 'direct' else C - 1 - step
+                    _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_A, step))
+                    _stat_sum(ys[c])
+                    _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_B, step))
+                    if step + 1 < C:
+                        _stat_sum(mom[step + 1])
+        out = bufs['xbuf'][L.gwtf_mtrain_final_forward_half(C)].clone()
+        ctx.save_for_backward(p, raw, lists, pw, pb, bufs['film_rec'], film_raw, bufs['moments'], bufs['ystats'])
+        ctx.meta = (int(K), int(C), int(f), int(G), int(FP), int(pattern0), float(eps), mode, float(n_total), bool(sharded))
+        ctx.mark_non_differentiable(lists, bufs['bn_batch'])
+        return out, bufs['logdet'], lists, bufs['bn_batch']
 
     @staticmethod
     def backward(ctx, g_out, g_logdet, _gl, _gb):
         p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats = ctx.saved_tensors
-        C, f, G, FP, pattern0, eps, mode = ctx.meta
-        C, f, G, FP, pattern0 = int(C), int(f), int(G), int(FP), int(pattern0)     # numpy ints would poison the pointer arithmetic
-        inverse = mode == 'inverse'
+        K, C, f, G, FP, pattern0, eps, mode, n_total, sharded = ctx.meta
         L = _lib.lib()
         B, _, N = p.shape
         dev = p.device
         R = _lib.STAT_REPLICAS
-        ps = lists[0]
-        cur = (g_out if g_out is not None else torch.zeros_like(p)).contiguous().float()
-        g_ld = (g_logdet if g_logdet is not None else torch.zeros_like(p)).contiguous().float()
-        g_raw = torch.zeros_like(raw)
-        g_film_raw = torch.zeros_like(film_raw)
-        g_film = torch.zeros(B, C, 2, 3, FP, device=dev, dtype=torch.float32)
-        g_sd0 = torch.zeros(C, R * 2 * 3 * FP, device=dev, dtype=torch.float32)
-        g_bias = torch.zeros(C, R * 4, device=dev, dtype=torch.float32)
-        g_stats = torch.empty(C, 2 * 2 * FP, device=dev, dtype=torch.float32)
-        g_mom = torch.empty(C, 96, device=dev, dtype=torch.float32)          # scratch: partial sums of the moment gradients
-        ws = _lib.dw1_workspace(f, B, N, dev, passes=2)      # dW1 partials of the coupling and the statistics pass
-        gxa, gxb = torch.empty_like(p), torch.empty_like(p)
-        bufs = torch.empty(2, *p.shape, device=dev, dtype=torch.float32)
-        final = ctypes.c_int(0)
-        P = lambda t: t.data_ptr()
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        zeros = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
+        g_out = (g_out if g_out is not None else zeros(K, B, 3, N)).contiguous().float()
+        g_ld = (g_logdet if g_logdet is not None else zeros(K, B, 3, N)).contiguous().float()
+        t = _lib.TrainCtx()
+        t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
+        t.eps, t.n_total = eps, n_total
+        scratch = new(K, B, 3, N)
+        bufs = dict(g_bufs=new(2, K, B, 3, N), g_xa=new(K, B, 3, N), g_xb=new(K, B, 3, N),
+                    dw1_ws=new(K * L.gwtf_mtrain_dw1_floats(f, B, N)), g_film=zeros(B, K * C, 2, 3, FP),
+                    g_sd0=zeros(C, K, R * 2 * 3 * FP), g_bias=zeros(C, K, R * 4), g_stats=new(C, K, 2 * 2 * FP),
+                    g_mom=torch.zeros(C, K, 48, device=dev, dtype=torch.float64), g_film_raw=torch.zeros_like(film_raw),
+                    g_raw=torch.zeros_like(raw))
+        t.p, t.raw, t.packed_w, t.packed_b = p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr()
+        t.film_raw, t.film_rec, t.moments, t.ystats = film_raw.data_ptr(), film_rec.data_ptr(), mom.data_ptr(), ystats.data_ptr()
+        t.bn_batch, t.xbuf, t.logdet = bufs['g_stats'].data_ptr(), bufs['g_bufs'].data_ptr(), scratch.data_ptr()   # forward-only fields
+        t.ps, t.mus, t.logvars = lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr()
+        t.g_out, t.g_ld = g_out.data_ptr(), g_ld.data_ptr()
+        for name, buf in bufs.items():
+            setattr(t, name, buf.data_ptr())
+        t.stream = _lib._stream(p)
         with torch.cuda.device(dev):
-            _lib.check(L.gwtf_train_backward(
-                P(p), P(ps), P(cur), P(g_ld), P(raw), P(pw), P(pb), P(film_rec), P(film_raw), P(mom), P(ystats), P(bufs),
-                P(gxa), P(gxb), P(ws), P(g_film), P(g_sd0), P(g_bias), P(g_stats), P(g_mom), P(g_film_raw), P(g_raw),
-                ctypes.addressof(final), B, N, C, f, G, pattern0, float(eps), _lib._MODES[mode], _lib._stream(p)))
-        cur = bufs[final.value]
-        return cur, g_raw, g_film_raw[:, :, :, 0, :f], g_film_raw[:, :, :, 1, :f], None, None, None, None, None, None
+            if not sharded:
+                _lib.check(L.gwtf_mtrain_backward(ctypes.addressof(t)))
+            else:
+                for step in range(C):
+                    c = step if mode == 'inverse' else C - 1 - step
+                    _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_BWD_A, step))
+                    _stat_sum(bufs['g_stats'][c])
+                    _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_BWD_B, step))
+                    _stat_sum(bufs['g_mom'][c])
+                    _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_BWD_C, step))
+        dp = bufs['g_bufs'][L.gwtf_mtrain_final_backward_half(C, _lib._MODES[mode])]
+        dp = dp[0] if K == 1 else dp.sum(0)                    # the K components read the same clouds
+        gfr = bufs['g_film_raw']
+        return (dp, bufs['g_raw'], gfr[:, :, :, 0, :f], gfr[:, :, :, 1, :f]) + (None,) * 9
 
 
-def train_density_forward_fast(engine, p, g, mode='inverse'):
-    """Single-rank train-mode density pass through the fused C pipeline.  -> out, logdet, lists (detached), bn_batch."""
-    C, f, G, eps = engine.C, engine.f, engine.G, engine.couplings[0]._eps_value
-    if p.shape[0] < 2:
-        raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
-    P = _gather(engine)
-    a, bsh, fmean, fvar = _film_train(P, g.float(), eps)
-    out, logdet, lists, bn_batch = TrainStackFn.apply(p.float(), P['raw'], a, bsh, C, f, G, engine.pattern0, eps,
-                                                      mode)
+def _rank_rows(g):
+    """Data-parallel bookkeeping for the per-shape FiLM BatchNorm: the latents of all ranks (differentiable all-gather,
+    uneven per-rank batches allowed: train_ae.py:77-78), this rank's first row and the global number of shapes."""
+    import torch.distributed as dist
+    sizes = [torch.zeros(1, dtype=torch.int64, device=g.device) for _ in range(dist.get_world_size())]
+    dist.all_gather(sizes, torch.tensor([g.shape[0]], dtype=torch.int64, device=g.device))
+    sizes = [int(x.item()) for x in sizes]
+    return _AllGatherRows.apply(g), sum(sizes[:dist.get_rank()]), sum(sizes)
+
+
+def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False):
+    """Train-mode density pass of K stacks (the components of a mixture, or one decoder) through the fused pipeline.
+    -> out, logdet (K,B,3,N), lists (3,K,C,B,3,N) detached, bn_batch (K,C,2,4,2,f) incl. the FiLM BatchNorm statistics."""
+    e0 = engines[0]
+    K, C, f, G, eps = len(engines), e0.C, e0.f, e0.G, e0.couplings[0]._eps_value
+    B, _, N = p.shape
+    g = g.float()
+    row0, rows_total = 0, B
+    if distributed:
+        g_all, row0, rows_total = _rank_rows(g)
+    else:
+        g_all = g
+    if rows_total < 2:
+        raise ValueError('train-mode BatchNorm needs more than 1 shape per (global) batch (torch raises the same)')
+    Ps = [_gather(e) for e in engines]
+    films = [_film_train(P, g_all, eps) for P in Ps]
+    a = torch.cat([q[0][row0:row0 + B] for q in films], dim=1)          # (B, K*C, 2, f)
+    bsh = torch.cat([q[1][row0:row0 + B] for q in films], dim=1)
+    raw = Ps[0]['raw'].unsqueeze(0) if K == 1 else torch.stack([P['raw'] for P in Ps])
+    out, logdet, lists, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
+                                                        float(rows_total) * N, distributed)
     bn_batch = bn_batch.clone()
-    bn_batch[:, :, 2:4, 0] = fmean
-    bn_batch[:, :, 2:4, 1] = fvar
+    bn_batch[:, :, :, 2:4, 0] = torch.stack([q[2] for q in films])
+    bn_batch[:, :, :, 2:4, 1] = torch.stack([q[3] for q in films])
     return out, logdet, lists, bn_batch
+
+
+def train_density_forward_fast(engine, p, g, mode='inverse', distributed=False):
+    """One stack through the fused pipeline.  -> out, logdet (B,3,N), lists (3,C,B,3,N) detached, bn_batch (C,2,4,2,f)."""
+    out, logdet, lists, bn_batch = train_density_forward_multi([engine], p, g, mode, distributed)
+    return out[0], logdet[0], lists[:, 0], bn_batch[0]

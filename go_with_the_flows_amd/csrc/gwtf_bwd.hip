@@ -46,10 +46,29 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
                                                   float* __restrict__ g_film,
                                                   float* __restrict__ g_sd0, float* __restrict__ g_bias,
                                                   const float* __restrict__ g_stats, int B, int N, int C, int c, int pat,
-                                                  float eps, int kk_steps, int f, int mode) {
+                                                  float eps, int kk_steps, int f, int mode, const GwtfKS ks_) {
   using K = Cfg<MB>;
   using KB = BCfg<MB>;
   constexpr int FP = K::FP;
+  {
+    // blockIdx.y = mixture component of the K-batched train pipeline (all strides 0, Ctot == C for a single stack)
+    const size_t comp = blockIdx.y;
+    x_in += comp * ks_.x;
+    pw_c += comp * ks_.pw;
+    pb_c += comp * ks_.pb;
+    g_in += comp * ks_.pts;
+    dw1_ws += comp * ks_.dw1;
+    g_sd0 += comp * ks_.gsd0;
+    if (!STATS) {
+      g_out += comp * ks_.pts;
+      g_ld += comp * ks_.pts;
+      g_bias += comp * ks_.gbias;
+      c += (int)comp * ks_.Cper;     // FiLM-side arrays: [shape][Ctot][...], coupling k*Cper + c
+      C = ks_.Ctot;
+    } else {
+      g_stats += comp * ks_.gstats;
+    }
+  }
   __shared__ __align__(16) float lds[K::PW + K::FSP + KB::PB];
   __shared__ float s_film[2][3][FP], s_sd0[2][3][FP], s_bias[4];
   // dW1 machinery: coordinates of the workgroup's points, per-wave |dacc| maxima, the transposed dacc image
@@ -492,10 +511,11 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
 template <int MB, bool STATS>
 int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
                const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0, float* g_bias,
-               const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, int mode, hipStream_t st) {
+               const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, int mode, int K,
+               const GwtfKS& ks, hipStream_t st) {
   const int pts_wg = 64 * nb;
-  const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg))), block(256);
-#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode)
+  const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B
   return (int)hipGetLastError();
@@ -525,11 +545,11 @@ static int bwd_grid(int B, int N) {
 static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                         const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0,
                         float* g_bias, const float* g_stats, int c, int B, int N, int C, int f, int pat, float eps, int mode,
-                        void* stream) {
+                        int K, const GwtfKS& ks, void* stream) {
   const int kk_steps = (f + 3) / 4;
   const int nb = bwd_points_per_wg(B, N) / 64;
   hipStream_t st = (hipStream_t)stream;
-#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, st
+#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, K, ks, st
   switch (gwtf_padded_width(f) / 16) {
     case 1: return stats ? launch_bwd<1, true>(nb, GWTF_A) : launch_bwd<1, false>(nb, GWTF_A);
     case 2: return stats ? launch_bwd<2, true>(nb, GWTF_A) : launch_bwd<2, false>(nb, GWTF_A);
@@ -548,8 +568,26 @@ extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, con
       !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5 ||
       (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE))
     return GWTF_E_BADARG;
+  GwtfKS ks = {};
+  ks.Cper = ks.Ctot = C;
   return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
-                      B, N, C, f, (pattern0 + c) % 6, eps, mode, stream);
+                      B, N, C, f, (pattern0 + c) % 6, eps, mode, 1, ks, stream);
+}
+
+// K-batched variants (train pipeline, gwtf_train.hip): component k adds k * stride (GwtfKS) to every base pointer
+int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                                      const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
+                                      float* g_sd0, float* g_bias, int c, int K, int B, int N, int f, int pattern0, float eps,
+                                      int mode, const GwtfKS& ks, void* stream) {
+  return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
+                      B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, stream);
+}
+int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
+                                   float* g_in, float* dw1_ws, float* g_sd0, int K, int B, int N, int f, int pattern,
+                                   const GwtfKS& ks, void* stream) {
+  return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dw1_ws,
+                      g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, K, ks,
+                      stream);
 }
 
 extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c,
@@ -558,8 +596,9 @@ extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, cons
   if (!x_in || !g_stats || !packed_w_c || !packed_b_c || !g_in || !dw1_ws || !g_sd0 || B <= 0 || N <= 0 || f <= 0 ||
       f > GWTF_MAX_FP || pattern < 0 || pattern > 5)
     return GWTF_E_BADARG;
-  return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dw1_ws,
-                      g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, stream);
+  GwtfKS ks = {};
+  ks.Cper = ks.Ctot = 1;
+  return gwtf_internal_stats_backward_k(x_in, g_stats, packed_w_c, packed_b_c, g_in, dw1_ws, g_sd0, 1, B, N, f, pattern, ks, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -572,9 +611,11 @@ constexpr int kDw1Stage = 64;    // stage 1 folds the partials into this many su
 // stage 1: grid (element tiles of 256, kDw1Stage); out[chunk][e] = sum over the chunk's partials of ws[p][e], e over the
 // whole [2][FP][FP] record (coalesced); thousands of workgroups stream the workspace at HBM rate
 __global__ __launch_bounds__(256) void dw1_fold_kernel(const float* __restrict__ ws, int n_partials, float* __restrict__ mid,
-                                                       int rec) {
+                                                       int rec, size_t ws_sk) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= rec) return;
+  ws += blockIdx.z * ws_sk;        // blockIdx.z = mixture component (K-batched train pipeline)
+  mid += blockIdx.z * ws_sk;
   const int per = (n_partials + kDw1Stage - 1) / kDw1Stage;
   const int p0 = blockIdx.y * per, p1 = min(n_partials, p0 + per);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -588,8 +629,10 @@ __global__ __launch_bounds__(256) void dw1_fold_kernel(const float* __restrict__
 
 // stage 2: 64 outputs per workgroup x 4 slices of the kDw1Stage sums, combined through LDS; crops FP -> f
 __global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict__ mid, float* __restrict__ out, int FP, int f,
-                                                         size_t branch_stride) {
+                                                         size_t branch_stride, size_t ws_sk, size_t out_sk) {
   __shared__ float part[4][64];
+  mid += blockIdx.y * ws_sk;       // blockIdx.y = mixture component
+  out += blockIdx.y * out_sk;
   const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + e;
   const bool on = t < 2 * f * f;
@@ -623,14 +666,20 @@ extern "C" size_t gwtf_dw1_reduce_scratch_floats(int f) {
   return (size_t)kDw1Stage * 2 * FP * FP;
 }
 
-extern "C" int gwtf_dw1_reduce(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N,
-                               void* stream) {
-  if (!workspace || !dW1 || passes < 1 || f <= 0 || f > GWTF_MAX_FP || B <= 0 || N <= 0 || branch_stride < (size_t)f * f)
+// K components: component k's workspace at workspace + k * ws_sk, its gradient blocks at dW1 + k * out_sk
+int gwtf_internal_dw1_reduce_k(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N, int K,
+                               size_t ws_sk, size_t out_sk, void* stream) {
+  if (!workspace || !dW1 || passes < 1 || f <= 0 || f > GWTF_MAX_FP || B <= 0 || N <= 0 || K <= 0 || branch_stride < (size_t)f * f)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int FP = gwtf_padded_width(f), rec = 2 * FP * FP, n_partials = passes * bwd_grid(B, N);
   float* mid = workspace + (size_t)n_partials * rec;
-  hipLaunchKernelGGL(dw1_fold_kernel, dim3((rec + 255) / 256, kDw1Stage), dim3(256), 0, st, workspace, n_partials, mid, rec);
-  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 63) / 64), dim3(256), 0, st, mid, dW1, FP, f, branch_stride);
+  hipLaunchKernelGGL(dw1_fold_kernel, dim3((rec + 255) / 256, kDw1Stage, K), dim3(256), 0, st, workspace, n_partials, mid, rec, ws_sk);
+  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 63) / 64, K), dim3(256), 0, st, mid, dW1, FP, f, branch_stride, ws_sk, out_sk);
   return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_dw1_reduce(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N,
+                               void* stream) {
+  return gwtf_internal_dw1_reduce_k(workspace, passes, dW1, branch_stride, f, B, N, 1, 0, 0, stream);
 }

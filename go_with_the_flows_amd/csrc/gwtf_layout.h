@@ -179,6 +179,14 @@ __device__ __forceinline__ bool gwtf_nonfinite(float x) { return (gwtf_float_bit
 //   bias float4 : {b2_logvar[0], b2_logvar[1], b2_mu[0], b2_mu[1]}
 GWTF_HD size_t gwtf_film_out_size(int FP) { return 6 * (size_t)FP + 4; }
 
+// Per-component strides (in floats) of the train-mode pipeline's buffers when K mixture components run through one launch
+// (csrc/gwtf_train.hip, "K-batched pipeline"): component k of a launch adds k * stride to the base pointer.  All zero and
+// Ctot == Cper for a single stack.  FiLM-side arrays are indexed [shape][Ctot = K*Cper][...] with coupling k*Cper + c.
+struct GwtfKS {
+  size_t raw, pw, pb, x, pts, mom, ys, bn, gsd0, gbias, gstats, gmom, dw1;
+  int Cper, Ctot;
+};
+
 // warp pattern of coupling c in direct order (reference flows.py:129-148, decoders.py:49-52):
 // index (pattern0 + c) % 6 -> 0:[0] 1:[1] 2:[2] 3:[0,1] 4:[0,2] 5:[1,2]
 GWTF_HD int gwtf_pattern_kept(int pat) { return pat < 3 ? 2 : 1; }

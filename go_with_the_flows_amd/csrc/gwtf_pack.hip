@@ -21,7 +21,7 @@ __device__ __forceinline__ int floor_log2(float x) {   // x > 0, finite
 // Range scaling exponents + poison of every (coupling, branch) -> packed_film's RS / CS / POISON slots (gwtf_layout.h).
 // One workgroup per branch record; runs before the two gather kernels below, which read the exponents.
 __global__ __launch_bounds__(256) void pack_scales_kernel(const float* __restrict__ raw, float* __restrict__ pf, int C, int f,
-                                                          int G, int FP, int training, int pattern0) {
+                                                          int G, int FP, int training, int pattern0, int Cper) {
   const GwtfRaw R(f, G);
   const GwtfPackF P(FP, G);
   const int cb = blockIdx.x, c = cb >> 1, t = threadIdx.x;
@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void pack_scales_kernel(const float* __restric
     if (!training && t < f) {
       const float* bn = rb + R.bn0();
       const float s = bn[t] * inv_std(bn[3 * f + t]);
-      const int k = gwtf_pattern_kept((pattern0 + c) % 6);
+      const int k = gwtf_pattern_kept((pattern0 + c % Cper) % 6);
       const float wa = rb[R.sd0_w(t, 0, k)] * s, wb = k > 1 ? rb[R.sd0_w(t, 1, k)] * s : 0.f, c0 = bn[f + t] - bn[2 * f + t] * s;
       const float T = fabsf(wa) + fabsf(wb) + fabsf(c0);
       if (T > 0.f && !nonfinite(T)) cs = min(40, max(-40, floor_log2(T)));
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void pack_scales_kernel(const float* __restric
 
 // packed stack weights (split-f16 fragment images + sd0 parameters), see gwtf_layout.h
 __global__ void pack_w_kernel(const float* __restrict__ raw, const float* __restrict__ pf, float* __restrict__ out, int C,
-                              int f, int G, int FP, int training, int pattern0) {
+                              int f, int G, int FP, int training, int pattern0, int Cper) {
   const GwtfRaw R(f, G);
   const GwtfPackW P(FP);
   const GwtfPackF PF(FP, G);
@@ -113,7 +113,7 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, const float* __rest
       if (ft < f && !training) {   // train: written per coupling by gwtf_train_fold0
         const float* bn = rb + R.bn0();
         const float s = bn[ft] * inv_std(bn[3 * f + ft]);
-        const int k = gwtf_pattern_kept((pattern0 + c) % 6);
+        const int k = gwtf_pattern_kept((pattern0 + c % Cper) % 6);
         v = e < 2 ? (e < k ? rb[R.sd0_w(ft, e, k)] * s : 0.f) : bn[f + ft] - bn[2 * f + ft] * s;
         v = ldexpf(v, -(int)pf[((size_t)c * 2 + br) * PF.branch_size() + PF.cs() + ft]);
       }
@@ -182,19 +182,22 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
 
 }  // namespace
 
-extern "C" int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film, int C, int f, int G,
-                                 int pattern0, int training, void* stream) {
-  if (C <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_w || !packed_film || pattern0 < 0 || pattern0 > 5)
+// K stacks of Cper couplings each, concatenated (raw [K][Cper][record]): every stack starts again at warp pattern `pattern0`
+// (the records store sd0.weight with 1 or 2 kept columns depending on the coupling's pattern)
+extern "C" int gwtf_pack_weights_k(const float* raw, float* packed_w, float* packed_film, int K, int Cper, int f, int G,
+                                   int pattern0, int training, void* stream) {
+  const int C = K * Cper;
+  if (K <= 0 || Cper <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_w || !packed_film || pattern0 < 0 || pattern0 > 5)
     return GWTF_E_BADARG;
   const int FP = gwtf_padded_width(f);
   hipStream_t st = (hipStream_t)stream;
   const int threads = 256;
-  hipLaunchKernelGGL(pack_scales_kernel, dim3(2 * C), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training, pattern0);
+  hipLaunchKernelGGL(pack_scales_kernel, dim3(2 * C), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training, pattern0, Cper);
   {
     const size_t total = GwtfPackW(FP).coupling_size() * (size_t)C;
     const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
     hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_film, packed_w, C, f, G, FP, training,
-                       pattern0);
+                       pattern0, Cper);
   }
   {
     const size_t total = GwtfPackF(FP, G).coupling_size() * (size_t)C;
@@ -202,4 +205,9 @@ extern "C" int gwtf_pack_weights(const float* raw, float* packed_w, float* packe
     hipLaunchKernelGGL(pack_film_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training);
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film, int C, int f, int G,
+                                 int pattern0, int training, void* stream) {
+  return gwtf_pack_weights_k(raw, packed_w, packed_film, 1, C, f, G, pattern0, training, stream);
 }

@@ -353,9 +353,13 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
 // atomic per feature and workgroup.   ystats: [GWTF_STAT_REPLICAS][2 branches][FP][2] = {sum y, sum y^2}
 template <int MB, int NB>
 __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p, const float* __restrict__ pw_c,
-                                                    float* __restrict__ ystats, int B, int N, int pat, int kk_steps) {
+                                                    float* __restrict__ ystats, int B, int N, int pat, int kk_steps,
+                                                    size_t p_sk, size_t pw_sk, size_t ys_sk) {
   using K = Cfg<MB>;
   constexpr int FP = K::FP;
+  p += blockIdx.y * p_sk;          // blockIdx.y = mixture component (K-batched train pipeline); strides 0 for a single stack
+  pw_c += blockIdx.y * pw_sk;
+  ystats += blockIdx.y * ys_sk;
   __shared__ __align__(16) float lds[K::PW];
   __shared__ float s_stats[2 * FP * 2];
   for (int t = threadIdx.x; t < 2 * FP * 2; t += blockDim.x) s_stats[t] = 0.f;
@@ -423,8 +427,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
 // continue from, and the coordinate moments the train-mode BatchNorm of the NEXT coupling needs.
 struct Extras {
   int c_first, c_count;          // couplings processed: c_first, c_first +/- 1, ... (c_count == 0: all C)
-  const float* logdet_in;        // [B][3][N] or null
+  const float* logdet_in;        // [B][3][N] or null (component k: + k * out_stride_k)
   float* moments_out;            // [GWTF_STAT_REPLICAS][16], 9 used {Sx0,Sx1,Sx2,Sx0x0,Sx0x1,Sx0x2,Sx1x1,Sx1x2,Sx2x2}, or null
+  size_t moments_stride_k;       // component k accumulates into moments_out + k * moments_stride_k
 };
 
 struct Jobs {
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     xo[d] = own_inrange ? p[((size_t)b * 3 + d) * N + n_own] : 0.f;
-    if (ex.logdet_in && own_inrange) ld[d] = ex.logdet_in[((size_t)b * 3 + d) * N + n_own];
+    if (ex.logdet_in && own_inrange) ld[d] = ex.logdet_in[comp * out_stride_k + ((size_t)b * 3 + d) * N + n_own];
   }
   const int n_steps = ex.c_count > 0 ? ex.c_count : C;
   const int c_start = ex.c_count > 0 ? ex.c_first : (MODE == GWTF_MODE_INVERSE ? C - 1 : 0);
@@ -603,7 +608,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     }
     __syncthreads();
     if (threadIdx.x < 9)
-      atomicAdd(&ex.moments_out[(blockIdx.x % GWTF_STAT_REPLICAS) * 16 + threadIdx.x],
+      atomicAdd(&ex.moments_out[comp * ex.moments_stride_k + (blockIdx.x % GWTF_STAT_REPLICAS) * 16 + threadIdx.x],
                 s_mom[0][threadIdx.x] + s_mom[1][threadIdx.x] + s_mom[2][threadIdx.x] + s_mom[3][threadIdx.x]);
   }
 }
@@ -718,7 +723,7 @@ extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, c
                                         float* logdet, float* ps, float* mus, float* logvars, const int* segments,
                                         int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
                                         size_t p_stride_k, size_t out_stride_k, void* stream) {
-  const Extras ex = {0, 0, nullptr, nullptr};
+  const Extras ex = {0, 0, nullptr, nullptr, 0};
   return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, segments, K, B, N, C, f, pattern0, eps, mode,
                         p_stride_k, out_stride_k, ex, stream);
 }
@@ -730,9 +735,20 @@ extern "C" int gwtf_train_apply(const float* p, const float* packed_w, const flo
                                 const float* logdet_in, float* logdet, float* ps, float* mus, float* logvars,
                                 float* moments_out, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
                                 void* stream) {
-  const Extras ex = {c, 1, logdet_in, moments_out};
+  const Extras ex = {c, 1, logdet_in, moments_out, 0};
   return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, 1, B, N, C, f, pattern0, eps, mode, 0, 0,
                         ex, stream);
+}
+
+// One coupling of K stacks in one launch (K-batched train pipeline, gwtf_train.hip): component k reads p + k * p_stride_k,
+// continues logdet + k * out_stride_k, accumulates the next coupling's moments into moments_out + k * moments_stride_k.
+int gwtf_internal_apply_k(const float* p, const float* packed_w, const float* film, float* out, const float* logdet_in,
+                          float* logdet, float* ps, float* mus, float* logvars, float* moments_out, size_t moments_stride_k,
+                          int c, int K, int B, int N, int C, int f, int pattern0, float eps, int mode, size_t p_stride_k,
+                          size_t out_stride_k, void* stream) {
+  const Extras ex = {c, 1, logdet_in, moments_out, moments_stride_k};
+  return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, K, B, N, C, f, pattern0, eps, mode,
+                        p_stride_k, out_stride_k, ex, stream);
 }
 
 extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const float* film, float* out, float* logdet,
@@ -744,33 +760,39 @@ extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const f
 
 namespace {
 template <int MB>
-int launch_stats(int nb, const float* p, const float* pw_c, float* ystats, int B, int N, int pat, int kk_steps,
-                 hipStream_t st) {
+int launch_stats(int nb, const float* p, const float* pw_c, float* ystats, int B, int N, int pat, int kk_steps, int K,
+                 size_t p_sk, size_t pw_sk, size_t ys_sk, hipStream_t st) {
   const int pts_wg = 64 * nb;
-  const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg))), block(256);
+  const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
   switch (nb) {
-    case 1: hipLaunchKernelGGL((stats_kernel<MB, 1>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps); break;
-    case 2: hipLaunchKernelGGL((stats_kernel<MB, 2>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps); break;
-    default: hipLaunchKernelGGL((stats_kernel<MB, 4>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps); break;
+    case 1: hipLaunchKernelGGL((stats_kernel<MB, 1>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;
+    case 2: hipLaunchKernelGGL((stats_kernel<MB, 2>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;
+    default: hipLaunchKernelGGL((stats_kernel<MB, 4>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;
   }
   return (int)hipGetLastError();
 }
 }  // namespace
 
-extern "C" int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats, int B, int N, int f, int pattern,
-                                void* stream) {
-  if (B <= 0 || N <= 0 || f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5 || !p || !packed_w_c || !ystats)
+// statistics pass of one coupling of K stacks (component k: p + k*p_sk, packed_w_c + k*pw_sk, ystats + k*ys_sk)
+int gwtf_internal_stats_k(const float* p, const float* packed_w_c, float* ystats, int K, int B, int N, int f, int pattern,
+                          size_t p_sk, size_t pw_sk, size_t ys_sk, void* stream) {
+  if (B <= 0 || N <= 0 || K <= 0 || f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5 || !p || !packed_w_c || !ystats)
     return GWTF_E_BADARG;
-  const long pts = (long)B * N;
+  const long pts = (long)B * N * K;
   int nb = g_force_nb;
   if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
   const int kk_steps = (f + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   switch (gwtf_padded_width(f) / 16) {
-    case 1: return launch_stats<1>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
-    case 2: return launch_stats<2>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
-    case 3: return launch_stats<3>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
-    case 4: return launch_stats<4>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, st);
+    case 1: return launch_stats<1>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
+    case 2: return launch_stats<2>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
+    case 3: return launch_stats<3>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
+    case 4: return launch_stats<4>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
     default: return GWTF_E_BADARG;
   }
+}
+
+extern "C" int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats, int B, int N, int f, int pattern,
+                                void* stream) {
+  return gwtf_internal_stats_k(p, packed_w_c, ystats, 1, B, N, f, pattern, 0, 0, 0, stream);
 }

@@ -46,8 +46,13 @@ __device__ __forceinline__ int mom2_index(int a, int b) {  // index of S x_a x_b
 // One workgroup, thread = (branch, feature).  bn_batch[branch][kind 0][2][f] <- {mean, unbiased var}.
 __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
                              float* __restrict__ pw_c, float* __restrict__ pb_c, float* __restrict__ bn_batch, int f, int G,
-                             int FP) {
+                             int FP, const GwtfKS ks) {
   const int t = threadIdx.x;
+  raw_c += blockIdx.x * ks.raw;      // blockIdx.x = mixture component (K-batched pipeline); strides 0 for a single stack
+  mom_rep += blockIdx.x * ks.mom;
+  pw_c += blockIdx.x * ks.pw;
+  if (pb_c) pb_c += blockIdx.x * ks.pb;
+  bn_batch += blockIdx.x * ks.bn;
   __shared__ float mom[9];
   if (t < 9) {
     float sacc = 0.f;
@@ -93,9 +98,14 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
 // grid = B workgroups, thread = (branch, feature).  Workgroup 0 also emits the running-stat update of sd1_bn.
 __global__ void fold1_kernel(const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total,
                              const float* __restrict__ film_raw, float* __restrict__ film_rec,
-                             float* __restrict__ bn_batch, int c, int C, int f, int G, int FP) {
+                             float* __restrict__ bn_batch, int c, int C, int f, int G, int FP, const GwtfKS ks) {
   const int t = threadIdx.x, b = blockIdx.x;
   if (t >= 2 * FP) return;
+  raw_c += blockIdx.y * ks.raw;      // blockIdx.y = mixture component
+  ystats += blockIdx.y * ks.ys;
+  bn_batch += blockIdx.y * ks.bn;
+  c += blockIdx.y * ks.Cper;         // FiLM-side arrays: [shape][Ctot][...]
+  C = ks.Ctot;
   const int br = t / FP, j = t % FP;
   const GwtfRaw R(f, G);
   const size_t FS = gwtf_film_out_size(FP);
@@ -136,13 +146,38 @@ extern "C" int gwtf_train_moments(const float* p, float* moments, int B, int N, 
   return (int)hipGetLastError();
 }
 
+// internal K-batched pieces defined in gwtf_stack.hip / gwtf_bwd.hip
+int gwtf_internal_stats_k(const float* p, const float* packed_w_c, float* ystats, int K, int B, int N, int f, int pattern,
+                          size_t p_sk, size_t pw_sk, size_t ys_sk, void* stream);
+int gwtf_internal_apply_k(const float* p, const float* packed_w, const float* film, float* out, const float* logdet_in,
+                          float* logdet, float* ps, float* mus, float* logvars, float* moments_out, size_t moments_stride_k,
+                          int c, int K, int B, int N, int C, int f, int pattern0, float eps, int mode, size_t p_stride_k,
+                          size_t out_stride_k, void* stream);
+int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                                      const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
+                                      float* g_sd0, float* g_bias, int c, int K, int B, int N, int f, int pattern0, float eps,
+                                      int mode, const GwtfKS& ks, void* stream);
+int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
+                                   float* g_in, float* dw1_ws, float* g_sd0, int K, int B, int N, int f, int pattern,
+                                   const GwtfKS& ks, void* stream);
+int gwtf_internal_dw1_reduce_k(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N, int K,
+                               size_t ws_sk, size_t out_sk, void* stream);
+
+namespace {
+GwtfKS single_ks(int C) {
+  GwtfKS ks = {};
+  ks.Cper = ks.Ctot = C;
+  return ks;
+}
+}  // namespace
+
 extern "C" int gwtf_train_fold0(const float* raw_c, const float* moments, double n_total, int pattern, float* packed_w_c,
                                 float* packed_b_c, float* bn_batch_c, int f, int G, void* stream) {
   if (!raw_c || !moments || !packed_w_c || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP || G <= 0 || pattern < 0 ||
       pattern > 5 || n_total < 1.0)
     return GWTF_E_BADARG;
   hipLaunchKernelGGL(fold0_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, moments, n_total, pattern,
-                     packed_w_c, packed_b_c, bn_batch_c, f, G, gwtf_padded_width(f));
+                     packed_w_c, packed_b_c, bn_batch_c, f, G, gwtf_padded_width(f), single_ks(1));
   return (int)hipGetLastError();
 }
 
@@ -152,48 +187,8 @@ extern "C" int gwtf_train_fold1(const float* raw_c, const float* ystats, double 
       c < 0 || c >= C || n_total < 1.0)
     return GWTF_E_BADARG;
   hipLaunchKernelGGL(fold1_kernel, dim3(B), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, ystats, n_total, film_raw,
-                     film_rec, bn_batch_c, c, C, f, G, gwtf_padded_width(f));
+                     film_rec, bn_batch_c, c, C, f, G, gwtf_padded_width(f), single_ks(C));
   return (int)hipGetLastError();
-}
-
-// Whole train-mode forward of one stack on one rank (no cross-rank statistics): enqueues moments + 4 launches per
-// coupling from C, so the host cost per coupling is four hipLaunchKernel calls instead of a Python iteration.
-// Workspace (caller-owned, pre-zeroed where stated): moments [(C+1)][64][16] zero, ystats [C][64][2*FP*2] zero,
-// bn_batch [C][2][4][2][f], film_rec [B][C][FS], xbuf [2][B][3][N].  Result coordinates end in
-// xbuf[(C-1) & 1]; packed_w is modified (sd0 records filled in); packed_b (optional, for the backward: W1T sections
-// pre-filled by gwtf_pack_w1t) receives the sd0 parameters in natural order.
-extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float* packed_b, const float* film_raw,
-                                  float* moments, float* ystats, float* bn_batch, float* film_rec, float* xbuf,
-                                  float* logdet, float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G,
-                                  int pattern0, float eps, int mode, void* stream) {
-  if (!p || !raw || !packed_w || !film_raw || !moments || !ystats || !bn_batch || !film_rec || !xbuf || !logdet)
-    return GWTF_E_BADARG;
-  if (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) return GWTF_E_BADARG;
-  const int FP = gwtf_padded_width(f);
-  const size_t R = gwtf_raw_coupling_floats(f, G), PW = gwtf_packed_w_coupling_floats(f);
-  const size_t MS = (size_t)GWTF_STAT_REPLICAS * 16, YS = (size_t)GWTF_STAT_REPLICAS * 2 * FP * 2;
-  const size_t BS = (size_t)2 * 4 * 2 * f, XS = (size_t)B * 3 * N;
-  const double n_total = (double)B * N;
-  int rc = gwtf_train_moments(p, moments, B, N, stream);
-  if (rc) return rc;
-  const float* cur = p;
-  for (int step = 0; step < C; ++step) {
-    const int c = mode == GWTF_MODE_DIRECT ? step : C - 1 - step;
-    const int pat = (pattern0 + c) % 6;
-    rc = gwtf_train_fold0(raw + c * R, moments + step * MS, n_total, pat, packed_w + c * PW,
-                          packed_b ? packed_b + c * gwtf_packed_b_coupling_floats(f) : nullptr, bn_batch + c * BS, f, G, stream);
-    if (rc) return rc;
-    rc = gwtf_train_stats(cur, packed_w + c * PW, ystats + c * YS, B, N, f, pat, stream);
-    if (rc) return rc;
-    rc = gwtf_train_fold1(raw + c * R, ystats + c * YS, n_total, film_raw, film_rec, bn_batch + c * BS, c, B, C, f, G, stream);
-    if (rc) return rc;
-    float* nxt = xbuf + (size_t)(step & 1) * XS;
-    rc = gwtf_train_apply(cur, packed_w, film_rec, nxt, step > 0 ? logdet : nullptr, logdet, ps, mus, logvars,
-                          step + 1 < C ? moments + (step + 1) * MS : nullptr, c, B, N, C, f, pattern0, eps, mode, stream);
-    if (rc) return rc;
-    cur = nxt;
-  }
-  return 0;
 }
 
 // =====================================================================================================================
@@ -227,7 +222,14 @@ constexpr int kF1Slices = 16;
 __global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
     const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total, const float* __restrict__ film_raw,
     const float* __restrict__ g_film, const float* __restrict__ g_bias, float* __restrict__ g_film_raw,
-    float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G, int FP) {
+    float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G, int FP, const GwtfKS ks) {
+  raw_c += blockIdx.z * ks.raw;      // blockIdx.z = mixture component
+  ystats += blockIdx.z * ks.ys;
+  g_bias += blockIdx.z * ks.gbias;
+  g_raw_c += blockIdx.z * ks.raw;
+  g_stats += blockIdx.z * ks.gstats;
+  c += blockIdx.z * ks.Cper;
+  C = ks.Ctot;
   __shared__ float st_part[kF1Slices][16][2];
   __shared__ double acc_part[kF1Slices][16][4];
   __shared__ float bias_part[kF1Slices][2];
@@ -342,7 +344,13 @@ __device__ inline KeptMoments kept_moments(const float (&mom)[9], int k0, int k1
 // the replicas) x 16 features; the partial sums go to `part` [2][FP/16][5] doubles and combine_kernel finishes the job.
 __global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
     const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
-    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP) {
+    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP,
+    const GwtfKS ks) {
+  raw_c += blockIdx.z * ks.raw;      // blockIdx.z = mixture component
+  mom_rep += blockIdx.z * ks.mom;
+  g_sd0 += blockIdx.z * ks.gsd0;
+  g_raw_c += blockIdx.z * ks.raw;
+  part += blockIdx.z * (ks.gmom / 2);   // ks.gmom counts floats, part is double
   const int t = threadIdx.x % 16, sl = threadIdx.x / 16;
   const int br = blockIdx.x, j = blockIdx.y * 16 + t;
   __shared__ float mom_part[kF1Slices][9];
@@ -430,7 +438,13 @@ __global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ x, const float* __restrict__ ga,
                                                       const float* __restrict__ gb, const float* __restrict__ mom_rep,
                                                       const double* __restrict__ part, int n_part, double n_total, int pat,
-                                                      float* __restrict__ g_in, int B, int N) {
+                                                      float* __restrict__ g_in, int B, int N, const GwtfKS ks) {
+  x += blockIdx.z * ks.x;            // blockIdx.z = mixture component
+  ga += blockIdx.z * ks.pts;
+  gb += blockIdx.z * ks.pts;
+  g_in += blockIdx.z * ks.pts;
+  mom_rep += blockIdx.z * ks.mom;
+  part += blockIdx.z * (ks.gmom / 2);
   __shared__ float s_mom[9];
   __shared__ double s_r5[5];
   __shared__ float s_gm[16];
@@ -485,13 +499,232 @@ extern "C" int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, in
   return (int)hipGetLastError();
 }
 
-// Backward of one coupling of the train-mode pipeline (single rank): coupling path, fold1, statistics path, fold0,
-// moments path, dW1 reduction.  dw1_ws: 2 * gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f) floats (the two backward
-// passes leave their per-workgroup dW1 partials in consecutive regions; both are summed into g_raw_c's sd1 blocks).
-// g_mom: 96 floats of 8-byte aligned scratch (partial sums of the moment gradients).
-// Workspaces g_sd0 [64][2][3][FP], g_bias [64][4] must be zero on entry; g_film [B][C][2][3][FP] is accumulated for
-// coupling c only (zero on entry).  g_raw_c receives dW0, dgamma0, dbeta0, dW1, dW2, db2 (other entries of the record are
-// left untouched).
+// =====================================================================================================================
+// K-BATCHED, PHASE-SPLIT TRAIN PIPELINE.  The K components of a flow mixture (reference flow_mixture.py:163-166 loops over
+// them in Python) go through every kernel of the train-mode chain TOGETHER -- grid dimension = component -- and the chain
+// is cut into phases at exactly the points where a data-parallel run must sum statistics over the ranks
+// (SyncBatchNorm semantics, reference train_ae.py:152):
+//
+//   forward, per depth level (coupling c = step or C-1-step):
+//     GWTF_PHASE_FWD_INIT           moments of the input clouds                      -> all-reduce moments[0]      (1 x 64*16)
+//     GWTF_PHASE_FWD_A   fold0 (K workgroups) + statistics pass (K x tiles)          -> all-reduce ystats[c]       (K x 64*2*FP*2)
+//     GWTF_PHASE_FWD_B   fold1 (B x K) + apply pass (K x tiles, moments of the output) -> all-reduce moments[step+1] (K x 64*16)
+//   backward, per depth level in reverse:
+//     GWTF_PHASE_BWD_A   coupling-path backward + fold1 backward                     -> all-reduce g_stats[c]      (K x 2*2*FP)
+//     GWTF_PHASE_BWD_B   statistics-path backward + fold0 backward                   -> all-reduce g_mom[c]        (K x 48 doubles)
+//     GWTF_PHASE_BWD_C   combine (moments path) + dW1 reduction
+//
+// i.e. TWO small collectives per depth level and direction for all K x 2 branches (66 per forward of the 33-coupling
+// configs; the reference's SyncBatchNorm issues 1056), 4 + 7 launches per level instead of 4K + 10K.  A single rank runs
+// all phases back to back from one C call (gwtf_mtrain_forward / gwtf_mtrain_backward).  Buffer layouts: GwtfTrainCtx in
+// include/gwtf.h; per-level slabs are contiguous over K so that one collective covers a level.
+// =====================================================================================================================
+namespace {
+struct Dims {
+  int FP;
+  size_t RC, PW, PB, MS, YS, BS, XS, GS0, GB, GST, GM, FS;
+};
+Dims dims_of(const GwtfTrainCtx* t) {
+  Dims d;
+  d.FP = gwtf_padded_width(t->f);
+  d.RC = gwtf_raw_coupling_floats(t->f, t->G);
+  d.PW = gwtf_packed_w_coupling_floats(t->f);
+  d.PB = gwtf_packed_b_coupling_floats(t->f);
+  d.MS = (size_t)GWTF_STAT_REPLICAS * 16;
+  d.YS = (size_t)GWTF_STAT_REPLICAS * 2 * d.FP * 2;
+  d.BS = (size_t)2 * 4 * 2 * t->f;
+  d.XS = (size_t)t->B * 3 * t->N;
+  d.GS0 = (size_t)GWTF_STAT_REPLICAS * 2 * 3 * d.FP;
+  d.GB = (size_t)GWTF_STAT_REPLICAS * 4;
+  d.GST = (size_t)2 * 2 * d.FP;
+  d.GM = 96;
+  d.FS = gwtf_film_out_size(d.FP);
+  return d;
+}
+size_t dw1_region(const GwtfTrainCtx* t) {   // one component's dW1 workspace: two passes of partials + reduction scratch
+  return 2 * gwtf_dw1_workspace_floats(t->f, t->B, t->N) + gwtf_dw1_reduce_scratch_floats(t->f);
+}
+GwtfKS strides_of(const GwtfTrainCtx* t, const Dims& d, bool first_level) {
+  GwtfKS ks = {};
+  ks.raw = (size_t)t->C * d.RC;
+  ks.pw = (size_t)t->C * d.PW;
+  ks.pb = (size_t)t->C * d.PB;
+  ks.x = first_level ? 0 : d.XS;       // the first level reads the shared input clouds
+  ks.pts = d.XS;
+  ks.mom = first_level ? 0 : d.MS;     // ... and their (single) moment record
+  ks.ys = d.YS;
+  ks.bn = (size_t)t->C * d.BS;
+  ks.gsd0 = d.GS0;
+  ks.gbias = d.GB;
+  ks.gstats = d.GST;
+  ks.gmom = d.GM;
+  ks.dw1 = dw1_region(t);
+  ks.Cper = t->C;
+  ks.Ctot = t->K * t->C;
+  return ks;
+}
+bool ctx_ok(const GwtfTrainCtx* t, bool backward) {
+  if (!t || t->K <= 0 || t->K > GWTF_MAX_COMPONENTS || t->B <= 0 || t->N <= 0 || t->C <= 0 || t->f <= 0 || t->f > GWTF_MAX_FP ||
+      t->G <= 0 || t->pattern0 < 0 || t->pattern0 > 5 || t->n_total < 1.0)
+    return false;
+  if (t->mode != GWTF_MODE_DIRECT && t->mode != GWTF_MODE_INVERSE) return false;
+  if (!t->p || !t->raw || !t->packed_w || !t->film_raw || !t->film_rec || !t->moments || !t->ystats || !t->bn_batch || !t->xbuf ||
+      !t->logdet)
+    return false;
+  const bool any = t->ps || t->mus || t->logvars, all = t->ps && t->mus && t->logvars;
+  if (any && !all) return false;
+  if (backward && (!t->ps || !t->packed_b || !t->g_out || !t->g_ld || !t->g_bufs || !t->g_xa || !t->g_xb || !t->dw1_ws ||
+                   !t->g_film || !t->g_sd0 || !t->g_bias || !t->g_stats || !t->g_mom || !t->g_film_raw || !t->g_raw))
+    return false;
+  return true;
+}
+}  // namespace
+
+extern "C" size_t gwtf_mtrain_dw1_floats(int f, int B, int N) {
+  return 2 * gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f);
+}
+
+extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
+  const bool bwd = phase == GWTF_PHASE_BWD_A || phase == GWTF_PHASE_BWD_B || phase == GWTF_PHASE_BWD_C;
+  if (!ctx_ok(t, bwd) || step < 0 || step >= t->C) return GWTF_E_BADARG;
+  const Dims d = dims_of(t);
+  const int K = t->K, C = t->C, B = t->B, N = t->N, f = t->f, G = t->G, FP = d.FP;
+  hipStream_t st = (hipStream_t)t->stream;
+  if (phase == GWTF_PHASE_FWD_INIT) return gwtf_train_moments(t->p, t->moments, B, N, t->stream);
+
+  if (!bwd) {
+    const int c = t->mode == GWTF_MODE_DIRECT ? step : C - 1 - step;
+    const int pat = (t->pattern0 + c) % 6;
+    const GwtfKS ks = strides_of(t, d, step == 0);
+    const float* cur = step == 0 ? t->p : t->xbuf + (size_t)((step - 1) & 1) * K * d.XS;
+    float* mom = t->moments + (size_t)step * K * d.MS;
+    float* ys = t->ystats + (size_t)c * K * d.YS;
+    if (phase == GWTF_PHASE_FWD_A) {
+      hipLaunchKernelGGL(fold0_kernel, dim3(K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, mom, t->n_total, pat,
+                         t->packed_w + (size_t)c * d.PW, t->packed_b ? t->packed_b + (size_t)c * d.PB : nullptr,
+                         t->bn_batch + (size_t)c * d.BS, f, G, FP, ks);
+      return gwtf_internal_stats_k(cur, t->packed_w + (size_t)c * d.PW, ys, K, B, N, f, pat, ks.x, ks.pw, ks.ys, t->stream);
+    }
+    if (phase == GWTF_PHASE_FWD_B) {
+      hipLaunchKernelGGL(fold1_kernel, dim3(B, K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, ys, t->n_total,
+                         t->film_raw, t->film_rec, t->bn_batch + (size_t)c * d.BS, c, C, f, G, FP, ks);
+      float* nxt = t->xbuf + (size_t)(step & 1) * K * d.XS;
+      return gwtf_internal_apply_k(cur, t->packed_w, t->film_rec, nxt, step > 0 ? t->logdet : nullptr, t->logdet, t->ps, t->mus,
+                                   t->logvars, step + 1 < C ? t->moments + (size_t)(step + 1) * K * d.MS : nullptr, d.MS, c, K, B,
+                                   N, C, f, t->pattern0, t->eps, t->mode, ks.x, d.XS, t->stream);
+    }
+    return GWTF_E_BADARG;
+  }
+
+  // backward: `step` counts the couplings in the REVERSE of the forward's processing order
+  const bool inverse = t->mode == GWTF_MODE_INVERSE;
+  const int c = inverse ? step : C - 1 - step;
+  const int fstep = inverse ? C - 1 - c : c;            // this coupling's position in the forward order
+  const int pat = (t->pattern0 + c) % 6;
+  const bool from_p = inverse ? c + 1 >= C : c == 0;    // this coupling read the shared input clouds
+  GwtfKS ks = strides_of(t, d, fstep == 0);
+  const float* x_in = from_p ? t->p : t->ps + (size_t)(inverse ? c + 1 : c - 1) * d.XS;
+  if (!from_p) ks.x = (size_t)C * d.XS;                 // lists are [K][C][B][3][N]
+  const int c_prev = inverse ? c - 1 : c + 1;           // the coupling handled by the previous backward step
+  const float* cur = step == 0 ? t->g_out : t->g_bufs + (size_t)(c_prev & 1) * K * d.XS;
+  float* nxt = t->g_bufs + (size_t)(c & 1) * K * d.XS;
+  const float* mom = t->moments + (size_t)fstep * K * d.MS;
+  const float* ys = t->ystats + (size_t)c * K * d.YS;
+  float* g_sd0 = t->g_sd0 + (size_t)c * K * d.GS0;
+  float* g_bias = t->g_bias + (size_t)c * K * d.GB;
+  float* g_stats = t->g_stats + (size_t)c * K * d.GST;
+  float* g_mom = t->g_mom + (size_t)c * K * d.GM;
+  const float* pw_c = t->packed_w + (size_t)c * d.PW;
+  const float* pb_c = t->packed_b + (size_t)c * d.PB;
+  float* g_raw_c = t->g_raw + (size_t)c * d.RC;
+  if (phase == GWTF_PHASE_BWD_A) {
+    int rc = gwtf_internal_coupling_backward_k(x_in, cur, t->g_ld, pw_c, pb_c, t->film_rec, t->g_xa, t->dw1_ws, t->g_film, g_sd0,
+                                               g_bias, c, K, B, N, f, t->pattern0, t->eps, t->mode, ks, t->stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, K), dim3(kF1Slices * 16), 0, st, t->raw + (size_t)c * d.RC, ys,
+                       t->n_total, t->film_raw, t->g_film, g_bias, t->g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks);
+    return (int)hipGetLastError();
+  }
+  if (phase == GWTF_PHASE_BWD_B) {
+    int rc = gwtf_internal_stats_backward_k(x_in, g_stats, pw_c, pb_c, t->g_xb, t->dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0,
+                                            K, B, N, f, pat, ks, t->stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(fold0_bwd_kernel, dim3(2, FP / 16, K), dim3(kF1Slices * 16), 0, st, t->raw + (size_t)c * d.RC, mom,
+                       t->n_total, pat, g_sd0, g_raw_c, reinterpret_cast<double*>(g_mom), f, G, FP, ks);
+    return (int)hipGetLastError();
+  }
+  // GWTF_PHASE_BWD_C
+  const int bx = (N + 255) / 256;
+  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B, K), dim3(256), 0, st, x_in, t->g_xa, t->g_xb, mom,
+                     reinterpret_cast<const double*>(g_mom), 2 * (FP / 16), t->n_total, pat, nxt, B, N, ks);
+  const GwtfRaw R(f, G);
+  return gwtf_internal_dw1_reduce_k(t->dw1_ws, 2, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, K, ks.dw1, ks.raw, t->stream);
+}
+
+extern "C" int gwtf_mtrain_forward(const GwtfTrainCtx* t) {
+  if (!ctx_ok(t, false)) return GWTF_E_BADARG;
+  int rc = gwtf_mtrain_phase(t, GWTF_PHASE_FWD_INIT, 0);
+  for (int step = 0; step < t->C && !rc; ++step) {
+    rc = gwtf_mtrain_phase(t, GWTF_PHASE_FWD_A, step);
+    if (!rc) rc = gwtf_mtrain_phase(t, GWTF_PHASE_FWD_B, step);
+  }
+  return rc;
+}
+
+extern "C" int gwtf_mtrain_backward(const GwtfTrainCtx* t) {
+  if (!ctx_ok(t, true)) return GWTF_E_BADARG;
+  int rc = 0;
+  for (int step = 0; step < t->C && !rc; ++step) {
+    rc = gwtf_mtrain_phase(t, GWTF_PHASE_BWD_A, step);
+    if (!rc) rc = gwtf_mtrain_phase(t, GWTF_PHASE_BWD_B, step);
+    if (!rc) rc = gwtf_mtrain_phase(t, GWTF_PHASE_BWD_C, step);
+  }
+  return rc;
+}
+
+// which half of xbuf / g_bufs holds the final coordinates / dL/dp of component k: base + half * K*B*3*N + k * B*3*N
+extern "C" int gwtf_mtrain_final_forward_half(int C) { return (C - 1) & 1; }
+extern "C" int gwtf_mtrain_final_backward_half(int C, int mode) { return (mode == GWTF_MODE_INVERSE ? C - 1 : 0) & 1; }
+
+// ---- single-stack entry points (the ABI of round 1), now thin wrappers over the K-batched pipeline with K = 1 ----------
+extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float* packed_b, const float* film_raw,
+                                  float* moments, float* ystats, float* bn_batch, float* film_rec, float* xbuf,
+                                  float* logdet, float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G,
+                                  int pattern0, float eps, int mode, void* stream) {
+  GwtfTrainCtx t = {};
+  t.K = 1; t.B = B; t.N = N; t.C = C; t.f = f; t.G = G; t.pattern0 = pattern0; t.mode = mode; t.eps = eps;
+  t.n_total = (double)B * N;
+  t.p = p; t.raw = raw; t.packed_w = packed_w; t.packed_b = packed_b; t.film_raw = film_raw; t.film_rec = film_rec;
+  t.moments = moments; t.ystats = ystats; t.bn_batch = bn_batch; t.xbuf = xbuf; t.logdet = logdet;
+  t.ps = ps; t.mus = mus; t.logvars = logvars; t.stream = stream;
+  return gwtf_mtrain_forward(&t);
+}
+
+extern "C" int gwtf_train_backward(const float* p, const float* ps, const float* g_out, const float* g_ld, const float* raw,
+                                   const float* packed_w, const float* packed_b, const float* film_rec, const float* film_raw,
+                                   const float* moments, const float* ystats, float* g_bufs, float* g_xa, float* g_xb,
+                                   float* dw1_ws, float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom,
+                                   float* g_film_raw, float* g_raw, int* final_buf, int B, int N, int C, int f, int G,
+                                   int pattern0, float eps, int mode, void* stream) {
+  if (!final_buf) return GWTF_E_BADARG;
+  GwtfTrainCtx t = {};
+  t.K = 1; t.B = B; t.N = N; t.C = C; t.f = f; t.G = G; t.pattern0 = pattern0; t.mode = mode; t.eps = eps;
+  t.n_total = (double)B * N;
+  t.p = p; t.raw = raw; t.packed_w = const_cast<float*>(packed_w); t.packed_b = const_cast<float*>(packed_b);
+  t.film_raw = film_raw; t.film_rec = const_cast<float*>(film_rec);
+  t.moments = const_cast<float*>(moments); t.ystats = const_cast<float*>(ystats);
+  // forward-only fields the backward does not touch: any non-null pointer satisfies the context check
+  t.bn_batch = g_stats; t.xbuf = g_bufs; t.logdet = g_xa;
+  t.ps = const_cast<float*>(ps); t.mus = const_cast<float*>(ps); t.logvars = const_cast<float*>(ps);
+  t.g_out = g_out; t.g_ld = g_ld; t.g_bufs = g_bufs; t.g_xa = g_xa; t.g_xb = g_xb; t.dw1_ws = dw1_ws; t.g_film = g_film;
+  t.g_sd0 = g_sd0; t.g_bias = g_bias; t.g_stats = g_stats; t.g_mom = g_mom; t.g_film_raw = g_film_raw; t.g_raw = g_raw;
+  t.stream = stream;
+  *final_buf = gwtf_mtrain_final_backward_half(C, mode);
+  return gwtf_mtrain_backward(&t);
+}
+
+// Backward of ONE coupling of the single-rank train pipeline (kept for the per-coupling autograd nodes and their tests):
+// the three backward phases of the K = 1 pipeline on caller-addressed per-coupling buffers.
 extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* raw_c,
                                             const float* packed_w_c, const float* packed_b_c, const float* film_rec,
                                             const float* film_raw, const float* moments_c, const float* ystats_c,
@@ -506,58 +739,21 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   const int FP = gwtf_padded_width(f), pat = (pattern0 + c) % 6;
   const double n_total = (double)B * N;
   hipStream_t st = (hipStream_t)stream;
+  const GwtfKS ks = single_ks(C);
   int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dw1_ws, g_film, g_sd0,
                                   g_bias, c, B, N, C, f, pattern0, eps, mode, stream);
   if (rc) return rc;
-  hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16), dim3(kF1Slices * 16), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
-                     g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP);
+  hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, 1), dim3(kF1Slices * 16), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
+                     g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks);
   rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0, B, N,
                            f, pat, stream);
   if (rc) return rc;
   double* part = reinterpret_cast<double*>(g_mom);          // [2][FP/16][5] doubles of scratch (<= 80 floats)
-  hipLaunchKernelGGL(fold0_bwd_kernel, dim3(2, FP / 16), dim3(kF1Slices * 16), 0, st, raw_c, moments_c, n_total, pat, g_sd0,
-                     g_raw_c, part, f, G, FP);
+  hipLaunchKernelGGL(fold0_bwd_kernel, dim3(2, FP / 16, 1), dim3(kF1Slices * 16), 0, st, raw_c, moments_c, n_total, pat, g_sd0,
+                     g_raw_c, part, f, G, FP, ks);
   const int bx = (N + 255) / 256;
-  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B), dim3(256), 0, st, x_in, g_xa, g_xb, moments_c, part,
-                     2 * (FP / 16), n_total, pat, g_in, B, N);
+  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B, 1), dim3(256), 0, st, x_in, g_xa, g_xb, moments_c, part,
+                     2 * (FP / 16), n_total, pat, g_in, B, N, ks);
   const GwtfRaw R(f, G);
   return gwtf_dw1_reduce(dw1_ws, 2, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, stream);
-}
-
-// Backward of the WHOLE train-mode stack (single rank): gwtf_train_coupling_backward for every coupling in the reverse of
-// the forward's processing order, ping-ponging dL/dx between the two halves of g_bufs.  Per-coupling slices of the
-// workspaces are addressed here (layouts as allocated by the forward / documented at gwtf_train_coupling_backward):
-//   ps [C][B][3][N] (the forward's list of coupling outputs), moments [C+1][64*16], ystats [C][64*2*FP*2],
-//   g_sd0 [C][64*2*3*FP], g_bias [C][64*4] (both zero on entry), g_stats [C][2*2*FP], g_mom [C][96] (scratch), g_raw [C][raw record]
-// (zero on entry), g_bufs [2][B][3][N].  *final_buf receives the index (0/1) of the half of g_bufs that holds dL/dp.
-extern "C" int gwtf_train_backward(const float* p, const float* ps, const float* g_out, const float* g_ld, const float* raw,
-                                   const float* packed_w, const float* packed_b, const float* film_rec, const float* film_raw,
-                                   const float* moments, const float* ystats, float* g_bufs, float* g_xa, float* g_xb,
-                                   float* dw1_ws, float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom,
-                                   float* g_film_raw, float* g_raw, int* final_buf, int B, int N, int C, int f, int G,
-                                   int pattern0, float eps, int mode, void* stream) {
-  if (!p || !ps || !g_out || !g_ld || !raw || !packed_w || !packed_b || !moments || !ystats || !g_bufs || !g_sd0 || !g_bias ||
-      !g_stats || !g_mom || !g_raw || !final_buf || B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP)
-    return GWTF_E_BADARG;
-  const size_t FP = gwtf_padded_width(f), R = GWTF_STAT_REPLICAS, pts = (size_t)B * 3 * N;
-  const size_t RC = gwtf_raw_coupling_floats(f, G), PW = gwtf_packed_w_coupling_floats(f), PB = gwtf_packed_b_coupling_floats(f);
-  const bool inverse = mode == GWTF_MODE_INVERSE;
-  const float* cur = g_out;
-  int last = 0;
-  for (int i = 0; i < C; ++i) {
-    const int c = inverse ? i : C - 1 - i;                 // reverse of the forward's processing order
-    const int step = inverse ? C - 1 - c : c;              // this coupling's position in the forward order
-    const float* x_in = inverse ? (c + 1 < C ? ps + (size_t)(c + 1) * pts : p) : (c > 0 ? ps + (size_t)(c - 1) * pts : p);
-    float* nxt = g_bufs + (size_t)(c & 1) * pts;
-    const int rc = gwtf_train_coupling_backward(
-        x_in, cur, g_ld, raw + c * RC, packed_w + c * PW, packed_b + c * PB, film_rec, film_raw, moments + (size_t)step * R * 16,
-        ystats + (size_t)c * R * 2 * FP * 2, nxt, g_xa, g_xb, dw1_ws, g_film, g_sd0 + (size_t)c * R * 2 * 3 * FP,
-        g_bias + (size_t)c * R * 4, g_stats + (size_t)c * 2 * 2 * FP, g_mom + (size_t)c * 96, g_film_raw, g_raw + c * RC, c, B, N, C, f,
-        G, pattern0, eps, mode, stream);
-    if (rc) return rc;
-    cur = nxt;
-    last = c & 1;
-  }
-  *final_buf = last;
-  return 0;
 }

@@ -284,9 +284,10 @@ class StackEngine:
         if needs_grad and c0.training:
             import torch.distributed as dist
             multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-            if not multi and not getattr(self, 'force_autograd_chain', False):
+            if not getattr(self, 'force_autograd_chain', False):
+                # the fused pipeline: single rank = two C calls; several ranks = one packed statistic all-reduce per phase
                 from .autograd import train_density_forward_fast
-                out, logdet, lists, bn_batch = train_density_forward_fast(self, p, g, mode)
+                out, logdet, lists, bn_batch = train_density_forward_fast(self, p, g, mode, distributed=multi)
                 self._update_running_stats(bn_batch)
                 self._last_lists = None
                 return out, logdet, lists

@@ -42,8 +42,20 @@ class MixtureStack:
         e0._check(p, g)
         needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or any(
             t.requires_grad for d in self.decoders for t in d.parameters()))
+        if e0.couplings[0].training and not any(getattr(e, 'force_autograd_chain', False) for e in self.engines):
+            # batch-statistic BatchNorm: all K components through every kernel of the train pipeline together
+            # (csrc/gwtf_train.hip, K-batched pipeline); data-parallel runs all-reduce one packed statistic per phase
+            import torch.distributed as dist
+            from .autograd import train_density_forward_multi
+            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            with torch.set_grad_enabled(needs_grad):
+                out, logdet, _, bn_batch = train_density_forward_multi(self.engines, p, g, mode, distributed=multi)
+            for k, e in enumerate(self.engines):
+                e._update_running_stats(bn_batch[k])
+                e._last_lists = None
+            return out, logdet
         if e0.couplings[0].training or needs_grad:
-            # batch-statistic BatchNorm and/or autograd: the per-component (differentiable) path
+            # eval BatchNorm with autograd (or the cross-check chain): the per-component differentiable path
             res = [e.run(p, g, mode, False) for e in self.engines]
             return torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res])
         pw, film, eps = self._film(g.contiguous().float())

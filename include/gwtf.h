@@ -51,6 +51,10 @@ size_t gwtf_film_out_floats(int f);                   /* FiLM output per (shape,
  *                un-folded so gwtf_film_forward takes batch statistics (model.train()). */
 int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film,
                       int C, int f, int G, int pattern0, int training, void* stream);
+/* The same for K concatenated stacks of Cper couplings each (the components of a mixture): raw [K][Cper][...], every stack
+ * starts again at warp pattern `pattern0`. */
+int gwtf_pack_weights_k(const float* raw, float* packed_w, float* packed_film,
+                        int K, int Cper, int f, int G, int pattern0, int training, void* stream);
 
 /* Per-shape FiLM conditioning for all C couplings: the four Linear->BN->Swish->Linear heads of each
  * coupling applied to the latent g, then a = eps + exp(w(g)), b' = a*c1 + b(g).
@@ -163,6 +167,60 @@ int gwtf_train_backward(const float* p, const float* ps, const float* g_out, con
                         float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom, float* g_film_raw,
                         float* g_raw, int* final_buf, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
                         void* stream);
+
+/* ---- K-batched, phase-split train pipeline (round 2) -------------------------------------------------------------------
+ * All K components of a flow mixture (reference flow_mixture.py:163-166: a Python loop over self.pc_decoder) run through
+ * every kernel of the train-mode chain together, and the chain is cut exactly where a data-parallel run sums BatchNorm
+ * statistics over the ranks (SyncBatchNorm, reference train_ae.py:152): two collectives per depth level and direction.
+ * A rank that owns the whole batch calls gwtf_mtrain_forward / gwtf_mtrain_backward; a sharded run calls
+ * gwtf_mtrain_phase level by level and all-reduces (sum) the named slab between the phases:
+ *     FWD_INIT -> moments[0] (64*16 floats) | per step: FWD_A -> ystats[c] (K*64*2*FP*2) | FWD_B -> moments[step+1] (K*64*16)
+ *     per backward step: BWD_A -> g_stats[c] (K*2*2*FP) | BWD_B -> g_mom[c] (K*48 DOUBLES) | BWD_C
+ * with c = step (DIRECT) or C-1-step (INVERSE) going forward, and c = step (INVERSE) or C-1-step (DIRECT) going backward.
+ * Every buffer is caller-owned; "zero" = must be zero on entry.  FP = gwtf_padded_width(f), R = 64 statistic replicas. */
+#define GWTF_PHASE_FWD_INIT 0
+#define GWTF_PHASE_FWD_A 1
+#define GWTF_PHASE_FWD_B 2
+#define GWTF_PHASE_BWD_A 3
+#define GWTF_PHASE_BWD_B 4
+#define GWTF_PHASE_BWD_C 5
+typedef struct GwtfTrainCtx {
+  int K, B, N, C, f, G, pattern0, mode;
+  float eps;
+  double n_total;            /* points the statistics cover: B*N summed over all ranks */
+  const float* p;            /* [B][3][N]            input clouds, shared by the K components */
+  const float* raw;          /* [K][C][raw record]   parameters + buffers (gwtf_layout.h GwtfRaw) */
+  float* packed_w;           /* [K][C][packed_w]     from gwtf_pack_weights(training=1); fold0 fills the sd0 records */
+  float* packed_b;           /* [K][C][packed_b]     from gwtf_pack_w1t; fold0 fills the sd0 sections; NULL: no backward */
+  const float* film_raw;     /* [B][K*C][2][2][FP]   raw FiLM {a, b} per shape (batch-statistic FiLM BatchNorm applied) */
+  float* film_rec;           /* [B][K*C][gwtf_film_out_floats]  written by fold1, read by apply and the backward */
+  float* moments;            /* [C+1][K][R*16]       zero */
+  float* ystats;             /* [C][K][R*2*FP*2]     zero */
+  float* bn_batch;           /* [K][C][2][4][2][f]   batch {mean, unbiased var} of sd0_bn (kind 0) and sd1_bn (kind 1) */
+  float* xbuf;               /* [2][K][B][3][N]      ping-pong coordinates; result in half gwtf_mtrain_final_forward_half(C) */
+  float* logdet;             /* [K][B][3][N] */
+  float* ps; float* mus; float* logvars;   /* [K][C][B][3][N] each, or all NULL (required for the backward: ps) */
+  /* backward only */
+  const float* g_out;        /* [K][B][3][N]  dL/d out */
+  const float* g_ld;         /* [K][B][3][N]  dL/d logdet */
+  float* g_bufs;             /* [2][K][B][3][N]  dL/dp per component ends in half gwtf_mtrain_final_backward_half(C, mode) */
+  float* g_xa; float* g_xb;  /* [K][B][3][N] scratch */
+  float* dw1_ws;             /* [K][gwtf_mtrain_dw1_floats(f, B, N)] scratch */
+  float* g_film;             /* [B][K*C][2][3][FP]   zero */
+  float* g_sd0;              /* [C][K][R*2*3*FP]     zero */
+  float* g_bias;             /* [C][K][R*4]          zero */
+  float* g_stats;            /* [C][K][2*2*FP] */
+  float* g_mom;              /* [C][K][96]  (8-byte aligned; 48 doubles per component and level) */
+  float* g_film_raw;         /* [B][K*C][2][2][FP]   dL/d film_raw */
+  float* g_raw;              /* [K][C][raw record]   zero; receives dW0, dgamma0, dbeta0, dW1, dW2, db2 */
+  void* stream;
+} GwtfTrainCtx;
+size_t gwtf_mtrain_dw1_floats(int f, int B, int N);
+int gwtf_mtrain_phase(const GwtfTrainCtx* ctx, int phase, int step);
+int gwtf_mtrain_forward(const GwtfTrainCtx* ctx);
+int gwtf_mtrain_backward(const GwtfTrainCtx* ctx);
+int gwtf_mtrain_final_forward_half(int C);
+int gwtf_mtrain_final_backward_half(int C, int mode);
 
 /* Backward of gwtf_train_stats: g_stats [2][2][FP] = dL/d{sum y, sum y^2} per branch and feature (replicas already
  * summed by the caller) -> g_in (kept coordinates only); dw1_ws: this pass's dW1 partials (as gwtf_coupling_backward);

@@ -28,16 +28,37 @@ def main():
     m = m.cuda().train()
     pt = torch.from_numpy(p[b0:b1]).cuda().requires_grad_(True)
     gt = torch.from_numpy(g[b0:b1]).cuda().requires_grad_(True)
+    from go_with_the_flows_amd import autograd as gwa
+    gwa.COLLECTIVES['n'] = 0
     z, ld = m.forward_fused(pt, gt, 'inverse')
     loss = (z * torch.from_numpy(wz[b0:b1]).cuda()).sum() + (ld * torch.from_numpy(wl[b0:b1]).cuda()).sum()
     loss.backward()
+    # ONE packed statistic all-reduce per phase: 2 per depth level going forward (the level-0 moments + C statistics passes +
+    # C-1 output moments) and 2 per level going backward -- independent of the number of mixture components
+    C = 3 * L
+    assert gwa.COLLECTIVES['n'] == 4 * C, gwa.COLLECTIVES
+    # K = 2 mixture components through the same pipeline: still 4 C collectives; results == single process (checked below)
+    import go_with_the_flows_amd as gw
+    decs = [decoder_and_state(L, f, G, 20 + k)[0].cuda().train() for k in range(2)]
+    ms = gw.MixtureStack(decs)
+    ptm = torch.from_numpy(p[b0:b1]).cuda().requires_grad_(True)
+    gtm = torch.from_numpy(g[b0:b1]).cuda().requires_grad_(True)
+    gwa.COLLECTIVES['n'] = 0
+    zm, ldm = ms.forward_all(ptm, gtm, 'inverse')
+    wk = torch.tensor([1.0, -0.5], device='cuda').view(2, 1, 1, 1)
+    ((zm * wk * torch.from_numpy(wz[b0:b1]).cuda()).sum() + (ldm * wk * torch.from_numpy(wl[b0:b1]).cuda()).sum()).backward()
+    assert gwa.COLLECTIVES['n'] == 4 * C, gwa.COLLECTIVES
     from go_with_the_flows_amd.dist import all_reduce_gradients
+    for d in decs:
+        all_reduce_gradients(d, average=False)
+    mix = {'zm': zm.detach().cpu().numpy(), 'dpm': ptm.grad.cpu().numpy(), 'dgm': gtm.grad.cpu().numpy(),
+           'gm': torch.cat([q.grad.reshape(-1) for d in decs for q in d.parameters()]).cpu().numpy()}
     n_flat = all_reduce_gradients(m, average=False)           # one flat buffer, summed (DDP would also divide by W)
     assert n_flat == sum(q.numel() for q in m.parameters())
     grads = torch.cat([q.grad.reshape(-1) for q in m.parameters()])
     out = {'z': z.detach().cpu().numpy(), 'dp': pt.grad.cpu().numpy(), 'dg': gt.grad.cpu().numpy(),
            'rv': torch.cat([v.reshape(-1) for k, v in m.state_dict().items() if k.endswith('running_var')]).cpu().numpy()}
-    np.savez(os.path.join(os.environ['GWTF_TMP'], f'rank{rank}.npz'), grads=grads.cpu().numpy(), b0=b0, b1=b1, **out)
+    np.savez(os.path.join(os.environ['GWTF_TMP'], f'rank{rank}.npz'), grads=grads.cpu().numpy(), b0=b0, b1=b1, **out, **mix)
     # the reference's own wrapping (train_ae.py:152-153): SyncBatchNorm conversion + DistributedDataParallel
     m2, _ = decoder_and_state(L, f, G, 13)
     m2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m2.cuda().train())
@@ -70,6 +91,16 @@ def main():
             'running_var': rel(parts[0]['rv'], torch.cat([v.reshape(-1) for k, v in m1.state_dict().items()
                                                           if k.endswith('running_var')]).cpu().numpy()),
         }
+        # the K = 2 mixture, single process
+        decs1 = [decoder_and_state(L, f, G, 20 + k)[0].cuda().train() for k in range(2)]
+        ms1 = gw.MixtureStack(decs1)
+        pm, gm_ = torch.from_numpy(p).cuda().requires_grad_(True), torch.from_numpy(g).cuda().requires_grad_(True)
+        zm1, ldm1 = ms1.forward_all(pm, gm_, 'inverse')
+        ((zm1 * wk * torch.from_numpy(wz).cuda()).sum() + (ldm1 * wk * torch.from_numpy(wl).cuda()).sum()).backward()
+        res['mix_z'] = rel(np.concatenate([q['zm'] for q in parts], axis=1), zm1.detach().cpu().numpy())
+        res['mix_dp'] = rel(np.concatenate([q['dpm'] for q in parts]), pm.grad.cpu().numpy())
+        res['mix_dg'] = rel(np.concatenate([q['dgm'] for q in parts]), gm_.grad.cpu().numpy())
+        res['mix_param_grads'] = rel(parts[0]['gm'], torch.cat([q.grad.reshape(-1) for d in decs1 for q in d.parameters()]).cpu().numpy())
         print('DIST2', ' '.join(f'{k}={v:.2e}' for k, v in res.items()), flush=True)
         assert all(v < 2e-3 for v in res.values()), res
     else:
