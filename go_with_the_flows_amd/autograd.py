@@ -487,6 +487,7 @@ def train_density_forward(engine, p, g, distributed=False, mode='inverse'):
 # 2-rank test).
 # ======================================================================================================================
 COLLECTIVES = {'n': 0}        # statistic all-reduces issued by TrainMixtureFn (tests assert the count)
+GRAD_SINK = {'reducer': None}  # set by dist.OverlappedGradients: receives the decoders' flat gradient as soon as it exists
 
 
 def _stat_sum(t):
@@ -624,6 +625,14 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
     a = torch.cat([q[0][row0:row0 + B] for q in films], dim=1)          # (B, K*C, 2, f)
     bsh = torch.cat([q[1][row0:row0 + B] for q in films], dim=1)
     raw = Ps[0]['raw'].unsqueeze(0) if K == 1 else torch.stack([P['raw'] for P in Ps])
+    sink = GRAD_SINK['reducer']
+    if sink is not None:
+        # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
+        # the FiLM heads' part, summed by autograd): hand it to the data-parallel reducer the moment it exists, so that its
+        # all-reduce overlaps the rest of the backward pass
+        for e, P in zip(engines, Ps):
+            if P['raw'].requires_grad:
+                P['raw'].register_hook(lambda grad, e=e: sink.on_flat_gradient(grad, e))
     out, logdet, lists, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
                                                         float(rows_total) * N, distributed)
     bn_batch = bn_batch.clone()

@@ -51,7 +51,24 @@ def main():
     from go_with_the_flows_amd.dist import all_reduce_gradients
     for d in decs:
         all_reduce_gradients(d, average=False)
-    mix = {'zm': zm.detach().cpu().numpy(), 'dpm': ptm.grad.cpu().numpy(), 'dgm': gtm.grad.cpu().numpy(),
+    # the same gradients with the exchange overlapped: the decoders' flat gradient is all-reduced asynchronously from INSIDE
+    # the backward pass, the remaining parameters afterwards
+    from go_with_the_flows_amd.dist import OverlappedGradients
+    holder = torch.nn.ModuleList(decs + [torch.nn.Linear(3, 2).cuda()])
+    ref_grads = torch.cat([q.grad.reshape(-1) for d in decs for q in d.parameters()]).clone()
+    dpm, dgm = ptm.grad.cpu().numpy().copy(), gtm.grad.cpu().numpy().copy()
+    for q in holder.parameters():
+        q.grad = None
+    reducer = OverlappedGradients(holder, average=False)
+    with reducer:
+        zo, ldo = ms.forward_all(ptm, gtm, 'inverse')
+        extra = holder[-1](torch.ones(1, 3, device='cuda')).sum() * (rank + 1.0)
+        ((zo * wk * torch.from_numpy(wz[b0:b1]).cuda()).sum() + (ldo * wk * torch.from_numpy(wl[b0:b1]).cuda()).sum() + extra).backward()
+    assert reducer.launched == 2                  # one flat gradient per decoder, launched from inside the backward pass
+    got = torch.cat([q.grad.reshape(-1) for d in decs for q in d.parameters()])
+    assert float((got - ref_grads).abs().max() / ref_grads.abs().max()) < 1e-5
+    assert abs(float(holder[-1].bias.grad[0]) - sum(r + 1.0 for r in range(world))) < 1e-6     # the non-decoder remainder
+    mix = {'zm': zm.detach().cpu().numpy(), 'dpm': dpm, 'dgm': dgm,
            'gm': torch.cat([q.grad.reshape(-1) for d in decs for q in d.parameters()]).cpu().numpy()}
     n_flat = all_reduce_gradients(m, average=False)           # one flat buffer, summed (DDP would also divide by W)
     assert n_flat == sum(q.numel() for q in m.parameters())
