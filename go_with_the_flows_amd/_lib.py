@@ -44,6 +44,7 @@ _SIGNATURES = {
     'gwtf_pack_folded': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_train_backward': (ctypes.c_int, [_c_fp] * 23 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_coupling_backward': (ctypes.c_int, [_c_fp] * 11 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_coupling_backward_lists': (ctypes.c_int, [_c_fp] * 13 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stats_backward': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 4 + [_c_fp]),
     'gwtf_dw1_partials': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     'gwtf_dw1_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
@@ -84,7 +85,7 @@ class TrainCtx(ctypes.Structure):
                 [('eps', ctypes.c_float), ('n_total', ctypes.c_double)] +
                 [(n, ctypes.c_void_p) for n in (
                     'p', 'raw', 'packed_w', 'packed_b', 'film_raw', 'film_rec', 'moments', 'ystats', 'bn_batch', 'xbuf',
-                    'logdet', 'ps', 'mus', 'logvars', 'g_out', 'g_ld', 'g_bufs', 'g_xa', 'g_xb', 'dw1_ws', 'g_film', 'g_sd0',
+                    'logdet', 'ps', 'mus', 'logvars', 'g_out', 'g_ld', 'g_ps', 'g_lvs', 'g_bufs', 'g_xa', 'g_xb', 'dw1_ws', 'g_film', 'g_sd0',
                     'g_bias', 'g_stats', 'g_mom', 'g_film_raw', 'g_raw', 'stream')])
 EXPORTS = tuple(_SIGNATURES)
 

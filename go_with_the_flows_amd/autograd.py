@@ -129,7 +129,10 @@ def film_record(cvec, u, b2, FP):
 
 
 class StackDensityFn(torch.autograd.Function):
-    """out, logdet = inverse pass of the whole stack, differentiable w.r.t. p and the folded tensors."""
+    """out, logdet, ps, mus, lvs = pass of the whole stack (either direction), differentiable w.r.t. p and the folded
+    tensors through out, logdet AND every per-coupling list entry ps[j] / lvs[j] (the reference's list API returns
+    differentiable tensors in every slot, decoders.py:61-79).  mus[j] is returned for the API; a gradient arriving through it
+    raises (no reference consumer differentiates through mus)."""
 
     @staticmethod
     def forward(ctx, p, W0f, c0f, W1p, cvec, u, b2, C, f, pattern0, eps, mode):
@@ -147,12 +150,16 @@ class StackDensityFn(torch.autograd.Function):
         out, logdet, lists = _lib.stack_forward(p, pw, rec, C, f, pattern0, eps, mode, True)
         ctx.save_for_backward(p, lists[0], pw, pb, rec)
         ctx.meta = (C, f, FP, pattern0, eps, mode)
-        return out, logdet
+        ctx.set_materialize_grads(False)          # list slots nobody differentiates through arrive as None, not as zeros
+        return out, logdet, lists[0], lists[1], lists[2]
 
     @staticmethod
-    def backward(ctx, g_out, g_logdet):
+    def backward(ctx, g_out, g_logdet, g_ps, g_mus, g_lvs):
         p, ps, pw, pb, rec = ctx.saved_tensors
         C, f, FP, pattern0, eps, mode = ctx.meta
+        if g_mus is not None:
+            raise NotImplementedError('a gradient reached a mus[j] list entry: the HIP backward differentiates through ps[j], '
+                                      'logvars[j], the final coordinates and sum(logvars) only')
         inverse = mode == 'inverse'
         L = _lib.lib()
         B, _, N = p.shape
@@ -161,6 +168,8 @@ class StackDensityFn(torch.autograd.Function):
         PW, PB = L.gwtf_packed_w_coupling_floats(f), L.gwtf_packed_b_coupling_floats(f)
         cur = (g_out if g_out is not None else torch.zeros_like(p)).contiguous().float()
         g_ld = (g_logdet if g_logdet is not None else torch.zeros_like(p)).contiguous().float()
+        g_ps = g_ps.contiguous().float() if g_ps is not None else None
+        g_lvs = g_lvs.contiguous().float() if g_lvs is not None else None
         g_film = torch.zeros(B, C, 2, 3, FP, device=dev, dtype=torch.float32)
         g_sd0 = torch.zeros(C, R, 2, 3, FP, device=dev, dtype=torch.float32)
         g_bias = torch.zeros(C, R, 4, device=dev, dtype=torch.float32)
@@ -175,7 +184,10 @@ class StackDensityFn(torch.autograd.Function):
                 else:
                     x_in = ps[c - 1] if c > 0 else p
                 nxt = bufs[c & 1]
-                _lib.check(L.gwtf_coupling_backward(x_in.data_ptr(), cur.data_ptr(), g_ld.data_ptr(),
+                # gradients entering through this coupling's own list slots are added inside the kernel
+                _lib.check(L.gwtf_coupling_backward_lists(x_in.data_ptr(), cur.data_ptr(), g_ld.data_ptr(),
+                                                    g_ps[c].data_ptr() if g_ps is not None else None,
+                                                    g_lvs[c].data_ptr() if g_lvs is not None else None,
                                                     pw[c * PW:].data_ptr(), pb[c * PB:].data_ptr(), rec.data_ptr(),
                                                     nxt.data_ptr(), ws.data_ptr(), g_film.data_ptr(),
                                                     g_sd0[c].data_ptr(), g_bias[c].data_ptr(), c, B, N, C, f, pattern0,
@@ -193,10 +205,13 @@ class StackDensityFn(torch.autograd.Function):
 
 
 def density_forward(engine, p, g, mode='inverse'):
-    """Differentiable (out, logdet) of the whole stack in either direction; eval-mode BatchNorm."""
+    """Differentiable (out, logdet, (ps, mus, lvs) stacked (C,B,3,N) each) of the whole stack in either direction;
+    eval-mode BatchNorm."""
     eps = engine.couplings[0]._eps_value
     W0f, c0f, W1p, cvec, u, b2 = fold(engine, g.float(), eps)
-    return StackDensityFn.apply(p.float(), W0f, c0f, W1p, cvec, u, b2, engine.C, engine.f, engine.pattern0, eps, mode)
+    out, logdet, ps, mus, lvs = StackDensityFn.apply(p.float(), W0f, c0f, W1p, cvec, u, b2, engine.C, engine.f,
+                                                     engine.pattern0, eps, mode)
+    return out, logdet, (ps, mus, lvs)
 
 
 # ======================================================================================================================
@@ -545,14 +560,20 @@ class TrainMixtureFn(torch.autograd.Function):
                     if step + 1 < C:
                         _stat_sum(mom[step + 1])
         out = bufs['xbuf'][L.gwtf_mtrain_final_forward_half(C)].clone()
-        ctx.save_for_backward(p, raw, lists, pw, pb, bufs['film_rec'], film_raw, bufs['moments'], bufs['ystats'])
+        ctx.save_for_backward(p, raw, lists[0], pw, pb, bufs['film_rec'], film_raw, bufs['moments'], bufs['ystats'])
         ctx.meta = (int(K), int(C), int(f), int(G), int(FP), int(pattern0), float(eps), mode, float(n_total), bool(sharded))
-        ctx.mark_non_differentiable(lists, bufs['bn_batch'])
-        return out, bufs['logdet'], lists, bufs['bn_batch']
+        ctx.mark_non_differentiable(bufs['bn_batch'])
+        ctx.set_materialize_grads(False)
+        # ps / logvars list slots are differentiable (the backward kernels add a slot's gradient where its coupling is
+        # processed); a gradient through a mus slot raises
+        return out, bufs['logdet'], lists[0], lists[1], lists[2], bufs['bn_batch']
 
     @staticmethod
-    def backward(ctx, g_out, g_logdet, _gl, _gb):
-        p, raw, lists, pw, pb, film_rec, film_raw, mom, ystats = ctx.saved_tensors
+    def backward(ctx, g_out, g_logdet, g_ps, g_mus, g_lvs, _gb):
+        if g_mus is not None:
+            raise NotImplementedError('a gradient reached a mus[j] list entry: the HIP backward differentiates through ps[j], '
+                                      'logvars[j], the final coordinates and sum(logvars) only')
+        p, raw, ps_saved, pw, pb, film_rec, film_raw, mom, ystats = ctx.saved_tensors
         K, C, f, G, FP, pattern0, eps, mode, n_total, sharded = ctx.meta
         L = _lib.lib()
         B, _, N = p.shape
@@ -574,8 +595,12 @@ class TrainMixtureFn(torch.autograd.Function):
         t.p, t.raw, t.packed_w, t.packed_b = p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr()
         t.film_raw, t.film_rec, t.moments, t.ystats = film_raw.data_ptr(), film_rec.data_ptr(), mom.data_ptr(), ystats.data_ptr()
         t.bn_batch, t.xbuf, t.logdet = bufs['g_stats'].data_ptr(), bufs['g_bufs'].data_ptr(), scratch.data_ptr()   # forward-only fields
-        t.ps, t.mus, t.logvars = lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr()
+        t.ps, t.mus, t.logvars = ps_saved.data_ptr(), ps_saved.data_ptr(), ps_saved.data_ptr()
         t.g_out, t.g_ld = g_out.data_ptr(), g_ld.data_ptr()
+        g_ps = g_ps.contiguous().float() if g_ps is not None else None
+        g_lvs = g_lvs.contiguous().float() if g_lvs is not None else None
+        t.g_ps = g_ps.data_ptr() if g_ps is not None else None
+        t.g_lvs = g_lvs.data_ptr() if g_lvs is not None else None
         for name, buf in bufs.items():
             setattr(t, name, buf.data_ptr())
         t.stream = _lib._stream(p)
@@ -608,7 +633,8 @@ def _rank_rows(g):
 
 def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False):
     """Train-mode density pass of K stacks (the components of a mixture, or one decoder) through the fused pipeline.
-    -> out, logdet (K,B,3,N), lists (3,K,C,B,3,N) detached, bn_batch (K,C,2,4,2,f) incl. the FiLM BatchNorm statistics."""
+    -> out, logdet (K,B,3,N), lists = (ps, mus, lvs) each (K,C,B,3,N) with ps / lvs differentiable, bn_batch (K,C,2,4,2,f)
+    incl. the FiLM BatchNorm statistics."""
     e0 = engines[0]
     K, C, f, G, eps = len(engines), e0.C, e0.f, e0.G, e0.couplings[0]._eps_value
     B, _, N = p.shape
@@ -633,8 +659,9 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
         for e, P in zip(engines, Ps):
             if P['raw'].requires_grad:
                 P['raw'].register_hook(lambda grad, e=e: sink.on_flat_gradient(grad, e))
-    out, logdet, lists, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
-                                                        float(rows_total) * N, distributed)
+    out, logdet, ps, mus, lvs, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
+                                                               float(rows_total) * N, distributed)
+    lists = (ps, mus, lvs)                                   # (K,C,B,3,N) each; ps / lvs differentiable
     bn_batch = bn_batch.clone()
     bn_batch[:, :, :, 2:4, 0] = torch.stack([q[2] for q in films])
     bn_batch[:, :, :, 2:4, 1] = torch.stack([q[3] for q in films])
@@ -642,6 +669,6 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
 
 
 def train_density_forward_fast(engine, p, g, mode='inverse', distributed=False):
-    """One stack through the fused pipeline.  -> out, logdet (B,3,N), lists (3,C,B,3,N) detached, bn_batch (C,2,4,2,f)."""
+    """One stack through the fused pipeline.  -> out, logdet (B,3,N), lists = (ps, mus, lvs) (C,B,3,N) each, bn_batch (C,2,4,2,f)."""
     out, logdet, lists, bn_batch = train_density_forward_multi([engine], p, g, mode, distributed)
-    return out[0], logdet[0], lists[:, 0], bn_batch[0]
+    return out[0], logdet[0], tuple(t[0] for t in lists), bn_batch[0]

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
                                                   float* __restrict__ g_film,
                                                   float* __restrict__ g_sd0, float* __restrict__ g_bias,
                                                   const float* __restrict__ g_stats, int B, int N, int C, int c, int pat,
-                                                  float eps, int kk_steps, int f, int mode, const GwtfKS ks_) {
+                                                  float eps, int kk_steps, int f, int mode, const GwtfKS ks_,
+                                                  const float* __restrict__ g_ps_c, const float* __restrict__ g_lvs_c) {
   using K = Cfg<MB>;
   using KB = BCfg<MB>;
   constexpr int FP = K::FP;
@@ -62,6 +63,9 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     if (!STATS) {
       g_out += comp * ks_.pts;
       g_ld += comp * ks_.pts;
+      // gradients entering through this coupling's own list slots (ps[c], logvars[c]; lists are [K][Cper][B][3][N])
+      if (g_ps_c) g_ps_c += comp * ks_.Cper * ks_.pts;
+      if (g_lvs_c) g_lvs_c += comp * ks_.Cper * ks_.pts;
       g_bias += comp * ks_.gbias;
       c += (int)comp * ks_.Cper;     // FiLM-side arrays: [shape][Ctot][...], coupling k*Cper + c
       C = ks_.Ctot;
@@ -126,6 +130,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     xo[d] = own_inrange ? x_in[o] : 0.f;
     go[d] = (!STATS && own_inrange) ? g_out[o] : 0.f;
     gl[d] = (!STATS && own_inrange) ? g_ld[o] : 0.f;
+    if (!STATS && own_inrange && g_ps_c) go[d] += g_ps_c[o];
+    if (!STATS && own_inrange && g_lvs_c) gl[d] += g_lvs_c[o];
   }
   float xa[NB], xb[NB];
 #pragma unroll
@@ -512,10 +518,10 @@ template <int MB, bool STATS>
 int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
                const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0, float* g_bias,
                const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, int mode, int K,
-               const GwtfKS& ks, hipStream_t st) {
+               const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
-#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks)
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B
   return (int)hipGetLastError();
@@ -536,6 +542,12 @@ extern "C" int gwtf_pack_folded(const float* W1p, const float* W0f, const float*
   return (int)hipGetLastError();
 }
 
+extern "C" int gwtf_coupling_backward_lists(const float* x_in, const float* g_out, const float* g_ld, const float* g_ps_c,
+                                            const float* g_lvs_c, const float* packed_w_c, const float* packed_b_c,
+                                            const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0,
+                                            float* g_bias, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                                            void* stream);
+
 static int bwd_points_per_wg(int B, int N) { return (long)B * N >= 2048L * 32 ? 128 : 64; }
 static int bwd_grid(int B, int N) {
   const int pts = bwd_points_per_wg(B, N);
@@ -545,11 +557,11 @@ static int bwd_grid(int B, int N) {
 static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                         const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0,
                         float* g_bias, const float* g_stats, int c, int B, int N, int C, int f, int pat, float eps, int mode,
-                        int K, const GwtfKS& ks, void* stream) {
+                        int K, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
   const int kk_steps = (f + 3) / 4;
   const int nb = bwd_points_per_wg(B, N) / 64;
   hipStream_t st = (hipStream_t)stream;
-#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, K, ks, st
+#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, K, ks, g_ps_c, g_lvs_c, st
   switch (gwtf_padded_width(f) / 16) {
     case 1: return stats ? launch_bwd<1, true>(nb, GWTF_A) : launch_bwd<1, false>(nb, GWTF_A);
     case 2: return stats ? launch_bwd<2, true>(nb, GWTF_A) : launch_bwd<2, false>(nb, GWTF_A);
@@ -564,6 +576,15 @@ extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, con
                                       const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
                                       float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0, float eps,
                                       int mode, void* stream) {
+  return gwtf_coupling_backward_lists(x_in, g_out, g_ld, nullptr, nullptr, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film,
+                                      g_sd0, g_bias, c, B, N, C, f, pattern0, eps, mode, stream);
+}
+
+extern "C" int gwtf_coupling_backward_lists(const float* x_in, const float* g_out, const float* g_ld, const float* g_ps_c,
+                                            const float* g_lvs_c, const float* packed_w_c, const float* packed_b_c,
+                                            const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0,
+                                            float* g_bias, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                                            void* stream) {
   if (!x_in || !g_out || !g_ld || !packed_w_c || !packed_b_c || !film || !g_in || !dw1_ws || !g_film || !g_sd0 ||
       !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5 ||
       (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE))
@@ -571,23 +592,23 @@ extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, con
   GwtfKS ks = {};
   ks.Cper = ks.Ctot = C;
   return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
-                      B, N, C, f, (pattern0 + c) % 6, eps, mode, 1, ks, stream);
+                      B, N, C, f, (pattern0 + c) % 6, eps, mode, 1, ks, g_ps_c, g_lvs_c, stream);
 }
 
 // K-batched variants (train pipeline, gwtf_train.hip): component k adds k * stride (GwtfKS) to every base pointer
 int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                       const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
                                       float* g_sd0, float* g_bias, int c, int K, int B, int N, int f, int pattern0, float eps,
-                                      int mode, const GwtfKS& ks, void* stream) {
+                                      int mode, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
   return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
-                      B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, stream);
+                      B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c, g_lvs_c, stream);
 }
 int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
                                    float* g_in, float* dw1_ws, float* g_sd0, int K, int B, int N, int f, int pattern,
                                    const GwtfKS& ks, void* stream) {
   return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dw1_ws,
                       g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, K, ks,
-                      stream);
+                      nullptr, nullptr, stream);
 }
 
 extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c,

@@ -156,7 +156,7 @@ int gwtf_internal_apply_k(const float* p, const float* packed_w, const float* fi
 int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                       const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
                                       float* g_sd0, float* g_bias, int c, int K, int B, int N, int f, int pattern0, float eps,
-                                      int mode, const GwtfKS& ks, void* stream);
+                                      int mode, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream);
 int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
                                    float* g_in, float* dw1_ws, float* g_sd0, int K, int B, int N, int f, int pattern,
                                    const GwtfKS& ks, void* stream);
@@ -639,7 +639,9 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   float* g_raw_c = t->g_raw + (size_t)c * d.RC;
   if (phase == GWTF_PHASE_BWD_A) {
     int rc = gwtf_internal_coupling_backward_k(x_in, cur, t->g_ld, pw_c, pb_c, t->film_rec, t->g_xa, t->dw1_ws, t->g_film, g_sd0,
-                                               g_bias, c, K, B, N, f, t->pattern0, t->eps, t->mode, ks, t->stream);
+                                               g_bias, c, K, B, N, f, t->pattern0, t->eps, t->mode, ks,
+                                               t->g_ps ? t->g_ps + (size_t)c * d.XS : nullptr,
+                                               t->g_lvs ? t->g_lvs + (size_t)c * d.XS : nullptr, t->stream);
     if (rc) return rc;
     hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, K), dim3(kF1Slices * 16), 0, st, t->raw + (size_t)c * d.RC, ys,
                        t->n_total, t->film_raw, t->g_film, g_bias, t->g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks);

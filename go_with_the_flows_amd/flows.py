@@ -23,6 +23,17 @@ _VERSION = operator.attrgetter('_version')
 WARP_PATTERNS = ((0,), (1,), (2,), (0, 1), (0, 2), (1, 2))
 
 
+def _sharded():
+    """True when BatchNorm statistics must be summed over the ranks of torch.distributed's default group (more than one
+    rank; GWTF_FORCE_SHARDED=1 takes the phase-split path on a 1-rank group too -- the only way to run the statistic
+    collectives over RCCL on a one-GPU box, tests/rccl_single_rank_worker.py)."""
+    import os
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('GWTF_FORCE_SHARDED') == '1'
+
+
 def _film_head(X, which, f, G):
     n = f'{X}_sd1_film_{which}'
     return nn.Sequential(OrderedDict([
@@ -283,7 +294,7 @@ class StackEngine:
                                                   any(t.requires_grad for t in self._tracked or self._collect()))
         if needs_grad and c0.training:
             import torch.distributed as dist
-            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            multi = _sharded()
             if not getattr(self, 'force_autograd_chain', False):
                 # the fused pipeline: single rank = two C calls; several ranks = one packed statistic all-reduce per phase
                 from .autograd import train_density_forward_fast
@@ -299,15 +310,11 @@ class StackEngine:
                 if want_lists else None
             return out, logdet, lists
         if needs_grad and not c0.training:
-            # differentiable density pass: HIP forward + HIP backward (autograd.py); the per-coupling lists are
-            # returned detached (no reference consumer differentiates through them)
+            # differentiable density pass: HIP forward + HIP backward (autograd.py); every ps[j] / logvars[j] list entry is
+            # differentiable as in the reference (decoders.py:61-79); a gradient through a mus[j] entry raises
             from .autograd import density_forward
-            out, logdet = density_forward(self, p, g, mode)
-            lists = None
-            if want_lists:
-                with torch.no_grad():
-                    lists = self.run(p.detach(), g.detach(), mode, True)[2]
-                # direct-order slot 0 is the final output: keep the differentiable tensor there
+            out, logdet, lists = density_forward(self, p, g, mode)
+            self._last_lists = None
             return out, logdet, lists
         pc, gc = p.contiguous().float(), g.contiguous().float()
         eps = c0._eps_value
@@ -400,11 +407,6 @@ class StackEngine:
             dps, dmus, dlvs = self._last_lists          # train mode: every ps[j] / logvars[j] is differentiable
             self._last_lists = None
             return list(dps), list(dmus), list(dlvs)
-        if out.requires_grad:
-            # differentiable entries the reference's loss reads: ps[0] (inverse) and sum(logvars) -- keep the sum
-            # differentiable by routing it through one slot (the others are detached constants)
-            ps[0 if mode == 'inverse' else -1] = out
-            lvs[0] = lvs[0] + (logdet - logdet.detach())
         return ps, mus, lvs
 
 

@@ -47,7 +47,8 @@ class MixtureStack:
             # (csrc/gwtf_train.hip, K-batched pipeline); data-parallel runs all-reduce one packed statistic per phase
             import torch.distributed as dist
             from .autograd import train_density_forward_multi
-            multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+            from .flows import _sharded
+            multi = _sharded()
             with torch.set_grad_enabled(needs_grad):
                 out, logdet, _, bn_batch = train_density_forward_multi(self.engines, p, g, mode, distributed=multi)
             for k, e in enumerate(self.engines):

@@ -144,6 +144,13 @@ int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g
                            float* g_sd0, float* g_bias, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
                            void* stream);
 
+/* The same with gradients that enter through the coupling's own list slots (the reference's forward returns differentiable
+ * per-coupling lists, decoders.py:61-79): g_ps_c = dL/d ps[c], g_lvs_c = dL/d logvars[c], each [B][3][N] or NULL. */
+int gwtf_coupling_backward_lists(const float* x_in, const float* g_out, const float* g_ld, const float* g_ps_c,
+                                 const float* g_lvs_c, const float* packed_w_c, const float* packed_b_c, const float* film,
+                                 float* g_in, float* dw1_ws, float* g_film, float* g_sd0, float* g_bias, int c, int B, int N,
+                                 int C, int f, int pattern0, float eps, int mode, void* stream);
+
 /* Backward records of the train pipeline: W1T sections from the un-scaled sd1 weights (sd0 sections: gwtf_train_fold0). */
 int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, int G, void* stream);
 /* Backward of ONE coupling of the single-rank train pipeline (coupling path + fold1 + statistics path + fold0 + moments
@@ -203,6 +210,8 @@ typedef struct GwtfTrainCtx {
   /* backward only */
   const float* g_out;        /* [K][B][3][N]  dL/d out */
   const float* g_ld;         /* [K][B][3][N]  dL/d logdet */
+  const float* g_ps;         /* [K][C][B][3][N] or NULL: dL/d ps[c], gradients entering through the per-coupling list slots */
+  const float* g_lvs;        /* [K][C][B][3][N] or NULL: dL/d logvars[c] */
   float* g_bufs;             /* [2][K][B][3][N]  dL/dp per component ends in half gwtf_mtrain_final_backward_half(C, mode) */
   float* g_xa; float* g_xb;  /* [K][B][3][N] scratch */
   float* dw1_ws;             /* [K][gwtf_mtrain_dw1_floats(f, B, N)] scratch */

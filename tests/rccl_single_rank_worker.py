@@ -28,6 +28,20 @@ n = gdist.all_reduce_gradients(m, average=True, force=True)
 torch.cuda.synchronize()
 assert n == sum(q.numel() for q in m.parameters()), n
 assert all(torch.equal(a, q.grad) for a, q in zip(before, m.parameters()))
+# the phase-split train pipeline with its statistic all-reduces going over RCCL (1-rank group): same numbers as the
+# single-call pipeline, 4 C collectives
+from go_with_the_flows_amd import autograd as gwa                   # noqa: E402
+os.environ['GWTF_FORCE_SHARDED'] = '1'
+gwa.COLLECTIVES['n'] = 0
+m.zero_grad(set_to_none=True)
+z2, ld2 = m.forward_fused(torch.from_numpy(p).to(dev), torch.from_numpy(g).to(dev), 'inverse')
+(0.5 * (ld2 + z2 * z2).sum() / 4).backward()
+torch.cuda.synchronize()
+assert gwa.COLLECTIVES['n'] == 4 * 3, gwa.COLLECTIVES
+assert float((z2 - z).abs().max()) < 1e-5 and float((ld2 - ld).abs().max()) < 1e-5
+worst = max(float((a - q.grad).abs().max() / (a.abs().max() + 1e-12)) for a, q in zip(before, m.parameters()))
+assert worst < 1e-4, worst
+del os.environ['GWTF_FORCE_SHARDED']
 t = torch.full((1 << 20,), 2.0, device=dev)
 dist.all_reduce(t)
 assert float(t.sum()) == 2.0 * (1 << 20)

@@ -881,3 +881,52 @@ def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B,
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
         else:
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('training', [False, True])
+@pytest.mark.parametrize('mode', ['inverse', 'direct'])
+def test_every_ps_and_logvar_list_slot_is_differentiable(training, mode):
+    """The reference's forward returns differentiable tensors in EVERY list slot (decoders.py:61-79).  A loss built from
+    intermediate slots ps[j], logvars[j] (not only ps[0] / ps[-1] and sum(logvars)) gets the gradients CPU autograd gives;
+    a gradient through a mus[j] slot raises instead of being silently dropped."""
+    from oracle import torch_port as tp
+    L, f, G, B, N = 2, 19, 12, 3, 70
+    m, st = decoder_and_state(L, f, G, 5150)
+    m = m.to(DEV).train(training)
+    p, g = synth_inputs(B, N, G, 5151)
+    rng = np.random.default_rng(5152)
+    C = 3 * L
+    w_ps = rng.normal(size=(C, B, 3, N)).astype(np.float32)
+    w_lv = rng.normal(size=(C, B, 3, N)).astype(np.float32)
+    w_ps[[1, 4]] = 0.0                                   # some slots unused, some used
+    pd, gd = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+    ps, mus, lvs = m(pd, gd, mode)
+    loss = sum((ps[j] * dev(w_ps[j])).sum() + (lvs[j] * dev(w_lv[j])).sum() for j in range(C))
+    loss.backward()
+    # CPU autograd of the torch port, coupling by coupling (lists in direct order)
+    tst = {k: torch.from_numpy(v.copy()).double() if v.dtype == np.float32 else torch.from_numpy(v.copy()) for k, v in st.items()}
+    for k, v in tst.items():
+        if v.dtype == torch.float64 and 'running' not in k and not k.endswith('eps'):
+            v.requires_grad_(True)
+    pt, gt = torch.from_numpy(p).double().requires_grad_(True), torch.from_numpy(g).double().requires_grad_(True)
+    tp._TRAIN[0] = training
+    try:
+        cur, rps, rlvs = pt, [None] * C, [None] * C
+        for c in (range(C) if mode == 'direct' else range(C - 1, -1, -1)):
+            cur, _, lv = tp.coupling(cur, gt, tst, f'flows.{c // 3}.nvp{c % 3 + 1}.', tp.PATTERNS[c % 6], mode)
+            rps[c], rlvs[c] = cur, lv
+    finally:
+        tp._TRAIN[0] = False
+    ref = sum((rps[j] * torch.from_numpy(w_ps[j]).double()).sum() + (rlvs[j] * torch.from_numpy(w_lv[j]).double()).sum() for j in range(C))
+    ref.backward()
+    tol = 2e-3 if training else 2e-4
+    assert abs(float(loss) - float(ref)) < 1e-4 * abs(float(ref)) + 1e-3
+    assert _rel(host(pd.grad), pt.grad.numpy()) < tol and _rel(host(gd.grad), gt.grad.numpy()) < tol
+    worst = 0.0
+    for k, v in m.named_parameters():
+        worst = max(worst, float((v.grad.double().cpu() - tst[k].grad).norm() / (tst[k].grad.norm() + 1e-30)))
+    assert worst < tol, worst
+    # a gradient through mus[j] must not be dropped silently
+    ps, mus, lvs = m(dev(p).requires_grad_(True), dev(g), mode)
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        (ps[0].sum() + mus[2].sum()).backward()
