@@ -32,6 +32,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // x = hi + lo with both parts rounded to nearest f16 (|lo| <= 2^-12 |x|): v_cvt_pk_f16_f32, two mixed-precision
 // FMAs computing h - float(hi) with the f16 operand converted inside the instruction (v_fma_mix_f32; the compiler
 // does not form it by itself: it emitted 2 x v_cvt_f32_f16 + v_pk_add_f32), v_cvt_pk_f16_f32: 4 VALU for two values.
+// MEASURED AND REJECTED (round 2): writing the lo pair directly with v_fma_mixlo_f16 + v_fma_mixhi_f16 (3 VALU, no second
+// conversion).  Same values on paper, and the census drops by 32 VALU per coupling and wave, but (1) the airplane kernel got
+// SLOWER (0.495 -> 0.510 ms: the two partial-register writes serialise on one destination) and (2) about one backward pass
+// in five came out wrong by 1e-3..1e-2 relative (same inputs, same process: tools/diag/bwd_repeat2.py) although hipcc did
+// put an s_nop between the two partial writes -- a forwarding hazard of 16-bit destination writes that the inline asm hides
+// from the compiler on the consumer side.  tests/test_gpu_parity.py::test_backward_is_reproducible_run_to_run guards it.
 __device__ __forceinline__ void split_pair(f32x2 h, f16x2& hi, f16x2& lo) {
   hi = __builtin_convertvector(h, f16x2);
   f32x2 r;

@@ -930,3 +930,24 @@ def test_every_ps_and_logvar_list_slot_is_differentiable(training, mode):
     ps, mus, lvs = m(dev(p).requires_grad_(True), dev(g), mode)
     with pytest.raises((NotImplementedError, RuntimeError)):
         (ps[0].sum() + mus[2].sum()).backward()
+
+
+def test_backward_is_reproducible_run_to_run():
+    """The same forward differentiated six times gives the same input gradient up to the order of float atomics (1e-6 of
+    its scale).  Regression guard: a partial-register-write hazard (v_fma_mixlo/mixhi_f16 in the f16 split) once made about
+    one backward in five wrong by 1e-3..1e-2 on exactly this ill-conditioned case (B*N = 192 points of batch statistics)."""
+    L, f, G, B, N = 2, 8, 16, 4, 48
+    p, g = synth_inputs(B, N, G, 1)
+    m, _ = decoder_and_state(L, f, G, 7)
+    m = m.to(DEV).train()
+    pd, gd = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+    z, ld = m.forward_fused(pd, gd, 'inverse')
+    loss = (z * z).sum() + ld.sum()
+    outs = []
+    for _ in range(6):
+        gp, gg = torch.autograd.grad(loss, [pd, gd], retain_graph=True)
+        outs.append((gp.clone(), gg.clone()))
+    scale_p, scale_g = float(outs[0][0].abs().max()), float(outs[0][1].abs().max())
+    for gp, gg in outs[1:]:
+        assert float((gp - outs[0][0]).abs().max()) < 1e-4 * scale_p
+        assert float((gg - outs[0][1]).abs().max()) < 1e-4 * scale_g

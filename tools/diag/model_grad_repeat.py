@@ -1,0 +1,24 @@
+"""Run-to-run spread of the full-model training gradients (fused path twice, list path once) on the g13 fixture."""
+import sys, json, os, numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from go_with_the_flows_amd import models
+from go_with_the_flows_amd.synth import load_synth_
+D = np.load('tests/golden/g13_full_model.npz')
+cfg = json.load(open('tests/golden/contract_model.json'))['cfg']
+dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+def run(fused):
+    m = models.Flow_Mixture_Model(**cfg); load_synth_(m, 1310); m = m.cuda().train()
+    noise = dev(D['noise_g'])
+    m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+    loss_fn = models.Flow_Mixture_Loss(**cfg)
+    if fused:
+        enc, f = m.forward_fused(dev(D['gcloud']), dev(D['pcloud'])); l = loss_fn.fused(enc, f)[0]
+    else:
+        enc, dec, logits = m(dev(D['gcloud']), dev(D['pcloud'])); l = loss_fn(enc, dec, logits)[0]
+    l.backward()
+    return float(l), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+runs = [run(True), run(True), run(False), run(False)]
+def cmp(a, b, tag):
+    rows = sorted(((float((a[1][n] - b[1][n]).abs().max() / (b[1][n].abs().max() + 1e-3)), n, float(b[1][n].abs().max())) for n in a[1]), reverse=True)[:4]
+    print(tag, 'loss', a[0], b[0]); [print('   %.3e  %s  |g|max %.3e' % r) for r in rows]
+cmp(runs[0], runs[1], 'fused vs fused'); cmp(runs[2], runs[3], 'list vs list'); cmp(runs[0], runs[2], 'fused vs list')
