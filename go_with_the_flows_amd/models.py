@@ -74,15 +74,20 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
     def _pooled_features(self, g_input):
         return self.pc_encoder.forward_max(g_input)          # == torch.max(self.pc_encoder(g_input), dim=2)[0]
 
-    def encode(self, g_input):
+    def encode(self, g_input, defer_prior=False):
         """models.py:111-151: posterior from the cloud (training / autoencoding) or a draw from the learned prior
-        (generating), pushed through the prior flow; lists are ordered base -> data."""
+        (generating), pushed through the prior flow; lists are ordered base -> data.
+        defer_prior=True (training mode): the prior flow is launched on a side stream and its lists are filled in by
+        ``finish_encode(out)`` -- call it after the decoders have been launched (forward_fused does)."""
         B, G = g_input.shape[0], self.g_latent_space_size
         out = {'g_prior_mus': [self.g0_prior_mus.expand(B, G)], 'g_prior_logvars': [self.g0_prior_logvars.expand(B, G)]}
         if self.mode in ('training', 'autoencoding'):
             out['g_posterior_mus'], out['g_posterior_logvars'] = self.g_posterior(self._pooled_features(g_input))
             out['g_posterior_samples'] = (self.reparameterize(out['g_posterior_mus'], out['g_posterior_logvars'])
                                           if self.mode == 'training' else out['g_posterior_mus'])
+            if defer_prior and hasattr(self.g_prior, 'forward_async'):
+                out['_prior_handle'] = self.g_prior.forward_async(out['g_posterior_samples'], mode='inverse')
+                return out
             buf_g = self.g_prior(out['g_posterior_samples'], mode='inverse')
             out['g_prior_samples'] = buf_g[0] + [out['g_posterior_samples']]
         elif self.mode == 'generating':
@@ -93,6 +98,16 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
             raise ValueError(f'unknown util_mode {self.mode!r}')
         out['g_prior_mus'] += buf_g[1]
         out['g_prior_logvars'] += buf_g[2]
+        return out
+
+    def finish_encode(self, out):
+        """Join the deferred prior flow (see encode(defer_prior=True)) and complete the three prior lists."""
+        handle = out.pop('_prior_handle', None)
+        if handle is not None:
+            buf_g = handle.result()
+            out['g_prior_samples'] = buf_g[0] + [out['g_posterior_samples']]
+            out['g_prior_mus'] += buf_g[1]
+            out['g_prior_logvars'] += buf_g[2]
         return out
 
     def _base_gaussian(self, g_sample):
@@ -240,7 +255,7 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
         eval mode and no gradient is needed; per component otherwise)."""
         if self.mode != 'training':
             raise ValueError("forward_fused is the density ('training') pass; use sample_fused for generation")
-        output_encoder = self.encode(g_input)
+        output_encoder = self.encode(g_input, defer_prior=True)     # the prior flow runs beside the decoders (side stream)
         g_sample = output_encoder['g_posterior_samples']
         logits = self.get_weights(g_sample, warmup)
         B, K, P = g_sample.shape[0], self.n_components, self.p_latent_space_size
@@ -250,6 +265,7 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
             mu0.append(m.expand(B, P, 1)[:, :, 0])
             lv0.append(v.expand(B, P, 1)[:, :, 0])
         z, logdet = self.mixture_stack().forward_all(p_input, g_sample, mode='inverse')
+        self.finish_encode(output_encoder)
         return output_encoder, {'z': z, 'logdet': logdet, 'mu0': torch.stack(mu0), 'lv0': torch.stack(lv0), 'logits': logits}
 
     @torch.no_grad()

@@ -1,12 +1,14 @@
 """Global prior flow on the shape latent and the Gaussian losses that consume it.
 
-Host-side mirror of lib/networks/flows.py:163-243 (RealNVPFlow, RealNVPFlowCouple), lib/networks/decoders.py:7-38
+Mirror of lib/networks/flows.py:163-243 (RealNVPFlow, RealNVPFlowCouple), lib/networks/decoders.py:7-38
 (GlobalRNVPDecoder) and lib/networks/losses.py:24-41 (GaussianFlowNLL, GaussianEntropy): same constructors, attribute
 names, ``state_dict`` keys and list-returning forward, so the reference's checkpoints and callers (models.py:137-151)
-work unchanged.  The work is per SHAPE -- B rows of G latents, 14 elementary flows of two (B x G/2)(G/2 x F) GEMM pairs
-("tiny") -- so it is a chain of plain library GEMMs on the HIP device (torch -> rocBLAS), not a
-hand-written kernel; the two shipped warp patterns (even/odd, halves) are applied as strided slices instead of the
-reference's index gathers.
+work unchanged.  The work is per SHAPE -- B rows of G latents, 14 elementary flows of two (B x G/2)(G/2 x F) GEMM pairs.
+``GlobalRNVPDecoder.forward`` on a HIP device runs the WHOLE stack as one launch (csrc/gwtf_prior.hip: forward, and one
+more launch for the backward; eval- and train-mode BatchNorm, every list slot differentiable) instead of the ~100 + ~200
+library launches of the module-by-module evaluation; the per-module ``forward`` of ``RealNVPFlow`` / ``RealNVPFlowCouple``
+(used on their own, on the CPU by the host-logic tests, and for batches beyond 128 shapes) stays a chain of torch ops with
+the two shipped warp patterns applied as strided slices instead of the reference's index gathers.
 """
 from collections import OrderedDict
 
@@ -38,6 +40,7 @@ class RealNVPFlow(nn.Module):
         self.warp_inds = [int(i) for i in warp_inds]
         self.keep_inds = [i for i in range(g_n_features) if i not in set(self.warp_inds)]
         self.register_buffer('eps', torch.from_numpy(np.array([eps], dtype=np.float32)))
+        self._eps_value = float(eps)          # host copy: reading the buffer would synchronise (and break hipGraph capture)
         for X in ('mu', 'logvar'):
             branch = nn.Sequential(OrderedDict([
                 (f'{X}_mlp0', nn.Linear(len(self.keep_inds), n_features, bias=False)),
@@ -50,6 +53,11 @@ class RealNVPFlow(nn.Module):
             setattr(self, f'T_{X}_0', branch)
         self._warp_sl = _as_slice(self.warp_inds, g_n_features)
         self._keep_sl = _as_slice(self.keep_inds, g_n_features)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        if prefix + 'eps' in state_dict:
+            self._eps_value = float(state_dict[prefix + 'eps'].reshape(-1)[0])
 
     def _take(self, g, inds, sl):
         return g[:, sl] if sl is not None else g[:, inds]
@@ -117,7 +125,74 @@ class GlobalRNVPDecoder(nn.Module):
         self.flows = nn.ModuleList([RealNVPFlowCouple(n_features, g_n_features, weight_std=weight_std, pattern=i % 2)
                                     for i in range(n_flows)])
 
+    # ---- fused HIP path ------------------------------------------------------------------------------------------------
+    def _bn_modules(self):
+        return [getattr(nvp, f'T_{X}_0')[1] for couple in self.flows for nvp in (couple.nvp1, couple.nvp2) for X in ('mu', 'logvar')]
+
+    def _raw_arena(self):
+        """Parameters + BatchNorm buffers in the record order of csrc/gwtf_prior.hip (one autograd-aware torch.cat)."""
+        parts = []
+        for couple in self.flows:
+            for nvp in (couple.nvp1, couple.nvp2):
+                for X in ('mu', 'logvar'):
+                    t = getattr(nvp, f'T_{X}_0')
+                    parts += [t[0].weight, t[1].weight, t[1].bias, t[1].running_mean, t[1].running_var, t[3].weight, t[3].bias]
+        return torch.cat([q.reshape(-1) for q in parts])
+
+    def _fused_ok(self, g):
+        return (g.is_cuda and g.dim() == 2 and 2 <= g.shape[1] == self.g_n_features and g.shape[0] <= 128 and
+                2 * self.n_flows <= 64 and all(bn.track_running_stats and bn.momentum is not None for bn in self._bn_modules()))
+
+    def _forward_fused(self, g, mode):
+        if mode not in ('direct', 'inverse'):
+            raise ValueError(f"mode must be 'direct' or 'inverse', got {mode!r}")
+        training = self.training
+        if training and g.shape[0] < 2:
+            raise ValueError('Expected more than 1 value per channel when training (BatchNorm over the batch)')
+        eps = self.flows[0].nvp1._eps_value
+        gs, mus, lvs, stats = _PriorFlowFn.apply(g.contiguous().float(), self._raw_arena(), self.n_flows, self.n_features,
+                                                 eps, mode, training)
+        if training:
+            # running = (1 - m) running + m batch, unbiased batch variance, num_batches_tracked += 1 (nn.BatchNorm1d)
+            B = g.shape[0]
+            mods = self._bn_modules()
+            with torch.no_grad():
+                flat = stats.reshape(len(mods), 2, self.n_features)
+                means, variances = list(flat[:, 0].unbind(0)), list((flat[:, 1] * (B / (B - 1.0))).unbind(0))
+                mom = [float(m.momentum) for m in mods]
+                rms, rvs = [m.running_mean for m in mods], [m.running_var for m in mods]
+                if len(set(mom)) == 1:
+                    torch._foreach_mul_(rms, 1.0 - mom[0]); torch._foreach_add_(rms, means, alpha=mom[0])
+                    torch._foreach_mul_(rvs, 1.0 - mom[0]); torch._foreach_add_(rvs, variances, alpha=mom[0])
+                else:
+                    for m, mu_, va, mo in zip(mods, means, variances, mom):
+                        m.running_mean.mul_(1.0 - mo).add_(mu_, alpha=mo)
+                        m.running_var.mul_(1.0 - mo).add_(va, alpha=mo)
+                torch._foreach_add_([m.num_batches_tracked for m in mods], 1)
+        return list(gs.unbind(0)), list(mus.unbind(0)), list(lvs.unbind(0))
+
+    def forward_async(self, g, mode='direct'):
+        """The fused launch on a SIDE stream: returns a handle whose ``result()`` joins the side stream into the current one
+        and gives the usual (gs, mus, logvars) lists.  The whole prior flow is one workgroup on one compute unit (a latency
+        chain, csrc/gwtf_prior.hip) and its outputs are only needed by the loss, so the caller can run the decoders -- which
+        fill the other 255 compute units -- in between: the prior flow then costs no time on the critical path, forward or
+        backward (autograd runs a node's backward on the stream of its forward).  Capturable: the fork / join pair becomes a
+        branch of the hipGraph.  Falls back to the synchronous evaluation when the fused path does not apply."""
+        if not self._fused_ok(g):
+            return _PriorResult(self.forward(g, mode), None, None)
+        cur = torch.cuda.current_stream(g.device)
+        side = getattr(self, '_side_stream', None)
+        if side is None or side.device != g.device:
+            side = self._side_stream = torch.cuda.Stream(device=g.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            res = self._forward_fused(g, mode)
+        g.record_stream(side)
+        return _PriorResult(res, side, cur)
+
     def forward(self, g, mode='direct'):
+        if self._fused_ok(g):
+            return self._forward_fused(g, mode)
         gs, mus, logvars = [], [], []
         cur = g
         order = self.flows if mode == 'direct' else reversed(self.flows)
@@ -130,6 +205,75 @@ class GlobalRNVPDecoder(nn.Module):
                 gs, mus, logvars = a + gs, b + mus, c + logvars
                 cur = gs[0]
         return gs, mus, logvars
+
+
+class _PriorResult:
+    """Handle of GlobalRNVPDecoder.forward_async."""
+
+    def __init__(self, res, side, origin):
+        self._res, self._side, self._origin = res, side, origin
+
+    def result(self):
+        if self._side is not None:
+            cur = torch.cuda.current_stream(self._side.device)
+            cur.wait_stream(self._side)
+            for lst in self._res:
+                for t in lst:
+                    t.record_stream(cur)
+            self._side = None
+        return self._res
+
+
+class _PriorFlowFn(torch.autograd.Function):
+    """gs, mus, logvars (2 n_flows, B, G) + BatchNorm batch statistics of the whole prior stack: one HIP launch forward,
+    one backward (csrc/gwtf_prior.hip).  gs / logvars slots are differentiable; a gradient through a mus slot raises."""
+
+    @staticmethod
+    def forward(ctx, g, raw, n_flows, F, eps, mode, training):
+        from . import _lib
+        L = _lib.lib()
+        B, G = g.shape
+        n2 = 2 * n_flows
+        raw = raw.contiguous()
+        if raw.numel() != L.gwtf_prior_raw_floats(n_flows, G, F):
+            raise _lib.GwtfError(f'prior raw arena has {raw.numel()} floats, expected {L.gwtf_prior_raw_floats(n_flows, G, F)}')
+        dev = g.device
+        lists = torch.empty(3, n2, B, G, device=dev, dtype=torch.float32)
+        ws = torch.empty(L.gwtf_prior_workspace_floats(B, G, F), device=dev, dtype=torch.float32)
+        stats = torch.zeros(n2, 2, 2, F, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.gwtf_prior_forward(_lib._ptr(g, 'g'), _lib._ptr(raw, 'raw'), lists[0].data_ptr(), lists[1].data_ptr(),
+                                            lists[2].data_ptr(), ws.data_ptr(), stats.data_ptr(), n_flows, B, G, F, float(eps),
+                                            _lib._MODES[mode], int(bool(training)), _lib._stream(g)))
+        ctx.save_for_backward(g, raw, lists)
+        ctx.meta = (n_flows, F, float(eps), mode, bool(training))
+        ctx.mark_non_differentiable(stats)
+        ctx.set_materialize_grads(False)
+        return lists[0], lists[1], lists[2], stats
+
+    @staticmethod
+    def backward(ctx, g_gs, g_mus, g_lvs, _gst):
+        from . import _lib
+        if g_mus is not None:
+            raise NotImplementedError('a gradient reached a mus[j] list entry of the prior flow: the HIP backward differentiates '
+                                      'through gs[j] and logvars[j] only (no reference consumer uses mus[j], losses.py:24-33)')
+        g, raw, lists = ctx.saved_tensors
+        n_flows, F, eps, mode, training = ctx.meta
+        L = _lib.lib()
+        B, G = g.shape
+        dev = g.device
+        g_gs = g_gs.contiguous().float() if g_gs is not None else None
+        g_lvs = g_lvs.contiguous().float() if g_lvs is not None else None
+        ws = torch.empty(L.gwtf_prior_workspace_floats(B, G, F), device=dev, dtype=torch.float32)
+        g_raw = torch.zeros_like(raw)
+        g_g = torch.empty_like(g)
+        with torch.cuda.device(dev):
+            _lib.check(L.gwtf_prior_backward(g.data_ptr(), raw.data_ptr(), lists[0].data_ptr(), lists[1].data_ptr(),
+                                             lists[2].data_ptr(), g_gs.data_ptr() if g_gs is not None else None,
+                                             g_lvs.data_ptr() if g_lvs is not None else None, ws.data_ptr(), g_raw.data_ptr(),
+                                             g_g.data_ptr(), n_flows, B, G, F, eps, _lib._MODES[mode], int(training),
+                                             _lib._stream(g)))
+        return g_g, g_raw, None, None, None, None, None
 
 
 class GaussianFlowNLL(nn.Module):

@@ -324,6 +324,26 @@ int gwtf_encoder_pack(const float* raw, float* packed, const int* widths, int n_
 int gwtf_encoder_forward(const float* x, const float* packed, float* features, float* pooled, int B, int N,
                          const int* widths, int n_widths, void* stream);
 
+/* Global prior flow on the shape latent: the whole GlobalRNVPDecoder (lib/networks/decoders.py:7-38; RealNVPFlowCouple /
+ * RealNVPFlow, flows.py:163-243) as ONE launch per direction -- forward (the lists the reference returns) and backward
+ * (every parameter, the input, gradients entering through any gs[j] / logvars[j] slot), eval- or train-mode BatchNorm.
+ *   raw       gwtf_prior_raw_floats(n_flows, G, F) floats: per elementary flow j (2 per couple), branch mu then logvar:
+ *             mlp0.weight[F][Gk] | bn.weight[F] | bn.bias[F] | bn.running_mean[F] | bn.running_var[F] | mlp1.weight[Gw][F] |
+ *             mlp1.bias[Gw]     (record j starts at gwtf_prior_raw_offset(n_flows, G, F, j))
+ *   g         [B][G], B <= 128;   gs, mus, logvars  [2 n_flows][B][G] direct-ordered lists (decoders.py:24-36)
+ *   workspace gwtf_prior_workspace_floats(B, G, F) floats of scratch
+ *   bn_stats  [2 n_flows][2 branches][2][F] = batch {mean, biased var} of every BatchNorm (train; may be NULL)
+ *   backward: g_gs / g_logvars [2 n_flows][B][G] = dL/d gs[j], dL/d logvars[j] (either may be NULL); g_raw (zero on entry)
+ *             receives the parameter gradients in the raw layout; g_g [B][G] = dL/d g. */
+size_t gwtf_prior_raw_floats(int n_flows, int G, int F);
+size_t gwtf_prior_raw_offset(int n_flows, int G, int F, int j);
+size_t gwtf_prior_workspace_floats(int B, int G, int F);
+int gwtf_prior_forward(const float* g, const float* raw, float* gs, float* mus, float* logvars, float* workspace,
+                       float* bn_stats, int n_flows, int B, int G, int F, float eps, int mode, int training, void* stream);
+int gwtf_prior_backward(const float* g, const float* raw, const float* gs, const float* mus, const float* logvars,
+                        const float* g_gs, const float* g_logvars, float* workspace, float* g_raw, float* g_g,
+                        int n_flows, int B, int G, int F, float eps, int mode, int training, void* stream);
+
 /* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
  * (16, 32 or 64 in the low 16 bits; anything else restores the size-based default).  Bit 30 set: also force the generic
  * coupling body instead of the software-pipelined one (the two are bit-identical; tests compare them).
