@@ -389,8 +389,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
             }
           }
       __syncthreads();
-      if (wave < MB) {
-        const int ni = wave;                                  // this wave's column of output tiles: h features 16 ni ..
+      for (int ni = wave; ni < MB; ni += 4) {                // this wave's column(s) of output tiles: h features 16 ni .. (f > 64: two)
         const f32x4 sp = sd0n[16 * ni + i16];                 // the lane's h feature: {w0a, w0b, c0, -}
         f32x4 dw[MB];
 #pragma unroll
@@ -535,7 +534,7 @@ extern "C" size_t gwtf_packed_b_coupling_floats(int f) {
 
 extern "C" int gwtf_pack_folded(const float* W1p, const float* W0f, const float* c0f, float* packed_w, float* packed_b,
                                 int C, int f, void* stream) {
-  if (!W1p || !W0f || !c0f || !packed_w || !packed_b || C <= 0 || f <= 0 || f > GWTF_MAX_FP) return GWTF_E_BADARG;
+  if (!W1p || !W0f || !c0f || !packed_w || !packed_b || C <= 0 || f <= 0 || f > GWTF_MAX_FP_TRAIN) return GWTF_E_BADARG;
   const int FP = gwtf_padded_width(f);
   hipLaunchKernelGGL(pack_folded_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, W1p, W0f, c0f, packed_w, packed_b, C,
                      f, FP);
@@ -567,7 +566,9 @@ static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const
     case 2: return stats ? launch_bwd<2, true>(nb, GWTF_A) : launch_bwd<2, false>(nb, GWTF_A);
     case 3: return stats ? launch_bwd<3, true>(nb, GWTF_A) : launch_bwd<3, false>(nb, GWTF_A);
     case 4: return stats ? launch_bwd<4, true>(nb, GWTF_A) : launch_bwd<4, false>(nb, GWTF_A);
-    default: return GWTF_E_BADARG;
+    case 5: return stats ? launch_bwd<5, true>(nb, GWTF_A) : launch_bwd<5, false>(nb, GWTF_A);
+    case 6: return stats ? launch_bwd<6, true>(nb, GWTF_A) : launch_bwd<6, false>(nb, GWTF_A);
+    default: return GWTF_E_BADARG;       // f > 96: the backward working set (forward + backward records) exceeds the LDS
   }
 #undef GWTF_A
 }
@@ -586,7 +587,7 @@ extern "C" int gwtf_coupling_backward_lists(const float* x_in, const float* g_ou
                                             float* g_bias, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
                                             void* stream) {
   if (!x_in || !g_out || !g_ld || !packed_w_c || !packed_b_c || !film || !g_in || !dw1_ws || !g_film || !g_sd0 ||
-      !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP || pattern0 < 0 || pattern0 > 5 ||
+      !g_bias || B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP_TRAIN || pattern0 < 0 || pattern0 > 5 ||
       (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE))
     return GWTF_E_BADARG;
   GwtfKS ks = {};
@@ -615,7 +616,7 @@ extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, cons
                                    const float* packed_b_c, float* g_in, float* dw1_ws, float* g_sd0, int B, int N, int f,
                                    int pattern, void* stream) {
   if (!x_in || !g_stats || !packed_w_c || !packed_b_c || !g_in || !dw1_ws || !g_sd0 || B <= 0 || N <= 0 || f <= 0 ||
-      f > GWTF_MAX_FP || pattern < 0 || pattern > 5)
+      f > GWTF_MAX_FP_TRAIN || pattern < 0 || pattern > 5)
     return GWTF_E_BADARG;
   GwtfKS ks = {};
   ks.Cper = ks.Ctot = 1;
@@ -690,7 +691,7 @@ extern "C" size_t gwtf_dw1_reduce_scratch_floats(int f) {
 // K components: component k's workspace at workspace + k * ws_sk, its gradient blocks at dW1 + k * out_sk
 int gwtf_internal_dw1_reduce_k(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N, int K,
                                size_t ws_sk, size_t out_sk, void* stream) {
-  if (!workspace || !dW1 || passes < 1 || f <= 0 || f > GWTF_MAX_FP || B <= 0 || N <= 0 || K <= 0 || branch_stride < (size_t)f * f)
+  if (!workspace || !dW1 || passes < 1 || f <= 0 || f > GWTF_MAX_FP_TRAIN || B <= 0 || N <= 0 || K <= 0 || branch_stride < (size_t)f * f)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int FP = gwtf_padded_width(f), rec = 2 * FP * FP, n_partials = passes * bwd_grid(B, N);

@@ -197,7 +197,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // 3 workgroups per CU), 64 takes two rounds but 4-5 workgroups fit a CU -- chosen when the grid exceeds one round of the
 // former (the K x C couplings of a mixture: 19.8 -> 17.1 us on the airplane grid of 1056 workgroups).
 template <int MB, int kGCH>
-__global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict__ g, const float* __restrict__ pf,
+__global__ __launch_bounds__(MB > 4 ? 512 : 256) void film_eval_kernel(const float* __restrict__ g, const float* __restrict__ pf,
                                                         float* __restrict__ out, int B, int G, int C, int f, float eps) {
   constexpr int FP = 16 * MB;
   __shared__ __align__(16) float hb[2][16][FP + 4];   // [head][shape][feature]
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void film_eval_kernel(const float* __restrict_
 extern "C" int gwtf_film_forward(const float* g, const float* packed_film, float* film_out, float* bn_stats_out, int B,
                                  int G, int C, int f, float eps, int training, void* stream) {
   if (B <= 0 || G <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || !g || !packed_film || !film_out) return GWTF_E_BADARG;
-  if (training && B > kMaxTrainB) return GWTF_E_BADARG;
+  if (training && (B > kMaxTrainB || f > 64)) return GWTF_E_BADARG;     // train kernel: lane = feature (f <= 64); wider stacks use the torch FiLM graph
   const int FP = gwtf_padded_width(f);
   const int hrows = training ? ((B + kBT - 1) / kBT) * kBT : kBT;
   const size_t smem = ((size_t)kBT * G + (size_t)hrows * 2 * FP + 4 * (size_t)FP) * sizeof(float);
@@ -329,14 +329,19 @@ extern "C" int gwtf_film_forward(const float* g, const float* packed_film, float
   } else {
     const dim3 grid(C, 2, (B + kBTe - 1) / kBTe);
     const bool many = (long)grid.x * grid.y * grid.z > 768;   // more than one round of 256 CUs x 3 resident workgroups
+    // one wavefront per block of 16 output features: 4 wavefronts up to f = 64, 8 beyond (f <= 128)
 #define GWTF_FILM_EVAL(MB_)                                                                                                  \
-  if (many) hipLaunchKernelGGL((film_eval_kernel<MB_, 64>), grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps); \
-  else hipLaunchKernelGGL((film_eval_kernel<MB_, 128>), grid, dim3(256), 0, st, g, packed_film, film_out, B, G, C, f, eps)
+  if (many) hipLaunchKernelGGL((film_eval_kernel<MB_, 64>), grid, dim3(MB_ > 4 ? 512 : 256), 0, st, g, packed_film, film_out, B, G, C, f, eps); \
+  else hipLaunchKernelGGL((film_eval_kernel<MB_, 128>), grid, dim3(MB_ > 4 ? 512 : 256), 0, st, g, packed_film, film_out, B, G, C, f, eps)
     switch (FP / 16) {
       case 1: GWTF_FILM_EVAL(1); break;
       case 2: GWTF_FILM_EVAL(2); break;
       case 3: GWTF_FILM_EVAL(3); break;
-      default: GWTF_FILM_EVAL(4); break;
+      case 4: GWTF_FILM_EVAL(4); break;
+      case 5: GWTF_FILM_EVAL(5); break;
+      case 6: GWTF_FILM_EVAL(6); break;
+      case 7: GWTF_FILM_EVAL(7); break;
+      default: GWTF_FILM_EVAL(8); break;
     }
 #undef GWTF_FILM_EVAL
   }

@@ -22,7 +22,8 @@
 #endif
 
 #define GWTF_BN_EPS 1e-5f
-#define GWTF_MAX_FP 64
+#define GWTF_MAX_FP 128        // widest padded feature width of the forward kernels (f_n_features <= 128)
+#define GWTF_MAX_FP_TRAIN 96   // ... of the train-mode / backward kernels (their LDS working set exceeds 160 KiB beyond)
 #define GWTF_MAX_COMPONENTS 64
 #define GWTF_STAT_REPLICAS 64   // copies of every train-mode statistic accumulator (atomic contention spreading)
 

@@ -446,7 +446,10 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
                                                     int pattern0, float eps, int kk_steps, const Jobs jobs,
                                                     size_t p_stride_k, size_t out_stride_k, const Extras ex) {
   using K = Cfg<MB>;
-  __shared__ __align__(16) float lds[2][K::LAYER];
+  // double buffer while two layers fit the 160 KiB of LDS (f <= 96); wider stacks (f = 97..128: 121 / 138 KiB per layer) stage
+  // a coupling, compute, and only then stage the next (the weight DMA is exposed: the widths no shipped config uses)
+  constexpr int NBUF = 2 * K::LAYER * 4 <= 160 * 1024 - 512 ? 2 : 1;
+  __shared__ __align__(16) float lds[NBUF][K::LAYER];
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
@@ -513,10 +516,10 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
 
   for (int step = 0; step < n_steps; ++step) {
     const int c = MODE == GWTF_MODE_INVERSE ? c_start - step : c_start + step;
-    const int buf = step & 1;
+    const int buf = NBUF == 2 ? step & 1 : 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (step + 1 < n_steps) stage(buf ^ 1, MODE == GWTF_MODE_INVERSE ? c - 1 : c + 1);
+    if (NBUF == 2 && step + 1 < n_steps) stage(buf ^ 1, MODE == GWTF_MODE_INVERSE ? c - 1 : c + 1);
 
     const int pat = (pattern0 + c) % 6;
     int k0, k1, w0, w1;
@@ -552,6 +555,10 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
       for (int d = 0; d < 3; ++d) x[nb][d] = __shfl(xo[d], 16 * nb + i16);
+    if (NBUF == 1 && step + 1 < n_steps) {
+      __syncthreads();                       // every wave is done with this coupling's weights
+      stage(0, MODE == GWTF_MODE_INVERSE ? c - 1 : c + 1);
+    }
   }
 
   {
@@ -668,10 +675,15 @@ template <int MB>
 int launch_nb(int nb, const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps,
               float* mus, float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps,
               const int* segs, int K, size_t p_stride_k, size_t out_stride_k, const Extras& ex, hipStream_t st) {
+  if constexpr (MB > 4) {      // f > 64: one workgroup per compute unit anyway (LDS); 16 or 32 points per wave keep the accumulators in registers
+    if (nb == 1) return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
+    return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
+  } else {
   switch (nb) {
     case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
     case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
     default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
+  }
   }
 }
 
@@ -707,6 +719,7 @@ static int stack_dispatch(const float* p, const float* packed_w, const float* fi
   // points per wave: the largest tile that still gives each of the 1024 SIMDs two waves
   int nb = g_force_nb;
   if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
+  if (f > 64 && nb > 2) nb = 2;
   const int kk_steps = (f + 3) / 4;
 #define GWTF_ARGS nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, segments, K, p_stride_k, out_stride_k, ex, st
   switch (gwtf_padded_width(f) / 16) {
@@ -714,6 +727,10 @@ static int stack_dispatch(const float* p, const float* packed_w, const float* fi
     case 2: return launch_nb<2>(GWTF_ARGS);
     case 3: return launch_nb<3>(GWTF_ARGS);
     case 4: return launch_nb<4>(GWTF_ARGS);
+    case 5: return launch_nb<5>(GWTF_ARGS);
+    case 6: return launch_nb<6>(GWTF_ARGS);
+    case 7: return launch_nb<7>(GWTF_ARGS);
+    case 8: return launch_nb<8>(GWTF_ARGS);
     default: return GWTF_E_BADARG;
   }
 #undef GWTF_ARGS
@@ -776,11 +793,12 @@ int launch_stats(int nb, const float* p, const float* pw_c, float* ystats, int B
 // statistics pass of one coupling of K stacks (component k: p + k*p_sk, packed_w_c + k*pw_sk, ystats + k*ys_sk)
 int gwtf_internal_stats_k(const float* p, const float* packed_w_c, float* ystats, int K, int B, int N, int f, int pattern,
                           size_t p_sk, size_t pw_sk, size_t ys_sk, void* stream) {
-  if (B <= 0 || N <= 0 || K <= 0 || f <= 0 || f > GWTF_MAX_FP || pattern < 0 || pattern > 5 || !p || !packed_w_c || !ystats)
+  if (B <= 0 || N <= 0 || K <= 0 || f <= 0 || f > GWTF_MAX_FP_TRAIN || pattern < 0 || pattern > 5 || !p || !packed_w_c || !ystats)
     return GWTF_E_BADARG;
   const long pts = (long)B * N * K;
   int nb = g_force_nb;
   if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
+  if (f > 64 && nb > 2) nb = 2;
   const int kk_steps = (f + 3) / 4;
   hipStream_t st = (hipStream_t)stream;
   switch (gwtf_padded_width(f) / 16) {
@@ -788,6 +806,8 @@ int gwtf_internal_stats_k(const float* p, const float* packed_w_c, float* ystats
     case 2: return launch_stats<2>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
     case 3: return launch_stats<3>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
     case 4: return launch_stats<4>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
+    case 5: return launch_stats<5>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
+    case 6: return launch_stats<6>(nb, p, packed_w_c, ystats, B, N, pattern, kk_steps, K, p_sk, pw_sk, ys_sk, st);
     default: return GWTF_E_BADARG;
   }
 }

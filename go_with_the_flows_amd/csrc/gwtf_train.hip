@@ -173,7 +173,7 @@ GwtfKS single_ks(int C) {
 
 extern "C" int gwtf_train_fold0(const float* raw_c, const float* moments, double n_total, int pattern, float* packed_w_c,
                                 float* packed_b_c, float* bn_batch_c, int f, int G, void* stream) {
-  if (!raw_c || !moments || !packed_w_c || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP || G <= 0 || pattern < 0 ||
+  if (!raw_c || !moments || !packed_w_c || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP_TRAIN || G <= 0 || pattern < 0 ||
       pattern > 5 || n_total < 1.0)
     return GWTF_E_BADARG;
   hipLaunchKernelGGL(fold0_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, moments, n_total, pattern,
@@ -183,7 +183,7 @@ extern "C" int gwtf_train_fold0(const float* raw_c, const float* moments, double
 
 extern "C" int gwtf_train_fold1(const float* raw_c, const float* ystats, double n_total, const float* film_raw,
                                 float* film_rec, float* bn_batch_c, int c, int B, int C, int f, int G, void* stream) {
-  if (!raw_c || !ystats || !film_raw || !film_rec || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP || G <= 0 || B <= 0 ||
+  if (!raw_c || !ystats || !film_raw || !film_rec || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP_TRAIN || G <= 0 || B <= 0 ||
       c < 0 || c >= C || n_total < 1.0)
     return GWTF_E_BADARG;
   hipLaunchKernelGGL(fold1_kernel, dim3(B), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, ystats, n_total, film_raw,
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
 }  // namespace
 
 extern "C" int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, int G, void* stream) {
-  if (!raw || !packed_b || C <= 0 || f <= 0 || f > GWTF_MAX_FP || G <= 0) return GWTF_E_BADARG;
+  if (!raw || !packed_b || C <= 0 || f <= 0 || f > GWTF_MAX_FP_TRAIN || G <= 0) return GWTF_E_BADARG;
   hipLaunchKernelGGL(pack_w1t_kernel, dim3(512), dim3(256), 0, (hipStream_t)stream, raw, packed_b, C, f, G,
                      gwtf_padded_width(f));
   return (int)hipGetLastError();
@@ -564,7 +564,7 @@ GwtfKS strides_of(const GwtfTrainCtx* t, const Dims& d, bool first_level) {
   return ks;
 }
 bool ctx_ok(const GwtfTrainCtx* t, bool backward) {
-  if (!t || t->K <= 0 || t->K > GWTF_MAX_COMPONENTS || t->B <= 0 || t->N <= 0 || t->C <= 0 || t->f <= 0 || t->f > GWTF_MAX_FP ||
+  if (!t || t->K <= 0 || t->K > GWTF_MAX_COMPONENTS || t->B <= 0 || t->N <= 0 || t->C <= 0 || t->f <= 0 || t->f > GWTF_MAX_FP_TRAIN ||
       t->G <= 0 || t->pattern0 < 0 || t->pattern0 > 5 || t->n_total < 1.0)
     return false;
   if (t->mode != GWTF_MODE_DIRECT && t->mode != GWTF_MODE_INVERSE) return false;

@@ -211,8 +211,9 @@ class StackEngine:
         self.pattern0 = pats[0]
         if any(pt != (self.pattern0 + i) % 6 for i, pt in enumerate(pats)):
             raise ValueError(f'couplings do not follow the cyclic warp pattern: {pats}')
-        if self.f > 64:
-            raise NotImplementedError(f'f_n_features={self.f} > 64 is not supported by the gfx950 kernels yet')
+        if self.f > 128:
+            raise NotImplementedError(f'f_n_features={self.f} > 128 is not supported by the gfx950 kernels '
+                                      '(reference configs use <= 64; the forward kernels reach 128, train / backward 96)')
         self._tracked, self._tracked_stamp = [], None
         self._srcs, self._src_stamp, self._zeros = None, None, None
         self._cache_key = None
@@ -292,6 +293,9 @@ class StackEngine:
             return p.new_zeros(B, 3, 0, dtype=torch.float32), p.new_zeros(B, 3, 0, dtype=torch.float32), lists
         needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or
                                                   any(t.requires_grad for t in self._tracked or self._collect()))
+        if (needs_grad or c0.training) and self.f > 96:
+            raise NotImplementedError(f'f_n_features={self.f}: train-mode BatchNorm and the backward pass are built for widths up to '
+                                      '96 (their LDS working set exceeds 160 KiB beyond); eval-mode forward works up to 128')
         if needs_grad and c0.training:
             import torch.distributed as dist
             multi = _sharded()
@@ -318,6 +322,13 @@ class StackEngine:
             return out, logdet, lists
         pc, gc = p.contiguous().float(), g.contiguous().float()
         eps = c0._eps_value
+        if c0.training and self.f > 64:
+            # the per-coupling train kernels of this path keep a feature per lane (f <= 64): wider stacks take the fused pipeline
+            from .autograd import train_density_forward_fast
+            with torch.no_grad():
+                out, logdet, lists, bn_batch = train_density_forward_fast(self, pc, gc, mode, distributed=_sharded())
+                self._update_running_stats(bn_batch)
+            return out, logdet, torch.stack(lists) if want_lists else None
         if c0.training:
             out, logdet, lists = self._run_train(pc, gc, mode, want_lists)
         else:

@@ -549,6 +549,11 @@ CASES = {
     'g15_airplane': lambda: decoder_case('g15_depth_11x37x128', 11, 37, 128, 2, 256, 1500, full_lists=False, train_too=False),
     'g15_ae': lambda: decoder_case('g15_depth_11x33x512', 11, 33, 512, 2, 128, 1510, full_lists=False, train_too=False),
     'g15_k16': lambda: decoder_case('g15_depth_6x19x128', 6, 19, 128, 2, 256, 1520, full_lists=False, train_too=False),
+    # widths beyond 64 (the reference accepts any f_n_features, flows.py:11-16): 96 = train / backward limit, 128 = forward limit, 80
+    'g16_w80': lambda: decoder_case('g16_width80', 1, 80, 32, 3, 96, 1600, full_lists=False, train_too=True),
+    'g16_w96': lambda: decoder_case('g16_width96', 2, 96, 64, 3, 80, 1610, full_lists=False, train_too=True),
+    'g16_w128': lambda: decoder_case('g16_width128', 1, 128, 64, 2, 80, 1620, full_lists=False, train_too=False),
+    'g16_w100': lambda: decoder_case('g16_width100', 1, 100, 32, 2, 70, 1630, full_lists=False, train_too=False),
 }
 
 if __name__ == '__main__':

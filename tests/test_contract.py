@@ -84,7 +84,7 @@ def test_no_cpu_fallback_and_bad_arguments():
     with pytest.raises(ValueError):
         d.engine().run(torch.zeros(2, 3, 5), torch.zeros(2, 16), 'sideways', False)
     with pytest.raises(NotImplementedError):
-        gw.LocalCondRNVPDecoder(1, 65, 16).engine()
+        gw.LocalCondRNVPDecoder(1, 129, 16).engine()
     # bad arguments are rejected by the library itself before anything is launched
     L = _lib.lib()
     assert L.gwtf_stack_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 8, 0, 1e-6, 1, None) == 10001

@@ -45,7 +45,8 @@ def test_g2_triple_ordering(mode, pattern):
     assert maxabs(np.stack(lvs), G2[f'lvs_{pattern}_{mode}']) < TIGHT
 
 
-DECODER_CASES = ['g3_decoder_4x64x128', 'g3s_decoder_lists', 'g4_width37', 'g4_width33', 'g4_width19']
+DECODER_CASES = ['g3_decoder_4x64x128', 'g3s_decoder_lists', 'g4_width37', 'g4_width33', 'g4_width19',
+                 'g16_width80', 'g16_width96', 'g16_width100', 'g16_width128']
 
 
 @pytest.mark.parametrize('name', DECODER_CASES)
