@@ -8,6 +8,8 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $OUT/pmc2 -o ts -- python3 tools/diag/trainstep_kernels.py > $OUT/pmc2.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc3 -o ts -- python3 tools/diag/trainstep_kernels.py > $OUT/pmc3.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc4 -o ts -- python3 tools/diag/trainstep_kernels.py > $OUT/pmc4.log 2>&1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/full -o full -- python3 tools/bench_train.py --steps 5 > $OUT/full.log 2>&1
+python3 tools/bench_train.py --graph --steps 10 > $OUT/full_graph.log 2>&1
 python3 - > $OUT/summary.txt 2>&1 <<PY
 import csv, glob, collections
 out = "$OUT"
@@ -18,6 +20,14 @@ print("===== train step, one 33-coupling component (f=37), 64 x 2048 points, eag
 print(f"kernel time per step (start-up uploads excluded): {sum(float(r['TotalDurationNs']) for r in rows)/7/1e6:.2f} ms, kernels per step: {sum(int(r['Calls']) for r in rows)/7:.0f}")
 for r in rows[:16]:
     print(f"  {r['Name'][:90]:90s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
+print("===== whole airplane train step: K=4 x 33 couplings f=37, encoder, prior flow, mixture NLL, backward, fused AMSGrad (tools/bench_train.py) =====")
+print("  " + "\n  ".join(l for l in open(f"{out}/full_graph.log").read().splitlines() if "ms/step" in l))
+ff = glob.glob(f"{out}/full/*kernel_stats.csv")
+if ff:
+    fr = [r for r in csv.DictReader(open(ff[0])) if 'copyBuffer' not in r['Name'] and 'FillFunctor' not in r['Name']]
+    print(f"  kernel time per eager step (start-up uploads and first-step optimiser state fills excluded): {sum(float(r['TotalDurationNs']) for r in fr)/7/1e6:.2f} ms, kernels per step: {sum(int(r['Calls']) for r in fr)/7:.0f}")
+    for r in fr[:14]:
+        print(f"  {r['Name'][:90]:90s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
 agg = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
 for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for fn in glob.glob(f"{out}/{d}/*counter_collection.csv"):
@@ -39,3 +49,5 @@ for key in agg:
     print(f"   HBM read/dispatch = 2*FETCH_SIZE*1024 = {2*g('FETCH_SIZE')*1024:.3e} B, write = WRITE_SIZE*1024 = {g('WRITE_SIZE')*1024:.3e} B")
 PY
 cat $OUT/summary.txt
+# keep what the summaries cite, drop the bulky raw traces (gpurun merges at most 64 MiB back)
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*agent_info.csv" -delete
