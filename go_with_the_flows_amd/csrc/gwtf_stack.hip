@@ -453,11 +453,21 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
+  // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one L2), so in launch
+  // order every XCD's 4 MiB L2 sees EVERY component's 0.9 MB of weights and every shape's FiLM records: 112 MB of L2 misses
+  // per airplane launch against 1.6 MB of input (profiles/r06).  The bijective remap below (cdna_hip_programming.md T1)
+  // gives XCD x the contiguous slice [x G/8, (x+1) G/8) of the tile list -- one component (K = 4: two XCDs each) and one
+  // eighth of the shapes per XCD.  Speed only: nothing depends on the placement.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, xq = nwg >> 3, xr = nwg & 7, xcd = bid & 7;
+    bid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+  }
   int comp = 0;
-  while (comp + 1 < jobs.K && (int)blockIdx.x >= jobs.tiles_cum[comp + 1]) ++comp;
+  while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
   const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
   const int tiles_per_shape = (n_end - n_begin + 64 * NB - 1) / (64 * NB);
-  const int local = blockIdx.x - jobs.tiles_cum[comp];
+  const int local = bid - jobs.tiles_cum[comp];
   const int b = local / tiles_per_shape;
   const int tile = local - b * tiles_per_shape;
   const int n_wave0 = n_begin + (tile * 4 + wave) * 16 * NB;
