@@ -251,27 +251,23 @@ def mixture_nll(z, logdet, mu0, lv0, logits, want_point_lse=False):
     return (nll, plse) if want_point_lse else nll
 
 
-def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum=None, g_all=None, row0=0):
-    """Train-mode (batch-statistic BatchNorm) forward of a coupling stack: fold0 -> stats -> fold1 -> apply per
-    coupling (csrc/gwtf_train.hip).  ``group_sum`` (optional callable) sums small statistic tensors in place over
-    the ranks of a data-parallel group (SyncBatchNorm semantics); ``g_all``/``row0``: the latents of ALL ranks and
-    this rank's first row, so the per-shape FiLM BatchNorm sees the global batch.
+def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists):
+    """Train-mode (batch-statistic BatchNorm) forward of one coupling stack on one rank, entirely in HIP: the FiLM heads with
+    batch statistics over the B latent rows (gwtf_film_forward, training=1), then fold0 -> stats -> fold1 -> apply per
+    coupling from ONE C call (csrc/gwtf_train.hip).  Data-parallel runs take autograd.train_density_forward_multi instead.
     Returns out, logdet, lists, bn_batch (C,2,4,2,f) = {batch mean, unbiased batch var} of the 8 BatchNorms per
     coupling (kind 0 sd0_bn, 1 sd1_bn, 2 film_w0_bn, 3 film_b0_bn; branch 0 logvar, 1 mu)."""
     L = lib()
     B, _, N = p.shape
     dev = p.device
     FP = L.gwtf_padded_width(f)
-    R, PW, FS = L.gwtf_raw_coupling_floats(f, G), L.gwtf_packed_w_coupling_floats(f), L.gwtf_film_out_floats(f)
+    FS = L.gwtf_film_out_floats(f)
     st = _stream(p)
-    gfull = g if g_all is None else g_all
-    Bg = gfull.shape[0]
-    if Bg < 2:
+    if B < 2:
         raise ValueError('train-mode BatchNorm needs more than 1 shape per batch (torch raises the same)')
     with torch.cuda.device(dev):
         pw, pf = pack_weights(raw, C, f, G, True, pattern0)
-        film_all, fstats = film_forward(gfull, pf, C, f, eps, True, want_stats=True)
-        film_raw = film_all[row0:row0 + B].contiguous()
+        film_raw, fstats = film_forward(g, pf, C, f, eps, True, want_stats=True)
         # a non-finite parameter anywhere in a branch record -> NaN FiLM scale -> NaN outputs (the kernels' v_max ReLU alone
         # would turn e.g. a NaN sd0 weight into a zero activation; reference training.py:43-46 aborts on a NaN loss)
         film_raw[:, :, :, 0] += (raw.view(C, 2, -1).sum(-1) * 0.0).view(1, C, 2, 1)
@@ -280,45 +276,15 @@ def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists, group_sum
         bn_batch = torch.zeros(C, 2, 4, 2, f, device=dev, dtype=torch.float32)
         film_rec = torch.empty(B, C, FS, device=dev, dtype=torch.float32)
         xbuf = torch.empty(2, B, 3, N, device=dev, dtype=torch.float32)
-        bufs = [xbuf[0], xbuf[1]]
         logdet = torch.empty_like(p)
         lists = torch.empty(3, C, B, 3, N, device=dev, dtype=torch.float32) if want_lists else None
         lp = [lists[i].data_ptr() for i in range(3)] if want_lists else [None, None, None]
-        n_total = float(B) * N
-        if group_sum is not None:
-            nt = torch.tensor([n_total], device=dev, dtype=torch.float64)
-            group_sum(nt)
-            n_total = float(nt.item())
-        order = range(C) if mode == 'direct' else range(C - 1, -1, -1)
-        cur = p
-        if group_sum is None:
-            # single rank: the whole pipeline is enqueued by one C call
-            check(L.gwtf_train_forward(_ptr(p, 'p'), _ptr(raw, 'raw'), pw.data_ptr(), None, film_raw.data_ptr(), mom.data_ptr(),
-                                       ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(), xbuf.data_ptr(),
-                                       logdet.data_ptr(), lp[0], lp[1], lp[2], B, N, C, f, G, pattern0, float(eps),
-                                       _MODES[mode], st))
-            cur, order = bufs[(C - 1) & 1], ()
-        else:
-            check(L.gwtf_train_moments(_ptr(p, 'p'), mom[0].data_ptr(), B, N, st))
-        for step, c in enumerate(order):
-            pat = (pattern0 + c) % 6
-            if group_sum is not None:
-                group_sum(mom[step])
-            raw_c, pw_c = raw[c * R:(c + 1) * R], pw[c * PW:(c + 1) * PW]
-            check(L.gwtf_train_fold0(raw_c.data_ptr(), mom[step].data_ptr(), n_total, pat, pw_c.data_ptr(), None,
-                                     bn_batch[c].data_ptr(), f, G, st))
-            check(L.gwtf_train_stats(cur.data_ptr(), pw_c.data_ptr(), ystats[c].data_ptr(), B, N, f, pat, st))
-            if group_sum is not None:
-                group_sum(ystats[c])
-            check(L.gwtf_train_fold1(raw_c.data_ptr(), ystats[c].data_ptr(), n_total, film_raw.data_ptr(),
-                                     film_rec.data_ptr(), bn_batch[c].data_ptr(), c, B, C, f, G, st))
-            nxt = bufs[step & 1]
-            check(L.gwtf_train_apply(cur.data_ptr(), pw.data_ptr(), film_rec.data_ptr(), nxt.data_ptr(),
-                                     logdet.data_ptr() if step > 0 else None, logdet.data_ptr(), lp[0], lp[1], lp[2],
-                                     mom[step + 1].data_ptr() if step + 1 < C else None, c, B, N, C, f, pattern0,
-                                     float(eps), _MODES[mode], st))
-            cur = nxt
+        check(L.gwtf_train_forward(_ptr(p, 'p'), _ptr(raw, 'raw'), pw.data_ptr(), None, film_raw.data_ptr(), mom.data_ptr(),
+                                   ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(), xbuf.data_ptr(),
+                                   logdet.data_ptr(), lp[0], lp[1], lp[2], B, N, C, f, G, pattern0, float(eps),
+                                   _MODES[mode], st))
+        out = xbuf[(C - 1) & 1]
         # per-shape FiLM BatchNorms: biased batch var -> unbiased
         bn_batch[:, :, 2:4, 0, :] = fstats[:, :, :, 0, :]
-        bn_batch[:, :, 2:4, 1, :] = fstats[:, :, :, 1, :] * (Bg / (Bg - 1.0))
-    return cur, logdet, lists, bn_batch
+        bn_batch[:, :, 2:4, 1, :] = fstats[:, :, :, 1, :] * (B / (B - 1.0))
+    return out, logdet, lists, bn_batch

@@ -8,8 +8,9 @@ module parameters and the latent g to the quantities the kernels consume (BatchN
 per-shape {c, u}), so autograd carries the kernels' gradients to every reference parameter and to g.
 
   * eval BatchNorm (running statistics):  StackDensityFn                      -- one fused forward, one backward launch per coupling
-  * train BatchNorm, one rank:            TrainStackFn                        -- gwtf_train_forward / gwtf_train_backward
-  * train BatchNorm, several ranks:       MomentsFn / StatsFn / ApplyFn chain -- statistics all-reduced in both directions
+  * train BatchNorm, any number of ranks: TrainMixtureFn                      -- the K-batched, phase-split C pipeline (gwtf_mtrain_*):
+                                          all K mixture components per launch, ONE packed statistic all-reduce per phase
+  * cross-check of the above:             MomentsFn / StatsFn / ApplyFn chain -- one autograd node per coupling (force_autograd_chain)
 
 Reference semantics: loss.backward() through LocalCondRNVPDecoder.forward, training.py:54.
 """

@@ -375,24 +375,20 @@ class StackEngine:
             torch._foreach_add_(counters, 1)
 
     def _run_train(self, p, g, mode, want_lists):
-        """model.train() forward: statistics over all B*N points (and, when torch.distributed is initialised,
-        over all ranks -- the reference wraps the model in SyncBatchNorm, train_ae.py:152), running statistics
-        updated with the modules' momentum, unbiased variance (torch semantics)."""
-        import torch.distributed as dist
-        group_sum, g_all, row0 = None, None, 0
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            def group_sum(t):
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            sizes = [torch.zeros(1, dtype=torch.int64, device=p.device) for _ in range(dist.get_world_size())]
-            dist.all_gather(sizes, torch.tensor([g.shape[0]], dtype=torch.int64, device=p.device))
-            sizes = [int(x.item()) for x in sizes]
-            from .autograd import gather_rows       # per-rank batches may differ by one (train_ae.py:77-78)
-            g_all, row0 = gather_rows(g, sizes), sum(sizes[:dist.get_rank()])
+        """model.train() forward without autograd: statistics over all B*N points, running statistics updated with the
+        modules' momentum, unbiased variance (torch semantics).  One rank: everything in HIP from one C call (the FiLM heads'
+        BatchNorm over the B latent rows included).  Several ranks (the reference wraps the model in SyncBatchNorm,
+        train_ae.py:152): the phase-split pipeline with its packed statistic all-reduces, as the differentiable path."""
+        if _sharded():
+            from .autograd import train_density_forward_fast
+            with torch.no_grad():
+                out, logdet, lists, bn_batch = train_density_forward_fast(self, p, g, mode, distributed=True)
+                self._update_running_stats(bn_batch)
+            return out, logdet, (torch.stack(lists) if want_lists else None)
         with torch.no_grad():
             raw = self.raw_arena()
             out, logdet, lists, bn_batch = _lib.train_forward(p, g, raw, self.C, self.f, self.G, self.pattern0,
-                                                              self.couplings[0]._eps_value, mode, want_lists,
-                                                              group_sum, g_all, row0)
+                                                              self.couplings[0]._eps_value, mode, want_lists)
             self._update_running_stats(bn_batch)
         return out, logdet, lists
 
