@@ -47,6 +47,9 @@ WORKLOADS = {
                      'K=4 x 33 couplings, f=33, G=512, B=16 x N=2500'),
     'k16': dict(K=16, L=6, f=19, G=128, B=32, N=2048, mode='direct',
                 name='configs[3] K=16 mixture sampling, batched: each point visits one of 16 flows, 18 couplings, f=19'),
+    'k16_b1': dict(K=16, L=6, f=19, G=128, B=1, N=2048, mode='direct',
+                   name='configs[3] K=16 mixture sampling with the reference\'s own batch of ONE shape (flow_mixture.py:146): '
+                        'latency of one 2048-point sample'),
 }
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_* dense peak (= fp32 vector peak)
 MFMA_F16_PEAK_TFLOPS = 2500.0  # dense f16/bf16 MFMA peak; the contraction runs as 3 f16 products per fp32 product
@@ -306,12 +309,15 @@ def main():
 
     m = run_workload(args.workload, args, dev, rank, world, sync_all, reduce_max)
     also = None
-    if args.workload != 'm1' and not args.no_also:
-        # the metric's own shape (B=32 x N=2048, the north-star module) timed by the same protocol in the same run
-        a = run_workload('m1', args, dev, rank, world, sync_all, reduce_max)
-        also = {'m1': {'value': round(a['value'], 3), 'unit': 'Mpoints/s', 'ms_per_step': round(a['elapsed'] / args.steps * 1e3, 4),
-                       'steps': args.steps, 'warmup': args.warmup, 'workload': a['cfg']['name'],
-                       'roofline': roofline_record('m1', a)}}
+    if args.workload == 'airplane' and not args.no_also:
+        # the metric's own shape (B=32 x N=2048, the north-star module) and the other BASELINE configs' shapes, timed by the
+        # same protocol in the same run (a few seconds each)
+        also = {}
+        for name in ('m1', 'ae', 'svr', 'k16', 'k16_b1'):
+            a = run_workload(name, args, dev, rank, world, sync_all, reduce_max)
+            also[name] = {'value': round(a['value'], 3), 'unit': 'Mpoints/s',
+                          'ms_per_step': round(a['elapsed'] / args.steps * 1e3, 4), 'steps': args.steps, 'warmup': args.warmup,
+                          'workload': a['cfg']['name'], 'roofline': roofline_record(name, a)}
 
     if rank == 0:
         cfg = m['cfg']
