@@ -33,13 +33,17 @@ struct BCfg {
   static constexpr int KS = (FP + 31) / 32;
   static constexpr int W1T = MB * KS * 2 * 256;         // floats, one branch: [mi][ks][part][lane][8 f16] (GwtfPackB)
   static constexpr int PB = 2 * W1T + 2 * FP * 4;       // + SD0N[2][FP][4]
+  // LDS holds ONE branch's W1T at a time (+ SD0N of both): branch 1's transposed weights stream in over branch 0's while
+  // the dW1 product of branch 0 runs.  12 KB less LDS at f = 37: three workgroups per CU instead of two.
+  static constexpr int PB_LDS = W1T + 2 * FP * 4;
 };
 
 // STATS = false: backward of the coupling itself.  STATS = true: backward of the train-mode statistics pass
 // (gwtf_train_stats): the upstream is g_stats[branch][{d/dSum y, d/dSum y^2}][FP], i.e. dL/dy(p) = gS + 2 gQ y(p) for every
 // point, y = un-biased accumulator (no FiLM record, no tail); everything after dacc is shared.
+// waves per SIMD the register allocation is held to: the LDS footprint admits three workgroups per CU up to FP = 48
 template <int MB, int NB, bool STATS>
-__global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3 : 1))) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
                                                   float* __restrict__ g_in, float* __restrict__ dw1_ws,
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
       g_stats += comp * ks_.gstats;
     }
   }
-  __shared__ __align__(16) float lds[K::PW + K::FSP + KB::PB];
+  __shared__ __align__(16) float lds[K::PW + K::FSP + KB::PB_LDS];
   __shared__ float s_film[2][3][FP], s_sd0[2][3][FP], s_bias[4];
   // dW1 machinery: coordinates of the workgroup's points, per-wave |dacc| maxima, the transposed dacc image
   constexpr int PTS = 64 * NB;                      // points per workgroup
@@ -111,10 +115,13 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
     }
     if (!STATS && wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
       __builtin_amdgcn_global_load_lds((glb_void*)(src_f + wave * 256), (lds_void*)&lds[K::PW + wave * 256], 16, 0, 0);
-    for (int piece = wave; piece * 256 < KB::PB; piece += 4) {
-      if (piece * 256 + lane * 4 < KB::PB)
-        __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + piece * 256 + lane * 4),
-                                         (lds_void*)&lds[K::PW + K::FSP + piece * 256], 16, 0, 0);
+    for (int piece = wave; piece * 256 < KB::W1T; piece += 4)        // W1T of branch 0 (W1T is a multiple of 256 floats)
+      __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + piece * 256 + lane * 4),
+                                       (lds_void*)&lds[K::PW + K::FSP + piece * 256], 16, 0, 0);
+    for (int piece = wave; piece * 256 < 2 * FP * 4; piece += 4) {   // SD0N of both branches
+      if (piece * 256 + lane * 4 < 2 * FP * 4)
+        __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + 2 * KB::W1T + piece * 256 + lane * 4),
+                                         (lds_void*)&lds[K::PW + K::FSP + KB::W1T + piece * 256], 16, 0, 0);
     }
   }
   int k0, k1, w0, w1;
@@ -295,6 +302,7 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
     if (lane == 0) s_amax[br][wave] = amax;
+    if (br == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of branch 1's W1T have landed
     __syncthreads();   // also: every wave is past its forward recompute (branch 0) / past reading the previous X image (branch 1)
     amax = fmaxf(fmaxf(s_amax[br][0], s_amax[br][1]), fmaxf(s_amax[br][2], s_amax[br][3]));
     const int ebits = (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, amax)) >> 23) & 0xff;
@@ -320,8 +328,8 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
             dlo[ks][nb][4 * half + 2 * pr] = l[0]; dlo[ks][nb][4 * half + 2 * pr + 1] = l[1];
           }
         }
-    const float* w1t = LB + br * KB::W1T + lane * 4;
-    const f32x4* sd0n = reinterpret_cast<const f32x4*>(LB + 2 * KB::W1T + br * FP * 4);
+    const float* w1t = LB + lane * 4;
+    const f32x4* sd0n = reinterpret_cast<const f32x4*>(LB + KB::W1T + br * FP * 4);
     float pxa[NB], pxb[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) pxa[nb] = pxb[nb] = 0.f;
@@ -389,6 +397,11 @@ __global__ __launch_bounds__(256) void bwd_kernel(const float* __restrict__ x_in
             }
           }
       __syncthreads();
+      if (br == 0) {   // every wave is past its dh product: branch 1's W1T replaces branch 0's behind the dW1 product
+        for (int piece = wave; piece * 256 < KB::W1T; piece += 4)
+          __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + KB::W1T + piece * 256 + lane * 4),
+                                           (lds_void*)&lds[K::PW + K::FSP + piece * 256], 16, 0, 0);
+      }
       for (int ni = wave; ni < MB; ni += 4) {                // this wave's column(s) of output tiles: h features 16 ni .. (f > 64: two)
         const f32x4 sp = sd0n[16 * ni + i16];                 // the lane's h feature: {w0a, w0b, c0, -}
         f32x4 dw[MB];
