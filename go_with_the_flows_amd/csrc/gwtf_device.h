@@ -52,6 +52,11 @@ __device__ __forceinline__ void split_pair(f32x2 h, f16x2& hi, f16x2& lo) {
 
 // Sum over the 16 lanes of a DPP row (= one quarter of the wavefront = the 16 points of a column group); every lane ends
 // with the total.  Four v_add_f32 with DPP operand modifiers -- no LDS traffic (a __shfl_xor goes through ds_bpermute).
+// MEASURED AND REJECTED (round 2): a transpose-reduce of twelve values at a time (bank-masked v_add_f32_dpp for the mirror
+// steps, selects for the quad steps: 29 VALU per twelve values instead of 48, one 64-lane ds_add_f32 instead of twelve
+// lane-0 branches).  Correct, 250 fewer VALU and 90 fewer branches per backward wave -- and the airplane train step got 5 %
+// SLOWER (19.0 -> 20.0 ms): the backward kernel is latency-bound, and the twelve-deep dependent chain of one block replaces
+// 36 independent four-deep chains the scheduler was interleaving with the neighbouring FMAs.
 __device__ __forceinline__ float row_sum16(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]

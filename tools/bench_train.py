@@ -21,8 +21,12 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--points', type=int, default=2048)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--graph', action='store_true', help='capture forward + backward in one hipGraph')
+ap.add_argument('--lib', default=None, help='A/B: load this build of libgwtf_hip.so instead of the in-tree one')
 ap.add_argument('--parts', default='epd', help='debug: which parts run (e=encoder, p=prior flow, d=decoders)')
 a = ap.parse_args()
+if a.lib:
+    from go_with_the_flows_amd import _lib
+    _lib.LIB_PATH = a.lib
 
 CFG = dict(train_mode='p_rnvp_mc_g_rnvp_vae', util_mode='training', deterministic=False,
            pc_enc_init_n_channels=3, pc_enc_init_n_features=64, pc_enc_n_features=[128, 256, 512],
