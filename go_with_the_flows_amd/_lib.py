@@ -68,6 +68,19 @@ _SIGNATURES = {
     'gwtf_encoder_pack': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_encoder_forward': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int, ctypes.c_int, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
+    'gwtf_enc_train_supported': (ctypes.c_int, [_c_fp, ctypes.c_int]),
+    'gwtf_enc_train_units_floats': (ctypes.c_size_t, [ctypes.c_int]),
+    'gwtf_enc_train_pack': (ctypes.c_int, [_c_fp] * 3 + [ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_xmoments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_fold0': (ctypes.c_int, [_c_fp, ctypes.c_double] + [_c_fp] * 5 + [ctypes.c_float, _c_fp, _c_fp, _c_fp]),
+    'gwtf_enc_train_fold': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 4 + [ctypes.c_float, _c_fp, _c_fp]),
+    'gwtf_enc_train_forward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_pool': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_top': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_bwd_consts': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 5 + [_c_fp]),
+    'gwtf_enc_train_backward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 12 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_dw_partial_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'gwtf_enc_train_dw': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 9 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_prior_raw_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'gwtf_prior_raw_offset': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'gwtf_prior_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),

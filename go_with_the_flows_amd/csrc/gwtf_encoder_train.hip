@@ -1,0 +1,817 @@
+// gwtf_encoder_train.hip -- PointNet cloud encoder under model.train(): batch-statistic BatchNorm forward, max-pool, and the
+// whole backward, layer at a time.
+// Reference: PointNetCloudEncoder (lib/networks/encoders.py:9-28: SharedDot -> BatchNorm1d -> ReLU, 3 -> 64 -> 128 -> 256 ->
+// 512), the pooling of its caller (lib/networks/models.py:127-128: torch.max(features, dim=2)[0]) and what loss.backward()
+// (lib/networks/training.py:54) computes for them; SyncBatchNorm (train_ae.py:152) = the same kernels with the statistic
+// sums all-reduced by the host between a layer's kernel and its fold.
+//
+// Notation: layer l = 0..3, y_l = W_l a_{l-1} (pre-BatchNorm, a_{-1} = x), yhat_l = (y_l - mean_l) rstd_l,
+// a_l = relu(gamma_l yhat_l + beta_l) = relu(s_l y_l + t_l), pooled[b][c] = max_n a_3[b][c][n].
+// Batch statistics make every layer a global barrier (the mean / variance of y_l over all B N points must exist before
+// a_l does), so the pass runs layer at a time with y_1, y_2, y_3 kept in HBM in the reference's own (B, C, N) layout
+// (y_0 = W_0 x is three FMAs and is recomputed wherever it is needed).  288 GB of HBM make 0.5 GB of saved
+// pre-activations a non-issue; what the library path (rocBLAS GEMM + MIOpen BatchNorm + elementwise kernels) pays on top is
+// every intermediate written and read again between those calls, and fp32 matrix throughput: here each layer is ONE kernel
+//   prologue  a_{l-1} = relu(s y + t) applied while loading the B operand (8 channels x 1 point per lane: 64-byte rows)
+//   product   v_mfma_f32_16x16x32_f16, three-product split (W_hi a_hi + W_hi a_lo + W_lo a_hi), weights streamed
+//             L2 -> LDS by LDS-DMA in 32-KiB chunks shared by 8 wavefronts (as gwtf_encoder.hip)
+//   epilogue  y_l stored, sum y / sum y^2 per channel (DPP row sums -> LDS -> 64 global replicas), max |y|
+// Backward, per layer from the top:  dy_l = rstd (gamma gm_l - m1 - yhat_l m2) = s gm_l + Q y_l + R  with per-channel
+// constants from the two BatchNorm-backward sums (m1 = gamma mean(gm), m2 = gamma mean(gm yhat)), gm_l = dL/da_l masked by
+// a_l > 0.  One kernel per layer computes dL/da_{l-1} = W_l^T dy_l (prologue builds dy_l from y_l and gm_l, same MFMA
+// core with the transposed fragments) and, in its epilogue, masks it with a_{l-1} > 0, stores it, and accumulates the NEXT
+// layer's two sums; the top layer's gm_3 is non-zero only at the arg-max point of each (shape, channel), which the
+// prologue gets by comparing the point index.  The weight gradients dW_l = sum_p dy_l(p) a_{l-1}(p)^T contract over
+// POINTS: both operands are read K-major straight from the (B, C, N) arrays (a lane = one channel x 8 consecutive points),
+// every wavefront owns a 64 x 64 block of dW_l over one slice of the points and writes a partial that a second kernel sums in
+// a fixed order.  Gradients have no natural scale, so every f16-split gradient operand is multiplied by a power of two
+// chosen from a bound on |dy_l| (host-free: the bound comes from max |gm_l| and max |y_l| tracked by the producing
+// kernels) and the result is scaled back: exact.
+#include <hip/hip_runtime.h>
+#include "gwtf_device.h"
+
+using namespace gwtf_dev;
+
+namespace {
+
+constexpr int kChunk = 8192;        // floats per LDS chunk (32 KiB = 16 units of [hi|lo] 16x32 f16 fragments)
+constexpr int kThreads = 512;
+constexpr int kR = GWTF_STAT_REPLICAS;
+constexpr int kC[5] = {3, 64, 128, 256, 512};
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// units [m][ks] of [hi | lo] x 64 lanes x 8 f16: A-operand row 16 m + (lane & 15), k-slot (ks, q, e) <-> contraction index
+// 32 ks + 16 (e >> 2) + 4 q + (e & 3) (the map gwtf_encoder.hip uses).  transposed = 0: A[row][k] = W[row][k] (W [rows][kdim]);
+// transposed = 1: A[row][k] = W[k][row] (W [kdim][rows]).
+__global__ void enc_train_pack_kernel(const float* __restrict__ W, float* __restrict__ units, int rows, int kdim, int transposed) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int KS = kdim / 32;
+  if (t >= (rows / 16) * KS * 2 * 64) return;
+  const int lane = t & 63, part = (t >> 6) & 1, unit = t >> 7;
+  const int m = unit / KS, ks = unit % KS;
+  const int row = 16 * m + (lane & 15), q = lane >> 4;
+  _Float16 out[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int k = 32 * ks + 16 * (e >> 2) + 4 * q + (e & 3);
+    const float v = transposed ? W[(size_t)k * rows + row] : W[(size_t)row * kdim + k];
+    const _Float16 hi = (_Float16)v;
+    out[e] = part == 0 ? hi : (_Float16)(v - (float)hi);
+  }
+  *reinterpret_cast<float4*>(units + (size_t)unit * 512 + part * 256 + lane * 4) = *reinterpret_cast<const float4*>(out);
+}
+
+// sum x (3) and sum x x^T (6: xx xy xz yy yz zz) over all points -> mom[replica][12] (pre-zeroed)
+__global__ __launch_bounds__(256) void enc_xmom_kernel(const float* __restrict__ x, float* __restrict__ mom, int B, int N) {
+  __shared__ float part[4][9];
+  const int b = blockIdx.y;
+  float s[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 4; ++i) {
+    const int n = blockIdx.x * 1024 + i * 256 + threadIdx.x;
+    if (n < N) {
+      const float a = x[((size_t)b * 3 + 0) * N + n], c = x[((size_t)b * 3 + 1) * N + n], d = x[((size_t)b * 3 + 2) * N + n];
+      s[0] += a; s[1] += c; s[2] += d;
+      s[3] = fmaf(a, a, s[3]); s[4] = fmaf(a, c, s[4]); s[5] = fmaf(a, d, s[5]);
+      s[6] = fmaf(c, c, s[6]); s[7] = fmaf(c, d, s[7]); s[8] = fmaf(d, d, s[8]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s[j] += __shfl_down(s[j], off);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int j = 0; j < 9; ++j) part[wave][j] = s[j];
+  __syncthreads();
+  if (threadIdx.x < 9)
+    atomicAdd(&mom[((blockIdx.y * gridDim.x + blockIdx.x) % kR) * 12 + threadIdx.x],
+              (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
+__device__ __forceinline__ void bn_running_update(float* rm, float* rv, int c, double mean, double var, double n, float momentum) {
+  if (rm) rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mean);
+  if (rv) rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * var * (n > 1.0 ? n / (n - 1.0) : 1.0));
+}
+
+// layer 0: statistics of y_0 = W_0 x are exact functions of the moments of x.  mom12 = sums over all points (and ranks).
+// aff [4][C0] = s, t, mean, rstd;  table0 [C0][4] = (s W_0 row, t)
+__global__ void enc_fold0_kernel(const float* __restrict__ mom12, double n, const float* __restrict__ W0,
+                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* rm, float* rv,
+                                 float momentum, float* __restrict__ aff, float* __restrict__ table0, int C0) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C0) return;
+  const double w0 = W0[c * 3], w1 = W0[c * 3 + 1], w2 = W0[c * 3 + 2];
+  const double mean = (w0 * mom12[0] + w1 * mom12[1] + w2 * mom12[2]) / n;
+  const double e2 = (w0 * w0 * mom12[3] + 2 * w0 * w1 * mom12[4] + 2 * w0 * w2 * mom12[5] + w1 * w1 * mom12[6] +
+                     2 * w1 * w2 * mom12[7] + w2 * w2 * mom12[8]) / n;
+  double var = e2 - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)GWTF_BN_EPS);
+  const double s = gamma[c] * rstd, t = beta[c] - mean * s;
+  aff[c] = (float)s; aff[C0 + c] = (float)t; aff[2 * C0 + c] = (float)mean; aff[3 * C0 + c] = (float)rstd;
+  table0[c * 4] = (float)(w0 * s); table0[c * 4 + 1] = (float)(w1 * s); table0[c * 4 + 2] = (float)(w2 * s); table0[c * 4 + 3] = (float)t;
+  bn_running_update(rm, rv, c, mean, var, n, momentum);
+}
+
+// sums [2][C] = sum y, sum y^2 over all points (replicas and ranks already summed)
+__global__ void enc_fold_kernel(const float* __restrict__ sums, int C, double n, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* rm, float* rv, float momentum, float* __restrict__ aff) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = (double)sums[c] / n;
+  double var = (double)sums[C + c] / n - mean * mean;
+  if (var < 0) var = 0;
+  const double rstd = 1.0 / sqrt(var + (double)GWTF_BN_EPS);
+  const double s = gamma[c] * rstd;
+  aff[c] = (float)s; aff[C + c] = (float)(beta[c] - mean * s); aff[2 * C + c] = (float)mean; aff[3 * C + c] = (float)rstd;
+  bn_running_update(rm, rv, c, mean, var, n, momentum);
+}
+
+// f16 hi/lo split of an accumulator-layout tile into elements 4*half..+3 of a B fragment; RELU: max(., 0) first
+template <bool RELU>
+__device__ __forceinline__ void split_into(const f32x4& a, f16x8& hi, f16x8& lo, int half) {
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    f32x2 v = {RELU ? fmaxf(a[2 * p], 0.f) : a[2 * p], RELU ? fmaxf(a[2 * p + 1], 0.f) : a[2 * p + 1]};
+    f16x2 h, l;
+    split_pair(v, h, l);
+    hi[4 * half + 2 * p] = h[0]; hi[4 * half + 2 * p + 1] = h[1];
+    lo[4 * half + 2 * p] = l[0]; lo[4 * half + 2 * p + 1] = l[1];
+  }
+}
+
+template <int KS, int NB>
+__device__ __forceinline__ void tile_mfma(const float* __restrict__ unit0, int lane, const f16x8 (&bhi)[KS][NB],
+                                          const f16x8 (&blo)[KS][NB], f32x4 (&acc)[NB]) {
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) acc[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const f16x8 ahi = *reinterpret_cast<const f16x8*>(unit0 + ks * 512 + lane * 4);
+    const f16x8 alo = *reinterpret_cast<const f16x8*>(unit0 + ks * 512 + 256 + lane * 4);
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[ks][nb], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[ks][nb], acc[nb], 0, 0, 0);
+      acc[nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[ks][nb], acc[nb], 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+  return v;
+}
+
+// ---- forward of one layer: y_out = W . relu(s in + t)  (FIRST: in = x, relu(W_0' x + t_0) from table0) -------------------
+template <int CIN, int COUT, bool FIRST>
+__global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __restrict__ in, const float* __restrict__ in_tab,
+                                                                 const float* __restrict__ units, float* __restrict__ y_out,
+                                                                 float* __restrict__ sums, float* __restrict__ ymax, int B,
+                                                                 int N) {
+  constexpr int NB = 2, KS = CIN / 32, MT = COUT / 16, TM = 16 / KS, NCH = MT / TM;
+  static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
+  __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
+  __shared__ __attribute__((aligned(16))) float tab[FIRST ? 4 * CIN : 2 * CIN];
+  __shared__ float wsum[2][COUT];
+  __shared__ float wmax[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, n_wave0 = blockIdx.x * 256 + wave * 32;
+
+  auto stage = [&](int buf, int g) {
+#pragma unroll
+    for (int i = 0; i < kChunk / 256 / 8; ++i) {
+      const int piece = wave + 8 * i;
+      __builtin_amdgcn_global_load_lds((glb_void*)(units + (size_t)g * kChunk + piece * 256 + lane * 4),
+                                       (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  for (int t = tid; t < (FIRST ? 4 * CIN : 2 * CIN); t += kThreads) tab[t] = in_tab[t];
+  for (int t = tid; t < 2 * COUT; t += kThreads) (&wsum[0][0])[t] = 0.f;
+
+  int n[NB];
+  bool valid[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    n[nb] = n_wave0 + 16 * nb + i16;
+    valid[nb] = n[nb] < N;
+  }
+  __syncthreads();
+
+  f16x8 bhi[KS][NB], blo[KS][NB];
+  if (FIRST) {
+    float px[NB], py[NB], pz[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      px[nb] = valid[nb] ? in[((size_t)b * 3 + 0) * N + n[nb]] : 0.f;
+      py[nb] = valid[nb] ? in[((size_t)b * 3 + 1) * N + n[nb]] : 0.f;
+      pz[nb] = valid[nb] ? in[((size_t)b * 3 + 2) * N + n[nb]] : 0.f;
+    }
+    const float4* t4 = reinterpret_cast<const float4*>(tab);
+#pragma unroll
+    for (int m = 0; m < CIN / 16; ++m) {
+      float4 w[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) w[r] = t4[16 * m + 4 * q + r];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x4 a;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] = w[r].x * px[nb] + (w[r].y * py[nb] + (w[r].z * pz[nb] + w[r].w));
+        split_into<true>(a, bhi[m >> 1][nb], blo[m >> 1][nb], m & 1);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int c0 = 32 * ks + 16 * half + 4 * q;
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(&tab[c0]), t4 = *reinterpret_cast<const f32x4*>(&tab[CIN + c0]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          f32x4 a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = valid[nb] ? in[((size_t)b * CIN + c0 + r) * N + n[nb]] : 0.f;
+            a[r] = fmaf(s4[r], v, t4[r]);
+          }
+          split_into<true>(a, bhi[ks][nb], blo[ks][nb], half);
+        }
+      }
+  }
+
+  int g = 0;
+  float amax = 0.f;
+#pragma unroll 1
+  for (int ci = 0; ci < NCH; ++ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (g + 1 < NCH) stage((g + 1) & 1, g + 1);
+    const float* L = lds[g & 1];
+    ++g;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int m = ci * TM + t;
+      f32x4 acc[NB];
+      tile_mfma<KS, NB>(L + t * KS * 512, lane, bhi, blo, acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ch = 16 * m + 4 * q + r;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          const float v = valid[nb] ? acc[nb][r] : 0.f;
+          if (valid[nb]) y_out[((size_t)b * COUT + ch) * N + n[nb]] = v;
+          s1 += v;
+          s2 = fmaf(v, v, s2);
+          amax = fmaxf(amax, fabsf(v));
+        }
+        s1 = row_sum16(s1);
+        s2 = row_sum16(s2);
+        if (i16 == 0) {
+          atomicAdd(&wsum[0][ch], s1);
+          atomicAdd(&wsum[1][ch], s2);
+        }
+      }
+    }
+  }
+  amax = wave_max(amax);
+  if (lane == 0) wmax[wave] = amax;
+  __syncthreads();
+  float* dst = sums + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % kR) * 2 * COUT;
+  for (int t = tid; t < 2 * COUT; t += kThreads) atomicAdd(&dst[t], (&wsum[0][0])[t]);
+  if (tid == 0) {
+    float m = wmax[0];
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, wmax[w]);
+    atomicMax(reinterpret_cast<int*>(ymax), __builtin_bit_cast(int, m));   // non-negative floats order like their bit patterns
+  }
+}
+
+// ---- pooled[b][c] = max_n relu(s y_3 + t), its first arg-max, and y_3 there; one wavefront per (b, c) row -----------------
+__global__ __launch_bounds__(256) void enc_pool_kernel(const float* __restrict__ y, const float* __restrict__ aff,
+                                                       float* __restrict__ pooled, int* __restrict__ amax,
+                                                       float* __restrict__ ystar, int B, int C, int N) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= B * C) return;
+  const int c = row % C;
+  const float s = aff[c], t = aff[C + c];
+  const float* src = y + (size_t)row * N;
+  float best = -1.f, yb = 0.f;
+  int bi = 0;
+  for (int n = lane; n < N; n += 64) {
+    const float v = src[n];
+    const float a = fmaxf(fmaf(s, v, t), 0.f);
+    if (a > best) { best = a; bi = n; yb = v; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off), oy = __shfl_xor(yb, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; yb = oy; }
+  }
+  if (lane == 0) {
+    pooled[row] = best;
+    amax[row] = bi;
+    ystar[row] = yb;
+  }
+}
+
+// ---- top of the backward: gp = g_pooled where the pooled activation is > 0; the two BatchNorm-backward sums of layer 3 -----
+__global__ void enc_top_kernel(const float* __restrict__ g_pooled, const float* __restrict__ pooled,
+                               const float* __restrict__ ystar, const float* __restrict__ aff, float* __restrict__ gp,
+                               float* __restrict__ sums, float* __restrict__ gmax, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = aff[2 * C + c], rstd = aff[3 * C + c];
+  float db = 0.f, dg = 0.f, mx = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = pooled[b * C + c] > 0.f ? g_pooled[b * C + c] : 0.f;
+    gp[b * C + c] = g;
+    db += g;
+    dg = fmaf(g, (ystar[b * C + c] - mean) * rstd, dg);
+    mx = fmaxf(mx, fabsf(g));
+  }
+  sums[c] = db;
+  sums[C + c] = dg;
+  atomicMax(reinterpret_cast<int*>(gmax), __builtin_bit_cast(int, mx));
+}
+
+// ---- per-channel constants of dy = s gm + Q y + R and the power-of-two operand scale ---------------------------------------
+// sums [2][C] = sum gm, sum gm yhat over ALL points (replicas and ranks summed).  bconst [3][C] + {up, down, -, -}
+__global__ __launch_bounds__(512) void enc_bwd_consts_kernel(const float* __restrict__ sums, int C, double n,
+                                                             const float* __restrict__ gamma, const float* __restrict__ aff,
+                                                             const float* __restrict__ gmax, const float* __restrict__ ymax,
+                                                             float* __restrict__ bconst) {
+  __shared__ float red[512];
+  float bound = 0.f;
+  const float gm = gmax ? *gmax : 0.f, ym = ymax ? *ymax : 0.f;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double mean = aff[2 * C + c], rstd = aff[3 * C + c];
+    const double m1 = (double)gamma[c] * sums[c] / n, m2 = (double)gamma[c] * sums[C + c] / n;
+    const float s = aff[c], Q = (float)(-rstd * rstd * m2), R = (float)(-rstd * m1 + rstd * rstd * m2 * mean);
+    bconst[c] = s;
+    bconst[C + c] = Q;
+    bconst[2 * C + c] = R;
+    bound = fmaxf(bound, fabsf(s) * gm + fabsf(Q) * ym + fabsf(R));
+  }
+  red[threadIdx.x] = bound;
+  __syncthreads();
+  for (int off = 256; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // bound in [2^(e-127), 2^(e-126)): up = 2^(14 - (e - 126)) maps it below 2^15 (f16 max 65504)
+    const int e = (__builtin_bit_cast(int, red[0]) >> 23) & 0xff;
+    const bool ok = e >= 16 && e <= 240;
+    bconst[3 * C] = ok ? __builtin_bit_cast(float, (127 + 14 - (e - 126)) << 23) : 1.0f;
+    bconst[3 * C + 1] = ok ? __builtin_bit_cast(float, (127 - 14 + (e - 126)) << 23) : 1.0f;
+    bconst[3 * C + 2] = 0.f;
+    bconst[3 * C + 3] = 0.f;
+  }
+}
+
+// ---- backward of one layer: dL/da_{l-1} = W_l^T dy_l, masked by a_{l-1} > 0; sums for the layer below -------------------------
+// CIN = C_{l-1} (rows of the product), COUT = C_l (contraction).  TOP: gm_l from (gp, amax); BOTTOM: layer l-1 = 0 (y_0 from x,
+// nothing stored, the extra sums sum gm_0 x_d for dW_0).
+template <int CIN, int COUT, int NB, bool TOP, bool BOTTOM>
+__global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
+                                                                 const float* __restrict__ gp, const int* __restrict__ amax,
+                                                                 const float* __restrict__ bconst, const float* __restrict__ units,
+                                                                 const float* __restrict__ y_prev, const float* __restrict__ aff_prev,
+                                                                 const float* __restrict__ w0, float* __restrict__ dA_prev,
+                                                                 float* __restrict__ sums, float* __restrict__ gmax_prev, int B,
+                                                                 int N) {
+  constexpr int KS = COUT / 32, MT = CIN / 16, TM = 16 / KS, NCH = MT / TM, NS = BOTTOM ? 5 : 2;
+  static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
+  __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
+  __shared__ __attribute__((aligned(16))) float bc[3 * COUT];
+  __shared__ __attribute__((aligned(16))) float ap[4 * CIN];
+  __shared__ __attribute__((aligned(16))) float topg[TOP ? COUT : 4];
+  __shared__ __attribute__((aligned(16))) int topi[TOP ? COUT : 4];
+  __shared__ __attribute__((aligned(16))) float w0s[BOTTOM ? CIN * 4 : 4];
+  __shared__ float wsum[NS][CIN];
+  __shared__ float wmax[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+  const int b = blockIdx.y, n_wave0 = blockIdx.x * (128 * NB) + wave * 16 * NB;
+
+  auto stage = [&](int buf, int g) {
+#pragma unroll
+    for (int i = 0; i < kChunk / 256 / 8; ++i) {
+      const int piece = wave + 8 * i;
+      __builtin_amdgcn_global_load_lds((glb_void*)(units + (size_t)g * kChunk + piece * 256 + lane * 4),
+                                       (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  for (int t = tid; t < 3 * COUT; t += kThreads) bc[t] = bconst[t];
+  for (int t = tid; t < 4 * CIN; t += kThreads) ap[t] = aff_prev[t];
+  if (TOP)
+    for (int t = tid; t < COUT; t += kThreads) {
+      topg[t] = gp[(size_t)b * COUT + t];
+      topi[t] = amax[(size_t)b * COUT + t];
+    }
+  if (BOTTOM)
+    for (int t = tid; t < CIN; t += kThreads) {
+      w0s[4 * t] = w0[3 * t]; w0s[4 * t + 1] = w0[3 * t + 1]; w0s[4 * t + 2] = w0[3 * t + 2]; w0s[4 * t + 3] = 0.f;
+    }
+  for (int t = tid; t < NS * CIN; t += kThreads) (&wsum[0][0])[t] = 0.f;
+  const float up = bconst[3 * COUT], down = bconst[3 * COUT + 1];
+
+  int n[NB];
+  bool valid[NB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+    n[nb] = n_wave0 + 16 * nb + i16;
+    valid[nb] = n[nb] < N;
+  }
+  __syncthreads();
+
+  // prologue: dy_l (scaled by `up`) for the lane's k-slots, split into the B fragments
+  f16x8 bhi[KS][NB], blo[KS][NB];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int c0 = 32 * ks + 16 * half + 4 * q;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(&bc[c0]) * up, q4 = *reinterpret_cast<const f32x4*>(&bc[COUT + c0]) * up,
+                  r4 = *reinterpret_cast<const f32x4*>(&bc[2 * COUT + c0]) * up;
+      f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+      i32x4 a4 = {0, 0, 0, 0};
+      if (TOP) {
+        g4 = *reinterpret_cast<const f32x4*>(&topg[c0]);
+        a4 = *reinterpret_cast<const i32x4*>(&topi[c0]);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        f32x4 d;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const size_t idx = ((size_t)b * COUT + c0 + r) * N + n[nb];
+          const float yv = valid[nb] ? y_l[idx] : 0.f;
+          const float gm = TOP ? (n[nb] == a4[r] ? g4[r] : 0.f) : (valid[nb] ? up_g[idx] : 0.f);
+          d[r] = valid[nb] ? fmaf(s4[r], gm, fmaf(q4[r], yv, r4[r])) : 0.f;
+        }
+        split_into<false>(d, bhi[ks][nb], blo[ks][nb], half);
+      }
+    }
+
+  float px[NB], py[NB], pz[NB];
+  if (BOTTOM) {
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      px[nb] = valid[nb] ? y_prev[((size_t)b * 3 + 0) * N + n[nb]] : 0.f;
+      py[nb] = valid[nb] ? y_prev[((size_t)b * 3 + 1) * N + n[nb]] : 0.f;
+      pz[nb] = valid[nb] ? y_prev[((size_t)b * 3 + 2) * N + n[nb]] : 0.f;
+    }
+  }
+
+  int g = 0;
+  float gmx = 0.f;
+#pragma unroll 1
+  for (int ci = 0; ci < NCH; ++ci) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (g + 1 < NCH) stage((g + 1) & 1, g + 1);
+    const float* L = lds[g & 1];
+    ++g;
+#pragma unroll
+    for (int t = 0; t < TM; ++t) {
+      const int m = ci * TM + t, j0 = 16 * m + 4 * q;
+      f32x4 acc[NB];
+      tile_mfma<KS, NB>(L + t * KS * 512, lane, bhi, blo, acc);
+      const f32x4 sp = *reinterpret_cast<const f32x4*>(&ap[j0]), tp = *reinterpret_cast<const f32x4*>(&ap[CIN + j0]),
+                  mp = *reinterpret_cast<const f32x4*>(&ap[2 * CIN + j0]), rp = *reinterpret_cast<const f32x4*>(&ap[3 * CIN + j0]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        float sb = 0.f, sg = 0.f, sx0 = 0.f, sx1 = 0.f, sx2 = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          float yv;
+          if (BOTTOM) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(&w0s[4 * j]);
+            yv = w[0] * px[nb] + (w[1] * py[nb] + w[2] * pz[nb]);
+          } else {
+            yv = valid[nb] ? y_prev[((size_t)b * CIN + j) * N + n[nb]] : 0.f;
+          }
+          const bool on = valid[nb] && fmaf(sp[r], yv, tp[r]) > 0.f;
+          const float gm = on ? acc[nb][r] * down : 0.f;
+          if (!BOTTOM && valid[nb]) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
+          sb += gm;
+          sg = fmaf(gm, (yv - mp[r]) * rp[r], sg);
+          if (BOTTOM) {
+            sx0 = fmaf(gm, px[nb], sx0);
+            sx1 = fmaf(gm, py[nb], sx1);
+            sx2 = fmaf(gm, pz[nb], sx2);
+          }
+          gmx = fmaxf(gmx, fabsf(gm));
+        }
+        sb = row_sum16(sb);
+        sg = row_sum16(sg);
+        if (BOTTOM) {
+          sx0 = row_sum16(sx0);
+          sx1 = row_sum16(sx1);
+          sx2 = row_sum16(sx2);
+        }
+        if (i16 == 0) {
+          atomicAdd(&wsum[0][j], sb);
+          atomicAdd(&wsum[1][j], sg);
+          if (BOTTOM) {
+            atomicAdd(&wsum[2][j], sx0);
+            atomicAdd(&wsum[3][j], sx1);
+            atomicAdd(&wsum[4][j], sx2);
+          }
+        }
+      }
+    }
+  }
+  gmx = wave_max(gmx);
+  if (lane == 0) wmax[wave] = gmx;
+  __syncthreads();
+  float* dst = sums + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % kR) * NS * CIN;
+  for (int t = tid; t < NS * CIN; t += kThreads) atomicAdd(&dst[t], (&wsum[0][0])[t]);
+  if (tid == 0 && gmax_prev) {
+    float m = wmax[0];
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, wmax[w]);
+    atomicMax(reinterpret_cast<int*>(gmax_prev), __builtin_bit_cast(int, m));
+  }
+}
+
+// ---- weight gradient dW_l[c][k] = sum_p dy_l[c](p) a_{l-1}[k](p): a wavefront = one 64 x 64 block over one slice of points ----
+__device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    f32x2 x = {v[2 * p], v[2 * p + 1]};
+    f16x2 h, l;
+    split_pair(x, h, l);
+    hi[2 * p] = h[0]; hi[2 * p + 1] = h[1];
+    lo[2 * p] = l[0]; lo[2 * p + 1] = l[1];
+  }
+}
+
+__device__ __forceinline__ void load8(const float* row, int n0, int p1, float (&v)[8]) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 a = n0 < p1 ? *reinterpret_cast<const float4*>(row + n0) : z;
+  const float4 c = n0 + 4 < p1 ? *reinterpret_cast<const float4*>(row + n0 + 4) : z;
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+}
+
+template <bool TOP, bool FIRST>
+__global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
+                                                           const float* __restrict__ gp, const int* __restrict__ amax,
+                                                           const float* __restrict__ bconst, const float* __restrict__ y_prev,
+                                                           const float* __restrict__ tab_prev, float* __restrict__ partials, int B,
+                                                           int N, int CA, int CB, int nsl, int per) {
+  const int lane = threadIdx.x & 63, i16 = lane & 15, q = lane >> 4;
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int nbn = CB / 64, nblk = (CA / 64) * nbn;
+  const int blk = w % nblk, sl = w / nblk;
+  if (sl >= B * nsl) return;
+  const int bm = blk / nbn, bn = blk % nbn, b = sl / nsl, part = sl % nsl;
+  const int p0 = part * per, p1 = min(N, p0 + per);
+  const float up = bconst[3 * CA], down = bconst[3 * CA + 1];
+
+  float sA[4], qA[4], rA[4], gpv[4], sB[4], tB[4], wB[4][3];
+  int amv[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int c = 64 * bm + 16 * mt + i16;
+    sA[mt] = bconst[c] * up; qA[mt] = bconst[CA + c] * up; rA[mt] = bconst[2 * CA + c] * up;
+    gpv[mt] = TOP ? gp[(size_t)b * CA + c] : 0.f;
+    amv[mt] = TOP ? amax[(size_t)b * CA + c] : -1;
+  }
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int k = 64 * bn + 16 * nt + i16;
+    if (FIRST) {
+      wB[nt][0] = tab_prev[4 * k]; wB[nt][1] = tab_prev[4 * k + 1]; wB[nt][2] = tab_prev[4 * k + 2];
+      tB[nt] = tab_prev[4 * k + 3];
+      sB[nt] = 0.f;
+    } else {
+      sB[nt] = tab_prev[k];
+      tB[nt] = tab_prev[CB + k];
+      wB[nt][0] = wB[nt][1] = wB[nt][2] = 0.f;
+    }
+  }
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int p = p0; p < p1; p += 32) {
+    const int n0 = p + 8 * q;
+    f16x8 ahi[4], alo[4], bhi[4], blo[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const size_t row = ((size_t)b * CA + 64 * bm + 16 * mt + i16) * N;
+      float yv[8], gm[8], d[8];
+      load8(y_l + row, n0, p1, yv);
+      if (TOP) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) gm[e] = (n0 + e == amv[mt]) ? gpv[mt] : 0.f;
+      } else {
+        load8(up_g + row, n0, p1, gm);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) d[e] = (n0 + (e & 4) < p1) ? fmaf(sA[mt], gm[e], fmaf(qA[mt], yv[e], rA[mt])) : 0.f;
+      split8(d, ahi[mt], alo[mt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float a[8];
+      if (FIRST) {
+        float x0[8], x1[8], x2[8];
+        load8(y_prev + ((size_t)b * 3 + 0) * N, n0, p1, x0);
+        load8(y_prev + ((size_t)b * 3 + 1) * N, n0, p1, x1);
+        load8(y_prev + ((size_t)b * 3 + 2) * N, n0, p1, x2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          a[e] = (n0 + (e & 4) < p1) ? fmaxf(wB[nt][0] * x0[e] + (wB[nt][1] * x1[e] + (wB[nt][2] * x2[e] + tB[nt])), 0.f) : 0.f;
+      } else {
+        float yv[8];
+        load8(y_prev + ((size_t)b * CB + 64 * bn + 16 * nt + i16) * N, n0, p1, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (n0 + (e & 4) < p1) ? fmaxf(fmaf(sB[nt], yv[e], tB[nt]), 0.f) : 0.f;
+      }
+      split8(a, bhi[nt], blo[nt]);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[mt], bhi[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[mt], blo[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[mt], bhi[nt], acc[mt][nt], 0, 0, 0);
+      }
+  }
+  float* out = partials + (size_t)sl * CA * CB;
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(size_t)(64 * bm + 16 * mt + 4 * q + r) * CB + 64 * bn + 16 * nt + i16] = acc[mt][nt][r] * down;
+}
+
+__global__ __launch_bounds__(256) void enc_dw_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out, int slices,
+                                                            int total) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int p = 0;
+  for (; p + 3 < slices; p += 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += partials[(size_t)(p + u) * total + e];
+  for (; p < slices; ++p) s[0] += partials[(size_t)p * total + e];
+  out[e] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+int dw_slices_per_shape(int layer) { return layer == 3 ? 1 : (layer == 2 ? 4 : 8); }
+int dw_per(int layer, int N) {
+  const int nsl = dw_slices_per_shape(layer);
+  return ((N + nsl - 1) / nsl + 31) / 32 * 32;
+}
+
+}  // namespace
+
+extern "C" int gwtf_enc_train_supported(const int* widths, int n_widths) {
+  if (!widths || n_widths != 5) return 0;
+  for (int i = 0; i < 5; ++i)
+    if (widths[i] != kC[i]) return 0;
+  return 1;
+}
+
+extern "C" size_t gwtf_enc_train_units_floats(int layer) {
+  if (layer < 1 || layer > 3) return 0;
+  return (size_t)(kC[layer + 1] / 16) * (kC[layer] / 32) * 512;
+}
+
+extern "C" int gwtf_enc_train_pack(const float* W, float* units_fwd, float* units_bwd, int layer, void* stream) {
+  if (!W || !units_fwd || !units_bwd || layer < 1 || layer > 3) return GWTF_E_BADARG;
+  const int cin = kC[layer], cout = kC[layer + 1];
+  const int total = (cout / 16) * (cin / 32) * 2 * 64;     // == (cin / 16) * (cout / 32) * 2 * 64
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(enc_train_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, units_fwd, cout, cin, 0);
+  hipLaunchKernelGGL(enc_train_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, units_bwd, cin, cout, 1);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_xmoments(const float* x, float* mom, int B, int N, void* stream) {
+  if (!x || !mom || B <= 0 || N <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(enc_xmom_kernel, dim3((N + 1023) / 1024, B), dim3(256), 0, (hipStream_t)stream, x, mom, B, N);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_fold0(const float* mom12, double n_total, const float* W0, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float* aff, float* table0,
+                                    void* stream) {
+  if (!mom12 || !W0 || !gamma || !beta || !aff || !table0 || n_total <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(enc_fold0_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, mom12, n_total, W0, gamma, beta, running_mean,
+                     running_var, momentum, aff, table0, kC[1]);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_fold(const float* sums, int layer, double n_total, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float* aff, void* stream) {
+  if (!sums || !gamma || !beta || !aff || layer < 1 || layer > 3 || n_total <= 0) return GWTF_E_BADARG;
+  const int C = kC[layer + 1];
+  hipLaunchKernelGGL(enc_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, C, n_total, gamma, beta,
+                     running_mean, running_var, momentum, aff);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_forward(int layer, const float* in, const float* in_tab, const float* units, float* y_out,
+                                      float* sums, float* ymax, int B, int N, void* stream) {
+  if (!in || !in_tab || !units || !y_out || !sums || !ymax || B <= 0 || N <= 0 || layer < 1 || layer > 3) return GWTF_E_BADARG;
+  const dim3 grid((N + 255) / 256, B), block(kThreads);
+  hipStream_t st = (hipStream_t)stream;
+  if (layer == 1) hipLaunchKernelGGL((enc_train_fwd_kernel<64, 128, true>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, B, N);
+  else if (layer == 2) hipLaunchKernelGGL((enc_train_fwd_kernel<128, 256, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, B, N);
+  else hipLaunchKernelGGL((enc_train_fwd_kernel<256, 512, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, B, N);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_pool(const float* y3, const float* aff3, float* pooled, int* amax, float* ystar, int B, int N,
+                                   void* stream) {
+  if (!y3 || !aff3 || !pooled || !amax || !ystar || B <= 0 || N <= 0) return GWTF_E_BADARG;
+  const int C = kC[4];
+  hipLaunchKernelGGL(enc_pool_kernel, dim3((B * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, y3, aff3, pooled, amax, ystar, B, C, N);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_top(const float* g_pooled, const float* pooled, const float* ystar, const float* aff3, float* gp,
+                                  float* sums, float* gmax, int B, void* stream) {
+  if (!g_pooled || !pooled || !ystar || !aff3 || !gp || !sums || !gmax || B <= 0) return GWTF_E_BADARG;
+  const int C = kC[4];
+  hipLaunchKernelGGL(enc_top_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, g_pooled, pooled, ystar, aff3, gp, sums,
+                     gmax, B, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, const float* gamma, const float* aff,
+                                         const float* gmax, const float* ymax, float* bconst, void* stream) {
+  if (!sums || !gamma || !aff || !bconst || layer < 0 || layer > 3 || n_total <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(enc_bwd_consts_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, sums, kC[layer + 1], n_total, gamma, aff,
+                     gmax, ymax, bconst);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax,
+                                       const float* bconst, const float* units_bwd, const float* y_prev, const float* aff_prev,
+                                       const float* w0, float* dA_prev, float* sums, float* gmax_prev, int B, int N, void* stream) {
+  if (!y_l || !bconst || !units_bwd || !y_prev || !aff_prev || !sums || B <= 0 || N <= 0 || layer < 1 || layer > 3)
+    return GWTF_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 block(kThreads);
+  if (layer == 3) {
+    if (!gp || !amax || !dA_prev || !gmax_prev) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_bwd_kernel<256, 512, 1, true, false>), dim3((N + 127) / 128, B), block, 0, st, y_l, up_g, gp, amax,
+                       bconst, units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N);
+  } else if (layer == 2) {
+    if (!up_g || !dA_prev || !gmax_prev) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_bwd_kernel<128, 256, 2, false, false>), dim3((N + 255) / 256, B), block, 0, st, y_l, up_g, gp, amax,
+                       bconst, units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N);
+  } else {
+    if (!up_g || !w0) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_bwd_kernel<64, 128, 2, false, true>), dim3((N + 255) / 256, B), block, 0, st, y_l, up_g, gp, amax,
+                       bconst, units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" size_t gwtf_enc_train_dw_partial_floats(int layer, int B, int N) {
+  if (layer < 1 || layer > 3 || B <= 0 || N <= 0) return 0;
+  return (size_t)B * dw_slices_per_shape(layer) * kC[layer + 1] * kC[layer];
+}
+
+extern "C" int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax,
+                                 const float* bconst, const float* y_prev, const float* tab_prev, float* partials, float* dW, int B,
+                                 int N, void* stream) {
+  if (!y_l || !bconst || !y_prev || !tab_prev || !partials || !dW || B <= 0 || N <= 0 || (N & 3) || layer < 1 || layer > 3)
+    return GWTF_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int CA = kC[layer + 1], CB = kC[layer], nsl = dw_slices_per_shape(layer), per = dw_per(layer, N);
+  const int waves = (CA / 64) * (CB / 64) * B * nsl;
+  const dim3 grid((waves + 3) / 4), block(256);
+  if (layer == 3) {
+    if (!gp || !amax) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_dw_kernel<true, false>), grid, block, 0, st, y_l, up_g, gp, amax, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
+  } else if (layer == 2) {
+    if (!up_g) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_dw_kernel<false, false>), grid, block, 0, st, y_l, up_g, gp, amax, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
+  } else {
+    if (!up_g) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_dw_kernel<false, true>), grid, block, 0, st, y_l, up_g, gp, amax, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
+  }
+  const int total = CA * CB;
+  hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partials, dW, B * nsl, total);
+  return (int)hipGetLastError();
+}

@@ -4,10 +4,13 @@ Host-side mirror of lib/networks/encoders.py (PointNetCloudEncoder :9-28, Featur
 same constructors, attribute names and ``state_dict`` keys, so the reference's checkpoints load.
 
 PointNetCloudEncoder in eval mode under ``torch.no_grad()`` runs the fused HIP kernel (csrc/gwtf_encoder.hip: all
-SharedDot+BatchNorm+ReLU layers chained in registers on the MFMA, optional max-pool fused).  With batch-statistic
-BatchNorm (``.train()``) or when a gradient is required it is a chain of plain library GEMMs and batch-norms on the HIP
-device (torch.matmul -> rocBLAS, F.batch_norm -> MIOpen), which autograd differentiates.  CPU tensors raise: there is no
-CPU path.  The per-shape heads are (B x in) x (in x out) library GEMMs.
+SharedDot+BatchNorm+ReLU layers chained in registers on the MFMA, optional max-pool fused).  ``forward_max`` under
+``.train()`` (batch-statistic BatchNorm, what the training step runs: models.py:127-128 inside training.py:43-54) is the
+layer-at-a-time HIP pipeline of csrc/gwtf_encoder_train.hip, forward and backward (``_EncoderTrainFn``).  What is left to
+plain library GEMMs and batch-norms on the HIP device (torch.matmul -> rocBLAS, F.batch_norm -> MIOpen, differentiated by
+autograd): eval mode with a gradient required, ``forward`` (the full (B,C,N) feature map) in train mode, width lists
+without kernels, an input that itself requires a gradient.  CPU tensors raise: there is no CPU path.  The per-shape heads
+are (B x in) x (in x out) library GEMMs.
 """
 from collections import OrderedDict
 
@@ -17,6 +20,142 @@ import torch.nn as nn
 from . import _lib
 from ._lib import GwtfError, _ptr, _stream, check
 from .layers import SharedDot, Swish
+
+
+def _bn_sync(bn):
+    """True when this BatchNorm sums its batch statistics over the ranks (SyncBatchNorm after train_ae.py:152, more than
+    one rank in the default group)."""
+    import torch.distributed as dist
+    return (isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
+            and dist.get_world_size() > 1)
+
+
+class _EncoderTrainFn(torch.autograd.Function):
+    """pooled (B,512) = max over points of the train-mode encoder, csrc/gwtf_encoder_train.hip.  params = (W, bn.weight,
+    bn.bias) of the four layers; ``enc`` supplies the BatchNorm buffers (running statistics are updated in place, as
+    F.batch_norm does)."""
+
+    @staticmethod
+    def forward(ctx, x, enc, sync, *params):
+        import torch.distributed as dist
+        L = _lib.lib()
+        x = x.contiguous()
+        B, _, N = x.shape
+        dev, st = x.device, _stream(x)
+        R = _lib.STAT_REPLICAS
+        C = enc._widths
+        bns = [m for m in enc.features.children() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        Ws = [w.detach().reshape(C[l + 1], C[l]).contiguous() for l, w in enumerate(params[0::3])]
+        gam = [g.detach().contiguous() for g in params[1::3]]
+        bet = [b.detach().contiguous() for b in params[2::3]]
+        world = dist.get_world_size() if sync else 1
+        n_total = float(B * N * world)
+        f32 = dict(device=dev, dtype=torch.float32)
+        P = lambda t: 0 if t is None else _ptr(t, 'encoder buffer')
+        rm = [bn.running_mean if bn.track_running_stats else None for bn in bns]
+        rv = [bn.running_var if bn.track_running_stats else None for bn in bns]
+
+        def over_ranks(t):
+            if sync:
+                t = t.clone()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t
+
+        with torch.cuda.device(dev):
+            mom = torch.zeros(R, 12, **f32)
+            check(L.gwtf_enc_train_xmoments(P(x), P(mom), B, N, st))
+            mom_local = mom.sum(0)
+            aff = [torch.empty(4 * C[l + 1], **f32) for l in range(4)]
+            table0 = torch.empty(4 * C[1], **f32)
+            check(L.gwtf_enc_train_fold0(P(over_ranks(mom_local)), n_total, P(Ws[0]), P(gam[0]), P(bet[0]), P(rm[0]), P(rv[0]),
+                                         float(bns[0].momentum), P(aff[0]), P(table0), st))
+            units_f, units_b = [None], [None]
+            for l in (1, 2, 3):
+                n_units = L.gwtf_enc_train_units_floats(l)
+                units_f.append(torch.empty(n_units, **f32))
+                units_b.append(torch.empty(n_units, **f32))
+                check(L.gwtf_enc_train_pack(P(Ws[l]), P(units_f[l]), P(units_b[l]), l, st))
+            ys, ymax = [None], torch.zeros(4, **f32)
+            for l in (1, 2, 3):
+                y = torch.empty(B, C[l + 1], N, **f32)
+                sums = torch.zeros(R, 2, C[l + 1], **f32)
+                check(L.gwtf_enc_train_forward(l, P(x if l == 1 else ys[l - 1]), P(table0 if l == 1 else aff[l - 1]),
+                                               P(units_f[l]), P(y), P(sums), P(ymax[l:l + 1]), B, N, st))
+                check(L.gwtf_enc_train_fold(P(over_ranks(sums.sum(0))), l, n_total, P(gam[l]), P(bet[l]), P(rm[l]), P(rv[l]),
+                                            float(bns[l].momentum), P(aff[l]), st))
+                ys.append(y)
+            pooled = torch.empty(B, C[4], **f32)
+            amax = torch.empty(B, C[4], device=dev, dtype=torch.int32)
+            ystar = torch.empty(B, C[4], **f32)
+            check(L.gwtf_enc_train_pool(P(ys[3]), P(aff[3]), P(pooled), amax.data_ptr(), P(ystar), B, N, st))
+            for bn in bns:
+                if bn.track_running_stats and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+        ctx.save_for_backward(x, pooled, *params)
+        ctx.buf = dict(ys=ys, aff=aff, table0=table0, units_b=units_b, ymax=ymax, amax=amax, ystar=ystar,
+                       mom_local=mom_local, Ws=Ws, gam=gam)
+        ctx.meta = (B, N, n_total, sync, tuple(C))
+        ctx.mark_non_differentiable(amax)
+        return pooled, amax
+
+    @staticmethod
+    def backward(ctx, g_pooled, _g_amax):
+        import torch.distributed as dist
+        L = _lib.lib()
+        x, pooled, *params = ctx.saved_tensors
+        b = ctx.buf
+        B, N, n_total, sync, C = ctx.meta
+        ys, aff, Ws, gam = b['ys'], b['aff'], b['Ws'], b['gam']
+        dev, st = x.device, _stream(x)
+        R = _lib.STAT_REPLICAS
+        f32 = dict(device=dev, dtype=torch.float32)
+        P = lambda t: 0 if t is None else _ptr(t, 'encoder buffer')
+
+        def over_ranks(t):
+            if sync:
+                t = t.clone()
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t
+
+        grads = [None] * 12
+        with torch.cuda.device(dev):
+            g_pooled = g_pooled.contiguous().float()
+            gp = torch.empty(B, C[4], **f32)
+            red = torch.empty(2, C[4], **f32)
+            gmax = torch.zeros(4, **f32)
+            check(L.gwtf_enc_train_top(P(g_pooled), P(pooled), P(b['ystar']), P(aff[3]), P(gp), P(red), P(gmax[3:4]), B, st))
+            partials = torch.empty(max(L.gwtf_enc_train_dw_partial_floats(l, B, N) for l in (1, 2, 3)), **f32)
+            up = None                                   # masked dL/da_l of the layer being processed
+            for l in (3, 2, 1):
+                grads[3 * l + 1], grads[3 * l + 2] = red[1].clone(), red[0].clone()          # bn.weight, bn.bias of layer l
+                bconst = torch.empty(3 * C[l + 1] + 4, **f32)
+                check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), l, n_total, P(gam[l]), P(aff[l]),
+                                                  P(gmax[l:l + 1]), P(b['ymax'][l:l + 1]), P(bconst), st))
+                top = l == 3
+                dA = torch.empty(B, C[l], N, **f32) if l > 1 else None
+                sums = torch.zeros(R, 5 if l == 1 else 2, C[l], **f32)
+                check(L.gwtf_enc_train_backward(l, P(ys[l]), P(up), P(gp if top else None), b['amax'].data_ptr() if top else 0,
+                                                P(bconst), P(b['units_b'][l]), P(x if l == 1 else ys[l - 1]), P(aff[l - 1]),
+                                                P(Ws[0] if l == 1 else None), P(dA), P(sums),
+                                                P(gmax[l - 1:l]) if l > 1 else 0, B, N, st))
+                dW = torch.empty(C[l + 1], C[l], **f32)
+                check(L.gwtf_enc_train_dw(l, P(ys[l]), P(up), P(gp if top else None), b['amax'].data_ptr() if top else 0, P(bconst),
+                                          P(x if l == 1 else ys[l - 1]), P(b['table0'] if l == 1 else aff[l - 1]),
+                                          P(partials), P(dW), B, N, st))
+                grads[3 * l] = dW.view_as(params[3 * l])
+                red = sums.sum(0)
+                up = dA
+            # layer 0 (3 -> 64): every sum its gradient needs is already there
+            grads[1], grads[2] = red[1].clone(), red[0].clone()
+            bconst = torch.empty(3 * C[1] + 4, **f32)
+            check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), 0, n_total, P(gam[0]), P(aff[0]), 0, 0,
+                                              P(bconst), st))
+            s0, q0, r0 = bconst[:C[1]], bconst[C[1]:2 * C[1]], bconst[2 * C[1]:3 * C[1]]
+            m = b['mom_local']
+            mxx = torch.stack([m[3], m[4], m[5], m[4], m[6], m[7], m[5], m[7], m[8]]).view(3, 3)
+            dW0 = s0[:, None] * red[2:5].t() + q0[:, None] * (Ws[0] @ mxx) + r0[:, None] * m[None, :3]
+            grads[0] = dW0.view_as(params[0])
+        return (None, None, None, *grads)
 
 
 class PointNetCloudEncoder(nn.Module):
@@ -118,12 +257,41 @@ class PointNetCloudEncoder(nn.Module):
             return self.features(input)
         return self._fused(input, True, False)[0]
 
-    def forward_max(self, input):
+    def _train_pipeline_ok(self, x):
+        """The layer-at-a-time HIP train pipeline covers this call: batch-statistic BatchNorm with a momentum, the width
+        list the kernels were built for, no gradient wanted for the points themselves, N a multiple of 4."""
+        if not self.training or x.dim() != 3 or x.shape[1] != 3 or x.shape[2] % 4 or x.shape[0] == 0:
+            return False
+        if torch.is_grad_enabled() and x.requires_grad:
+            return False
+        bns = [m for m in self.features.children() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+        if any(bn.momentum is None or not bn.affine for bn in bns):
+            return False
+        w, n = self._widths_c()
+        return bool(_lib.lib().gwtf_enc_train_supported(w, n))
+
+    def _train_params(self):
+        out = []
+        for mod in self.features.children():
+            if isinstance(mod, SharedDot):
+                out.append(mod.weight)
+            elif isinstance(mod, nn.modules.batchnorm._BatchNorm):
+                out += [mod.weight, mod.bias]
+        return out
+
+    def forward_max(self, input, return_indices=False):
         """(B,3,N) -> (B,C_last): features max-pooled over points, what models.py:127-128 consumes; eval/no-grad never
-        materialises the (B,C_last,N) tensor."""
+        materialises the (B,C_last,N) tensor, train mode runs csrc/gwtf_encoder_train.hip (forward and backward)."""
         _ptr(input if input.is_contiguous() else input.contiguous(), 'input')
+        if self._train_pipeline_ok(input):
+            bns = [m for m in self.features.children() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
+            pooled, amax = _EncoderTrainFn.apply(input, self, _bn_sync(bns[0]), *self._train_params())
+            return (pooled, amax) if return_indices else pooled
         if self._needs_graph(input):
-            return torch.max(self.features(input), dim=2)[0]
+            pooled, amax = torch.max(self.features(input), dim=2)
+            return (pooled, amax) if return_indices else pooled
+        if return_indices:
+            raise GwtfError('arg-max indices are not produced by the fused eval kernel')
         return self._fused(input, False, True)[1]
 
 

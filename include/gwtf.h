@@ -324,6 +324,54 @@ int gwtf_encoder_pack(const float* raw, float* packed, const int* widths, int n_
 int gwtf_encoder_forward(const float* x, const float* packed, float* features, float* pooled, int B, int N,
                          const int* widths, int n_widths, void* stream);
 
+/* PointNet cloud encoder 3-64-128-256-512 under model.train() (batch-statistic BatchNorm1d; SyncBatchNorm = sum the
+ * statistic arrays over the ranks between a kernel and its fold), max-pooled, forward AND backward, layer at a time.
+ * Replaces, for lib/networks/encoders.py:9-28 + models.py:127-128 inside the training step (training.py:43-54), the chain of
+ * library GEMM / batch-norm / elementwise calls and their autograd.  Channel counts C = {3, 64, 128, 256, 512}: layer l maps
+ * C[l] -> C[l+1] channels with weight W_l [C[l+1]][C[l]]; kernels exist for layer = 1..3 (layer 0, 3 -> 64, is three FMAs
+ * folded into layer 1's prologue).  All activations are the reference's (B, C, N) fp32 tensors.
+ *   aff     [4][C]  = s, t, mean, rstd of a layer's BatchNorm (a = relu(s y + t));  table0 [64][4] = (s W_0 row, t)
+ *   sums    replicated accumulators, zero on entry: the caller sums the 64 replicas (and the ranks) before the fold
+ *   bconst  [3][C] + 4: dy = s gm + Q y + R per channel, then {up, down} = the power-of-two scale of the f16-split operand
+ * gwtf_enc_train_supported(widths, n) -> 1 when this width list has kernels. */
+int gwtf_enc_train_supported(const int* widths, int n_widths);
+size_t gwtf_enc_train_units_floats(int layer);
+/* W [C[l+1]][C[l]] -> MFMA fragment images of W (forward) and W^T (backward), gwtf_enc_train_units_floats(layer) floats each */
+int gwtf_enc_train_pack(const float* W, float* units_fwd, float* units_bwd, int layer, void* stream);
+/* mom [64][12] += {sum x (3), sum x x^T (xx xy xz yy yz zz), -} over this rank's points */
+int gwtf_enc_train_xmoments(const float* x, float* mom, int B, int N, void* stream);
+/* layer 0: batch statistics of y_0 = W_0 x from the summed moments mom12; updates the running statistics (NULL: skip) */
+int gwtf_enc_train_fold0(const float* mom12, double n_total, const float* W0, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float* aff, float* table0, void* stream);
+/* sums [2][C[layer+1]] = sum y, sum y^2 -> aff of that layer's BatchNorm; running statistics updated (momentum, unbiased var) */
+int gwtf_enc_train_fold(const float* sums, int layer, double n_total, const float* gamma, const float* beta,
+                        float* running_mean, float* running_var, float momentum, float* aff, void* stream);
+/* y_out (B, C[layer+1], N) = W_layer . relu(s in + t); in = x and in_tab = table0 for layer 1, else y_{layer-1} and its aff.
+ * sums [64][2][C[layer+1]] += {sum y, sum y^2}; ymax[0] = max |y| (bit pattern max, zero on entry) */
+int gwtf_enc_train_forward(int layer, const float* in, const float* in_tab, const float* units, float* y_out, float* sums,
+                           float* ymax, int B, int N, void* stream);
+/* pooled (B,512) = max_n relu(s y3 + t), amax = its (first) arg-max, ystar = y3 there */
+int gwtf_enc_train_pool(const float* y3, const float* aff3, float* pooled, int* amax, float* ystar, int B, int N, void* stream);
+/* gp = g_pooled where pooled > 0; sums [2][512] = {sum gp, sum gp yhat*}; gmax[0] = max |gp| (zero on entry) */
+int gwtf_enc_train_top(const float* g_pooled, const float* pooled, const float* ystar, const float* aff3, float* gp, float* sums,
+                       float* gmax, int B, void* stream);
+/* layer = 0..3 (BatchNorm of y_layer): sums [2][C[layer+1]] = {sum gm, sum gm yhat} over all points and ranks -> bconst;
+ * gmax / ymax (may be NULL for layer 0): the maxima the operand scale is derived from */
+int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, const float* gamma, const float* aff,
+                              const float* gmax, const float* ymax, float* bconst, void* stream);
+/* dA_prev (B, C[layer], N) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
+ * (y_l, up_g = masked dL/da_layer) or, layer 3, (gp, amax).  y_prev / aff_prev: y_{layer-1} and its aff (layer 1: x, aff_0, and
+ * w0 = raw W_0).  sums [64][2 (layer 1: 5)][C[layer]] += {sum gm, sum gm yhat (, sum gm x_d)} of the layer below;
+ * gmax_prev[0] = max |dA_prev| */
+int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax,
+                            const float* bconst, const float* units_bwd, const float* y_prev, const float* aff_prev,
+                            const float* w0, float* dA_prev, float* sums, float* gmax_prev, int B, int N, void* stream);
+/* dW (C[layer+1], C[layer]) = sum over this rank's points of dy_layer a_{layer-1}^T; partials: scratch of
+ * gwtf_enc_train_dw_partial_floats floats; tab_prev = aff_{layer-1} (layer 1: table0, y_prev = x).  N % 4 == 0. */
+size_t gwtf_enc_train_dw_partial_floats(int layer, int B, int N);
+int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax, const float* bconst,
+                      const float* y_prev, const float* tab_prev, float* partials, float* dW, int B, int N, void* stream);
+
 /* Global prior flow on the shape latent: the whole GlobalRNVPDecoder (lib/networks/decoders.py:7-38; RealNVPFlowCouple /
  * RealNVPFlow, flows.py:163-243) as ONE launch per direction -- forward (the lists the reference returns) and backward
  * (every parameter, the input, gradients entering through any gs[j] / logvars[j] slot), eval- or train-mode BatchNorm.

@@ -526,6 +526,32 @@ def contract():
     print('contract.json', len(spec), 'entries')
 
 
+def g17_encoder_train():
+    """The reference PointNet encoder + max-pool under model.train(): pooled code, every BatchNorm's running statistics
+    after one step and the gradient of a weighted sum of the pooled code w.r.t. all 12 parameter tensors (fp32 as the
+    reference runs, and the same in fp64 for the noise floor).  N a multiple of 4: what the HIP train pipeline covers."""
+    from lib.networks import encoders as renc
+    from go_with_the_flows_amd import encoders as oenc
+    out = {}
+    for tag, B, N, seed in (('a', 3, 72, 1700), ('b', 2, 260, 1710)):
+        x, _ = synth_inputs(B, N, 4, seed + 1)
+        wgt = np.random.default_rng(seed + 2).standard_normal((B, 512)).astype(np.float32)
+        out[f'{tag}_x'], out[f'{tag}_wgt'] = x, wgt
+        for dt, suffix in ((torch.float32, ''), (torch.float64, '_f64')):
+            ref, mine = renc.PointNetCloudEncoder(3, 64, [128, 256, 512]), oenc.PointNetCloudEncoder(3, 64, [128, 256, 512])
+            load_into(ref, mine, seed)
+            ref = ref.to(dt).train()
+            pooled = torch.max(ref(T(x).to(dt)), dim=2)[0]
+            (pooled * T(wgt).to(dt)).sum().backward()
+            out[f'{tag}_pooled{suffix}'] = npy(pooled).astype(np.float64 if suffix else np.float32)
+            for name, prm in ref.named_parameters():
+                out[f'{tag}_grad{suffix}.{name}'] = npy(prm.grad).astype(np.float32)     # fp64 run rounded once
+            if not suffix:
+                for name, buf in ref.named_buffers():
+                    out[f'{tag}_buf.{name}'] = npy(buf)
+    save('g17_encoder_train', **out)
+
+
 CASES = {
     'contract': contract,
     'g1': g1_single_couplings,
@@ -542,6 +568,7 @@ CASES = {
     'g9': g9_train_gradients,
     'g10': g10_optimizer,
     'g11': g11_encoder,
+    'g17': g17_encoder_train,
     'g12': g12_prior,
     'g13': g13_full_model,
     'g14': g14_evaluation_metrics,

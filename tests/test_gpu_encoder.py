@@ -108,3 +108,87 @@ def test_full_size_properties():
     assert torch.equal(pooled, pooled_p)            # max is order-independent and each point's arithmetic is identical
     assert torch.equal(feat.max(2)[0], pooled)
     assert float(pooled.min()) >= 0
+
+
+# ---- train-mode pipeline (csrc/gwtf_encoder_train.hip): batch-statistic BatchNorm forward + max-pool + the whole backward ----
+def _train_case(tag):
+    G = golden('g17_encoder_train')
+    seed = {'a': 1700, 'b': 1710}[tag]
+    m = encoders.PointNetCloudEncoder(3, 64, [128, 256, 512])
+    load_synth_(m, seed)
+    return G, m.to(DEV).train(), dev(G[f'{tag}_x']), dev(G[f'{tag}_wgt'])
+
+
+@pytest.mark.parametrize('tag', ['a', 'b'])
+def test_train_pipeline_matches_reference_golden(tag):
+    """Pooled code, running statistics of all four BatchNorms and the gradient of every parameter against the genuine
+    reference (fp32 run; its own fp64 run gives the noise floor: pooled 4e-6, gradients 1e-6 relative)."""
+    G, m, x, wgt = _train_case(tag)
+    assert m._train_pipeline_ok(x)                                   # the HIP pipeline is what runs
+    pooled = m.forward_max(x)
+    assert pooled.grad_fn is not None and 'EncoderTrainFn' in type(pooled.grad_fn).__name__
+    ref64 = G[f'{tag}_pooled_f64']
+    scale = max(1.0, float(np.abs(ref64).max()))
+    err, ref_err = maxabs(host(pooled), ref64), maxabs(G[f'{tag}_pooled'], ref64)
+    assert err < 2e-5 * scale and err < max(3 * ref_err, 1e-5 * scale)
+    for name, buf in m.named_buffers():
+        want = G[f'{tag}_buf.{name}']
+        if name.endswith('num_batches_tracked'):
+            assert int(buf) == int(want)
+        else:
+            assert maxabs(host(buf), want) < 2e-5 * max(1.0, float(np.abs(want).max())), name
+    (pooled * wgt).sum().backward()
+    worst = {}
+    for name, prm in m.named_parameters():
+        want = G[f'{tag}_grad_f64.{name}']
+        gs = float(np.abs(want).max())
+        worst[name] = maxabs(host(prm.grad), want) / gs
+        assert worst[name] < 2e-4, (name, worst[name])               # split-f16 operands carry 22 bits; sums over B N points
+    from conftest import record_parity
+    record_parity(f'encoder_train_{tag}', pooled=err, pooled_ref32=ref_err, grad_rel_max=max(worst.values()))
+
+
+def test_train_pipeline_against_library_path_at_ragged_and_full_sizes():
+    """Same module through the library path (rocBLAS GEMM + MIOpen batch-norm + autograd, an independent implementation):
+    N not a multiple of the 256-point tile, and the airplane batch 64 x 2048."""
+    for B, N, seed in ((2, 1000, 31), (64, 2048, 32)):
+        m = encoders.PointNetCloudEncoder(3, 64, [128, 256, 512])
+        load_synth_(m, seed)
+        m = m.to(DEV).train()
+        x = dev(synth_inputs(B, N, 4, seed + 1)[0])
+        wgt = torch.randn(B, 512, device=DEV, generator=torch.Generator(DEV).manual_seed(seed))
+        import copy
+        lib = copy.deepcopy(m)
+        pooled = m.forward_max(x)
+        (pooled * wgt).sum().backward()
+        ref = torch.max(lib.features(x), dim=2)[0]
+        (ref * wgt).sum().backward()
+        scale = max(1.0, float(ref.detach().abs().max()))
+        assert float((pooled - ref).abs().max()) < 5e-5 * scale
+        for (name, p), q in zip(m.named_parameters(), lib.parameters()):
+            gs = float(q.grad.abs().max())
+            assert float((p.grad - q.grad).abs().max()) < 1e-3 * gs, (B, N, name)
+        for (name, a), b in zip(m.named_buffers(), lib.buffers()):
+            assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5), name
+
+
+def test_train_pipeline_small_gradients_keep_their_precision():
+    """A loss scaled by 1e-7 (gradients near the f16 subnormals): the power-of-two operand scale keeps the relative error."""
+    G, m, x, wgt = _train_case('a')
+    (m.forward_max(x) * wgt * 1e-7).sum().backward()
+    for name, prm in m.named_parameters():
+        want = G[f'a_grad_f64.{name}'] * 1e-7
+        assert maxabs(host(prm.grad), want) / float(np.abs(want).max()) < 2e-4, name
+
+
+def test_train_pipeline_falls_back_to_the_library_path_outside_its_cover():
+    m = encoders.PointNetCloudEncoder(3, 64, [128, 256, 512]).to(DEV).train()
+    x = dev(synth_inputs(2, 70, 4, 3)[0])                            # N % 4 != 0
+    assert not m._train_pipeline_ok(x)
+    assert m.forward_max(x).shape == (2, 512)
+    x4 = dev(synth_inputs(2, 72, 4, 3)[0]).requires_grad_()          # gradient wanted for the points themselves
+    assert not m._train_pipeline_ok(x4)
+    m.forward_max(x4).sum().backward()
+    assert x4.grad is not None
+    m.features.sd1_bn.momentum = None                                # cumulative-average BatchNorm
+    assert not m._train_pipeline_ok(x4.detach())
