@@ -80,7 +80,8 @@ _SIGNATURES = {
     'gwtf_enc_train_bwd_consts': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 5 + [_c_fp]),
     'gwtf_enc_train_backward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 12 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_dw_partial_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
-    'gwtf_enc_train_dw': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 9 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_dw': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 7 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_dw3': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_prior_raw_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'gwtf_prior_raw_offset': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'gwtf_prior_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),

@@ -387,7 +387,7 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
                                                                  const float* __restrict__ w0, float* __restrict__ dA_prev,
                                                                  float* __restrict__ sums, float* __restrict__ gmax_prev, int B,
                                                                  int N) {
-  constexpr int KS = COUT / 32, MT = CIN / 16, TM = 16 / KS, NCH = MT / TM, NS = BOTTOM ? 5 : 2;
+  constexpr int KS = COUT / 32, MT = CIN / 16, TM = 16 / KS, NCH = MT / TM, NS = BOTTOM ? 5 : (TOP ? 3 : 2);
   static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
   __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
   __shared__ __attribute__((aligned(16))) float bc[3 * COUT];
@@ -500,8 +500,10 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
           } else {
             yv = valid[nb] ? y_prev[((size_t)b * CIN + j) * N + n[nb]] : 0.f;
           }
-          const bool on = valid[nb] && fmaf(sp[r], yv, tp[r]) > 0.f;
+          const float pre = fmaf(sp[r], yv, tp[r]);
+          const bool on = valid[nb] && pre > 0.f;
           const float gm = on ? acc[nb][r] * down : 0.f;
+          if (TOP) sx0 += on ? pre : 0.f;                  // sum_p a_{l-1}: the R term of dW_3 (gwtf_enc_train_dw3)
           if (!BOTTOM && valid[nb]) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
           sb += gm;
           sg = fmaf(gm, (yv - mp[r]) * rp[r], sg);
@@ -519,9 +521,11 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
           sx1 = row_sum16(sx1);
           sx2 = row_sum16(sx2);
         }
+        if (TOP) sx0 = row_sum16(sx0);
         if (i16 == 0) {
           atomicAdd(&wsum[0][j], sb);
           atomicAdd(&wsum[1][j], sg);
+          if (TOP) atomicAdd(&wsum[2][j], sx0);
           if (BOTTOM) {
             atomicAdd(&wsum[2][j], sx0);
             atomicAdd(&wsum[3][j], sx1);
@@ -562,9 +566,10 @@ __device__ __forceinline__ void load8(const float* row, int n0, int p1, float (&
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
 }
 
-template <bool TOP, bool FIRST>
+// AMODE 0: A = dy_l from (y_l, up_g);  AMODE 2: A = a_l = relu(s y_l + t) (the Gram matrix of layer 3's input: bconst = aff,
+// no operand scale)
+template <int AMODE, bool FIRST>
 __global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
-                                                           const float* __restrict__ gp, const int* __restrict__ amax,
                                                            const float* __restrict__ bconst, const float* __restrict__ y_prev,
                                                            const float* __restrict__ tab_prev, float* __restrict__ partials, int B,
                                                            int N, int CA, int CB, int nsl, int per) {
@@ -575,16 +580,13 @@ __global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restri
   if (sl >= B * nsl) return;
   const int bm = blk / nbn, bn = blk % nbn, b = sl / nsl, part = sl % nsl;
   const int p0 = part * per, p1 = min(N, p0 + per);
-  const float up = bconst[3 * CA], down = bconst[3 * CA + 1];
+  const float up = AMODE == 2 ? 1.0f : bconst[3 * CA], down = AMODE == 2 ? 1.0f : bconst[3 * CA + 1];
 
-  float sA[4], qA[4], rA[4], gpv[4], sB[4], tB[4], wB[4][3];
-  int amv[4];
+  float sA[4], qA[4], rA[4], sB[4], tB[4], wB[4][3];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int c = 64 * bm + 16 * mt + i16;
-    sA[mt] = bconst[c] * up; qA[mt] = bconst[CA + c] * up; rA[mt] = bconst[2 * CA + c] * up;
-    gpv[mt] = TOP ? gp[(size_t)b * CA + c] : 0.f;
-    amv[mt] = TOP ? amax[(size_t)b * CA + c] : -1;
+    sA[mt] = bconst[c] * up; qA[mt] = bconst[CA + c] * up; rA[mt] = AMODE == 2 ? 0.f : bconst[2 * CA + c] * up;
   }
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
@@ -611,16 +613,17 @@ __global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restri
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       const size_t row = ((size_t)b * CA + 64 * bm + 16 * mt + i16) * N;
-      float yv[8], gm[8], d[8];
+      float yv[8], d[8];
       load8(y_l + row, n0, p1, yv);
-      if (TOP) {
+      if (AMODE == 2) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) gm[e] = (n0 + e == amv[mt]) ? gpv[mt] : 0.f;
+        for (int e = 0; e < 8; ++e) d[e] = (n0 + (e & 4) < p1) ? fmaxf(fmaf(sA[mt], yv[e], qA[mt]), 0.f) : 0.f;
       } else {
+        float gm[8];
         load8(up_g + row, n0, p1, gm);
-      }
 #pragma unroll
-      for (int e = 0; e < 8; ++e) d[e] = (n0 + (e & 4) < p1) ? fmaf(sA[mt], gm[e], fmaf(qA[mt], yv[e], rA[mt])) : 0.f;
+        for (int e = 0; e < 8; ++e) d[e] = (n0 + (e & 4) < p1) ? fmaf(sA[mt], gm[e], fmaf(qA[mt], yv[e], rA[mt])) : 0.f;
+      }
       split8(d, ahi[mt], alo[mt]);
     }
 #pragma unroll
@@ -659,6 +662,22 @@ __global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         out[(size_t)(64 * bm + 16 * mt + 4 * q + r) * CB + 64 * bn + 16 * nt + i16] = acc[mt][nt][r] * down;
+}
+
+// S[c][k] = sum_b gp[b][c] a_2[k](b, amax[b][c]): the arg-max part of dW_3 (one workgroup per output channel c, a thread per k)
+__global__ __launch_bounds__(256) void enc_top_gather_kernel(const float* __restrict__ gp, const int* __restrict__ amax,
+                                                             const float* __restrict__ y_prev, const float* __restrict__ aff_prev,
+                                                             float* __restrict__ S, int B, int N, int C, int CP) {
+  const int c = blockIdx.x;
+  for (int k = threadIdx.x; k < CP; k += blockDim.x) {
+    const float s = aff_prev[k], t = aff_prev[CP + k];
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float g = gp[(size_t)b * C + c];
+      if (g != 0.f) acc = fmaf(g, fmaxf(fmaf(s, y_prev[((size_t)b * CP + k) * N + amax[(size_t)b * C + c]], t), 0.f), acc);
+    }
+    S[(size_t)c * CP + k] = acc;
+  }
 }
 
 __global__ __launch_bounds__(256) void enc_dw_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out, int slices,
@@ -789,29 +808,41 @@ extern "C" int gwtf_enc_train_backward(int layer, const float* y_l, const float*
 
 extern "C" size_t gwtf_enc_train_dw_partial_floats(int layer, int B, int N) {
   if (layer < 1 || layer > 3 || B <= 0 || N <= 0) return 0;
-  return (size_t)B * dw_slices_per_shape(layer) * kC[layer + 1] * kC[layer];
+  // layer 3 goes through the Gram matrix of a_2 (C[3] x C[3]); see gwtf_enc_train_dw3
+  const int CA = layer == 3 ? kC[3] : kC[layer + 1];
+  return (size_t)B * dw_slices_per_shape(layer) * CA * kC[layer];
 }
 
-extern "C" int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax,
-                                 const float* bconst, const float* y_prev, const float* tab_prev, float* partials, float* dW, int B,
-                                 int N, void* stream) {
-  if (!y_l || !bconst || !y_prev || !tab_prev || !partials || !dW || B <= 0 || N <= 0 || (N & 3) || layer < 1 || layer > 3)
+extern "C" int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const float* bconst, const float* y_prev,
+                                 const float* tab_prev, float* partials, float* dW, int B, int N, void* stream) {
+  if (!y_l || !up_g || !bconst || !y_prev || !tab_prev || !partials || !dW || B <= 0 || N <= 0 || (N & 3) || layer < 1 || layer > 2)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int CA = kC[layer + 1], CB = kC[layer], nsl = dw_slices_per_shape(layer), per = dw_per(layer, N);
   const int waves = (CA / 64) * (CB / 64) * B * nsl;
   const dim3 grid((waves + 3) / 4), block(256);
-  if (layer == 3) {
-    if (!gp || !amax) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_dw_kernel<true, false>), grid, block, 0, st, y_l, up_g, gp, amax, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
-  } else if (layer == 2) {
-    if (!up_g) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_dw_kernel<false, false>), grid, block, 0, st, y_l, up_g, gp, amax, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
-  } else {
-    if (!up_g) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_dw_kernel<false, true>), grid, block, 0, st, y_l, up_g, gp, amax, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
-  }
+  if (layer == 2)
+    hipLaunchKernelGGL((enc_train_dw_kernel<0, false>), grid, block, 0, st, y_l, up_g, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
+  else
+    hipLaunchKernelGGL((enc_train_dw_kernel<0, true>), grid, block, 0, st, y_l, up_g, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
   const int total = CA * CB;
   hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partials, dW, B * nsl, total);
+  return (int)hipGetLastError();
+}
+
+// The top layer's weight gradient without a contraction over its 512 output channels: with dy_3 = s gm_3 + Q y_3 + R and
+// y_3 = W_3 a_2,   dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2,   S[c][:] = sum_b gp[b][c] a_2(b, amax[b][c]) (gm_3 is
+// non-zero at the arg-max points only), G_2 = sum_p a_2 a_2^T.  This call leaves G_2 (256 x 256) and S (512 x 256); the caller
+// finishes with one small library GEMM (W_3 G_2) -- half the matrix work of the direct product and no pass over y_3.
+extern "C" int gwtf_enc_train_dw3(const float* gp, const int* amax, const float* y2, const float* aff2, float* partials,
+                                  float* gram, float* S, int B, int N, void* stream) {
+  if (!gp || !amax || !y2 || !aff2 || !partials || !gram || !S || B <= 0 || N <= 0 || (N & 3)) return GWTF_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int C2 = kC[3], nsl = dw_slices_per_shape(3), per = dw_per(3, N);
+  const int waves = (C2 / 64) * (C2 / 64) * B * nsl;
+  hipLaunchKernelGGL((enc_train_dw_kernel<2, false>), dim3((waves + 3) / 4), dim3(256), 0, st, y2, nullptr, aff2, y2, aff2, partials,
+                     B, N, C2, C2, nsl, per);
+  hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((C2 * C2 + 255) / 256), dim3(256), 0, st, partials, gram, B * nsl, C2 * C2);
+  hipLaunchKernelGGL(enc_top_gather_kernel, dim3(kC[4]), dim3(256), 0, st, gp, amax, y2, aff2, S, B, N, kC[4], C2);
   return (int)hipGetLastError();
 }

@@ -133,17 +133,24 @@ class _EncoderTrainFn(torch.autograd.Function):
                                                   P(gmax[l:l + 1]), P(b['ymax'][l:l + 1]), P(bconst), st))
                 top = l == 3
                 dA = torch.empty(B, C[l], N, **f32) if l > 1 else None
-                sums = torch.zeros(R, 5 if l == 1 else 2, C[l], **f32)
+                sums = torch.zeros(R, {1: 5, 2: 2, 3: 3}[l], C[l], **f32)
                 check(L.gwtf_enc_train_backward(l, P(ys[l]), P(up), P(gp if top else None), b['amax'].data_ptr() if top else 0,
                                                 P(bconst), P(b['units_b'][l]), P(x if l == 1 else ys[l - 1]), P(aff[l - 1]),
                                                 P(Ws[0] if l == 1 else None), P(dA), P(sums),
                                                 P(gmax[l - 1:l]) if l > 1 else 0, B, N, st))
-                dW = torch.empty(C[l + 1], C[l], **f32)
-                check(L.gwtf_enc_train_dw(l, P(ys[l]), P(up), P(gp if top else None), b['amax'].data_ptr() if top else 0, P(bconst),
-                                          P(x if l == 1 else ys[l - 1]), P(b['table0'] if l == 1 else aff[l - 1]),
-                                          P(partials), P(dW), B, N, st))
+                red_below = sums.sum(0)
+                if top:     # dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2  (csrc/gwtf_encoder_train.hip: gwtf_enc_train_dw3)
+                    gram, S = torch.empty(C[3], C[3], **f32), torch.empty(C[4], C[3], **f32)
+                    check(L.gwtf_enc_train_dw3(P(gp), b['amax'].data_ptr(), P(ys[2]), P(aff[2]), P(partials), P(gram), P(S),
+                                               B, N, st))
+                    s3, q3, r3 = (bconst[i * C[4]:(i + 1) * C[4], None] for i in range(3))
+                    dW = s3 * S + q3 * (Ws[3] @ gram) + r3 * red_below[2][None, :]
+                else:
+                    dW = torch.empty(C[l + 1], C[l], **f32)
+                    check(L.gwtf_enc_train_dw(l, P(ys[l]), P(up), P(bconst), P(x if l == 1 else ys[l - 1]),
+                                              P(b['table0'] if l == 1 else aff[l - 1]), P(partials), P(dW), B, N, st))
                 grads[3 * l] = dW.view_as(params[3 * l])
-                red = sums.sum(0)
+                red = red_below
                 up = dA
             # layer 0 (3 -> 64): every sum its gradient needs is already there
             grads[1], grads[2] = red[1].clone(), red[0].clone()

@@ -361,16 +361,22 @@ int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, cons
                               const float* gmax, const float* ymax, float* bconst, void* stream);
 /* dA_prev (B, C[layer], N) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
  * (y_l, up_g = masked dL/da_layer) or, layer 3, (gp, amax).  y_prev / aff_prev: y_{layer-1} and its aff (layer 1: x, aff_0, and
- * w0 = raw W_0).  sums [64][2 (layer 1: 5)][C[layer]] += {sum gm, sum gm yhat (, sum gm x_d)} of the layer below;
+ * w0 = raw W_0).  sums [64][2 (layer 3: 3, layer 1: 5)][C[layer]] += {sum gm, sum gm yhat (layer 3: , sum a) (layer 1: , sum gm x_d)} of the
+ * layer below;
  * gmax_prev[0] = max |dA_prev| */
 int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax,
                             const float* bconst, const float* units_bwd, const float* y_prev, const float* aff_prev,
                             const float* w0, float* dA_prev, float* sums, float* gmax_prev, int B, int N, void* stream);
-/* dW (C[layer+1], C[layer]) = sum over this rank's points of dy_layer a_{layer-1}^T; partials: scratch of
+/* layer = 1, 2: dW (C[layer+1], C[layer]) = sum over this rank's points of dy_layer a_{layer-1}^T; partials: scratch of
  * gwtf_enc_train_dw_partial_floats floats; tab_prev = aff_{layer-1} (layer 1: table0, y_prev = x).  N % 4 == 0. */
 size_t gwtf_enc_train_dw_partial_floats(int layer, int B, int N);
-int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax, const float* bconst,
-                      const float* y_prev, const float* tab_prev, float* partials, float* dW, int B, int N, void* stream);
+int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const float* bconst, const float* y_prev,
+                      const float* tab_prev, float* partials, float* dW, int B, int N, void* stream);
+/* layer 3 through the Gram matrix: gram (256,256) = sum_p a_2 a_2^T, S (512,256)[c] = sum_b gp[b][c] a_2(b, amax[b][c]); then
+ * dW_3 = s (.) S + Q (.) (W_3 gram) + R (x) sum_p a_2  (s, Q, R = bconst of layer 3; sum_p a_2 = row 2 of the sums that
+ * gwtf_enc_train_backward(layer 3) accumulates). */
+int gwtf_enc_train_dw3(const float* gp, const int* amax, const float* y2, const float* aff2, float* partials, float* gram,
+                       float* S, int B, int N, void* stream);
 
 /* Global prior flow on the shape latent: the whole GlobalRNVPDecoder (lib/networks/decoders.py:7-38; RealNVPFlowCouple /
  * RealNVPFlow, flows.py:163-243) as ONE launch per direction -- forward (the lists the reference returns) and backward
