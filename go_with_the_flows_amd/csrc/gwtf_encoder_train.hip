@@ -566,84 +566,128 @@ __device__ __forceinline__ void load8(const float* row, int n0, int p1, float (&
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
 }
 
-// AMODE 0: A = dy_l from (y_l, up_g);  AMODE 2: A = a_l = relu(s y_l + t) (the Gram matrix of layer 3's input: bconst = aff,
-// no operand scale)
-template <int AMODE, bool FIRST>
-__global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
-                                                           const float* __restrict__ bconst, const float* __restrict__ y_prev,
-                                                           const float* __restrict__ tab_prev, float* __restrict__ partials, int B,
-                                                           int N, int CA, int CB, int nsl, int per) {
-  const int lane = threadIdx.x & 63, i16 = lane & 15, q = lane >> 4;
-  const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int nbn = CB / 64, nblk = (CA / 64) * nbn;
-  const int blk = w % nblk, sl = w / nblk;
-  if (sl >= B * nsl) return;
-  const int bm = blk / nbn, bn = blk % nbn, b = sl / nsl, part = sl % nsl;
+// One workgroup = WM x WN wavefronts = the WHOLE (64 WM) x (64 WN) matrix over one slice of the points; a wavefront owns a
+// 64 x 64 block.  Per k-step of 32 points every thread produces a few operand fragments (a fragment lane = one channel x 8
+// consecutive points: two 16-byte loads per source array, the per-channel transform, the f16 hi/lo split) into a
+// double-buffered LDS image laid out in MFMA fragment order, so each element is loaded, transformed and split ONCE per
+// workgroup and every consumer read is one conflict-free ds_read_b128.  One barrier per k-step.
+// AMODE 0: A = dy_l = s gm + Q y + R from (y_l, up_g), scaled by `up`;  AMODE 2: A = a_l = relu(s y_l + t) and B IS A (the Gram
+// matrix of layer 3's input; bconst = that layer's aff).  FIRST: B = a_0 = relu(W_0' x + t_0) from x and table0.
+template <int WM, int WN, int AMODE, bool FIRST>
+__global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
+                                                                    const float* __restrict__ bconst,
+                                                                    const float* __restrict__ y_prev,
+                                                                    const float* __restrict__ tab_prev, float* __restrict__ partials,
+                                                                    int B, int N, int nsl, int per) {
+  constexpr int CA = 64 * WM, CB = 64 * WN, NT = 64 * WM * WN;
+  constexpr bool SAME = AMODE == 2;
+  constexpr int TA = CA / 16, TB = SAME ? 0 : CB / 16;          // 16-row fragment tiles in the LDS image
+  constexpr int IA = CA * 4 / NT, IB = SAME ? 0 : CB * 4 / NT;   // producer items (row, q) per thread and k-step
+  static_assert(CA * 4 % NT == 0 && (SAME || CB * 4 % NT == 0), "whole items per thread");
+  __shared__ uint4 img[2][(TA + TB) * 2 * 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int sl = blockIdx.x, b = sl / nsl, part = sl % nsl;
   const int p0 = part * per, p1 = min(N, p0 + per);
-  const float up = AMODE == 2 ? 1.0f : bconst[3 * CA], down = AMODE == 2 ? 1.0f : bconst[3 * CA + 1];
+  const float up = SAME ? 1.0f : bconst[3 * CA], down = SAME ? 1.0f : bconst[3 * CA + 1];
 
-  float sA[4], qA[4], rA[4], sB[4], tB[4], wB[4][3];
+  // producer constants: item i of this thread is row (tid + NT i) >> 2, point group (tid + NT i) & 3
+  float cA0[IA], cA1[IA], cA2[IA], cB0[IB > 0 ? IB : 1], cB1[IB > 0 ? IB : 1], cB2[IB > 0 ? IB : 1], cB3[IB > 0 ? IB : 1];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int c = 64 * bm + 16 * mt + i16;
-    sA[mt] = bconst[c] * up; qA[mt] = bconst[CA + c] * up; rA[mt] = AMODE == 2 ? 0.f : bconst[2 * CA + c] * up;
+  for (int i = 0; i < IA; ++i) {
+    const int row = (tid + NT * i) >> 2;
+    cA0[i] = bconst[row] * up;
+    cA1[i] = bconst[CA + row] * up;
+    cA2[i] = SAME ? 0.f : bconst[2 * CA + row] * up;
   }
 #pragma unroll
-  for (int nt = 0; nt < 4; ++nt) {
-    const int k = 64 * bn + 16 * nt + i16;
+  for (int i = 0; i < IB; ++i) {
+    const int row = (tid + NT * i) >> 2;
     if (FIRST) {
-      wB[nt][0] = tab_prev[4 * k]; wB[nt][1] = tab_prev[4 * k + 1]; wB[nt][2] = tab_prev[4 * k + 2];
-      tB[nt] = tab_prev[4 * k + 3];
-      sB[nt] = 0.f;
+      cB0[i] = tab_prev[4 * row]; cB1[i] = tab_prev[4 * row + 1]; cB2[i] = tab_prev[4 * row + 2]; cB3[i] = tab_prev[4 * row + 3];
     } else {
-      sB[nt] = tab_prev[k];
-      tB[nt] = tab_prev[CB + k];
-      wB[nt][0] = wB[nt][1] = wB[nt][2] = 0.f;
+      cB0[i] = tab_prev[row]; cB1[i] = tab_prev[CB + row]; cB2[i] = cB3[i] = 0.f;
     }
   }
+
+  float rA[IA][8], rG[SAME ? 1 : IA][8], rB[IB > 0 ? IB : 1][FIRST ? 3 : 1][8];
+  auto fetch = [&](int p) {
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int it = tid + NT * i, row = it >> 2, n0 = p + 8 * (it & 3);
+      load8((SAME ? y_prev : y_l) + ((size_t)b * CA + row) * N, n0, p1, rA[i]);
+      if (!SAME) load8(up_g + ((size_t)b * CA + row) * N, n0, p1, rG[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int it = tid + NT * i, row = it >> 2, n0 = p + 8 * (it & 3);
+      if (FIRST) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) load8(y_prev + ((size_t)b * 3 + d) * N, n0, p1, rB[i][d]);
+      } else {
+        load8(y_prev + ((size_t)b * CB + row) * N, n0, p1, rB[i][0]);
+      }
+    }
+  };
+  auto produce = [&](int buf, int p) {
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+      const int it = tid + NT * i, row = it >> 2, qq = it & 3, n0 = p + 8 * qq;
+      float d[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool on = n0 + (e & 4) < p1;
+        if (SAME) d[e] = on ? fmaxf(fmaf(cA0[i], rA[i][e], cA1[i]), 0.f) : 0.f;
+        else d[e] = on ? fmaf(cA0[i], rG[i][e], fmaf(cA1[i], rA[i][e], cA2[i])) : 0.f;
+      }
+      f16x8 hi, lo;
+      split8(d, hi, lo);
+      const int slot = ((row >> 4) * 2) * 64 + (row & 15) + 16 * qq;
+      img[buf][slot] = __builtin_bit_cast(uint4, hi);
+      img[buf][slot + 64] = __builtin_bit_cast(uint4, lo);
+    }
+#pragma unroll
+    for (int i = 0; i < IB; ++i) {
+      const int it = tid + NT * i, row = it >> 2, qq = it & 3, n0 = p + 8 * qq;
+      float d[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool on = n0 + (e & 4) < p1;
+        const float pre = FIRST ? cB0[i] * rB[i][0][e] + (cB1[i] * rB[i][FIRST ? 1 : 0][e] + (cB2[i] * rB[i][FIRST ? 2 : 0][e] + cB3[i]))
+                                : fmaf(cB0[i], rB[i][0][e], cB1[i]);
+        d[e] = on ? fmaxf(pre, 0.f) : 0.f;
+      }
+      f16x8 hi, lo;
+      split8(d, hi, lo);
+      const int slot = ((TA + (row >> 4)) * 2) * 64 + (row & 15) + 16 * qq;
+      img[buf][slot] = __builtin_bit_cast(uint4, hi);
+      img[buf][slot + 64] = __builtin_bit_cast(uint4, lo);
+    }
+  };
+
   f32x4 acc[4][4];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int p = p0; p < p1; p += 32) {
-    const int n0 = p + 8 * q;
+  if (p0 < p1) {
+    fetch(p0);
+    produce(0, p0);
+  }
+  __syncthreads();
+  int buf = 0;
+  for (int p = p0; p < p1; p += 32, buf ^= 1) {
+    const bool more = p + 32 < p1;
+    if (more) fetch(p + 32);                    // global loads in flight behind the MFMAs
     f16x8 ahi[4], alo[4], bhi[4], blo[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      const size_t row = ((size_t)b * CA + 64 * bm + 16 * mt + i16) * N;
-      float yv[8], d[8];
-      load8(y_l + row, n0, p1, yv);
-      if (AMODE == 2) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = (n0 + (e & 4) < p1) ? fmaxf(fmaf(sA[mt], yv[e], qA[mt]), 0.f) : 0.f;
-      } else {
-        float gm[8];
-        load8(up_g + row, n0, p1, gm);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) d[e] = (n0 + (e & 4) < p1) ? fmaf(sA[mt], gm[e], fmaf(qA[mt], yv[e], rA[mt])) : 0.f;
-      }
-      split8(d, ahi[mt], alo[mt]);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      float a[8];
-      if (FIRST) {
-        float x0[8], x1[8], x2[8];
-        load8(y_prev + ((size_t)b * 3 + 0) * N, n0, p1, x0);
-        load8(y_prev + ((size_t)b * 3 + 1) * N, n0, p1, x1);
-        load8(y_prev + ((size_t)b * 3 + 2) * N, n0, p1, x2);
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          a[e] = (n0 + (e & 4) < p1) ? fmaxf(wB[nt][0] * x0[e] + (wB[nt][1] * x1[e] + (wB[nt][2] * x2[e] + tB[nt])), 0.f) : 0.f;
-      } else {
-        float yv[8];
-        load8(y_prev + ((size_t)b * CB + 64 * bn + 16 * nt + i16) * N, n0, p1, yv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = (n0 + (e & 4) < p1) ? fmaxf(fmaf(sB[nt], yv[e], tB[nt]), 0.f) : 0.f;
-      }
-      split8(a, bhi[nt], blo[nt]);
+    for (int t = 0; t < 4; ++t) {
+      ahi[t] = __builtin_bit_cast(f16x8, img[buf][((4 * wm + t) * 2) * 64 + lane]);
+      alo[t] = __builtin_bit_cast(f16x8, img[buf][((4 * wm + t) * 2 + 1) * 64 + lane]);
+      const int tb = SAME ? 4 * wn + t : TA + 4 * wn + t;
+      bhi[t] = __builtin_bit_cast(f16x8, img[buf][(tb * 2) * 64 + lane]);
+      blo[t] = __builtin_bit_cast(f16x8, img[buf][(tb * 2 + 1) * 64 + lane]);
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
@@ -653,6 +697,8 @@ __global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restri
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[mt], blo[nt], acc[mt][nt], 0, 0, 0);
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[mt], bhi[nt], acc[mt][nt], 0, 0, 0);
       }
+    if (more) produce(buf ^ 1, p + 32);
+    __syncthreads();
   }
   float* out = partials + (size_t)sl * CA * CB;
 #pragma unroll
@@ -661,7 +707,7 @@ __global__ __launch_bounds__(256) void enc_train_dw_kernel(const float* __restri
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
-        out[(size_t)(64 * bm + 16 * mt + 4 * q + r) * CB + 64 * bn + 16 * nt + i16] = acc[mt][nt][r] * down;
+        out[(size_t)(64 * wm + 16 * mt + 4 * q + r) * CB + 64 * wn + 16 * nt + i16] = acc[mt][nt][r] * down;
 }
 
 // S[c][k] = sum_b gp[b][c] a_2[k](b, amax[b][c]): the arg-max part of dW_3 (one workgroup per output channel c, a thread per k)
@@ -693,7 +739,7 @@ __global__ __launch_bounds__(256) void enc_dw_reduce_kernel(const float* __restr
   out[e] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
-int dw_slices_per_shape(int layer) { return layer == 3 ? 1 : (layer == 2 ? 4 : 8); }
+int dw_slices_per_shape(int layer) { return layer == 1 ? 8 : 4; }
 int dw_per(int layer, int N) {
   const int nsl = dw_slices_per_shape(layer);
   return ((N + nsl - 1) / nsl + 31) / 32 * 32;
@@ -819,12 +865,10 @@ extern "C" int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g,
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int CA = kC[layer + 1], CB = kC[layer], nsl = dw_slices_per_shape(layer), per = dw_per(layer, N);
-  const int waves = (CA / 64) * (CB / 64) * B * nsl;
-  const dim3 grid((waves + 3) / 4), block(256);
   if (layer == 2)
-    hipLaunchKernelGGL((enc_train_dw_kernel<0, false>), grid, block, 0, st, y_l, up_g, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
+    hipLaunchKernelGGL((enc_train_dw_kernel<4, 2, 0, false>), dim3(B * nsl), dim3(512), 0, st, y_l, up_g, bconst, y_prev, tab_prev, partials, B, N, nsl, per);
   else
-    hipLaunchKernelGGL((enc_train_dw_kernel<0, true>), grid, block, 0, st, y_l, up_g, bconst, y_prev, tab_prev, partials, B, N, CA, CB, nsl, per);
+    hipLaunchKernelGGL((enc_train_dw_kernel<2, 1, 0, true>), dim3(B * nsl), dim3(128), 0, st, y_l, up_g, bconst, y_prev, tab_prev, partials, B, N, nsl, per);
   const int total = CA * CB;
   hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partials, dW, B * nsl, total);
   return (int)hipGetLastError();
@@ -839,9 +883,8 @@ extern "C" int gwtf_enc_train_dw3(const float* gp, const int* amax, const float*
   if (!gp || !amax || !y2 || !aff2 || !partials || !gram || !S || B <= 0 || N <= 0 || (N & 3)) return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int C2 = kC[3], nsl = dw_slices_per_shape(3), per = dw_per(3, N);
-  const int waves = (C2 / 64) * (C2 / 64) * B * nsl;
-  hipLaunchKernelGGL((enc_train_dw_kernel<2, false>), dim3((waves + 3) / 4), dim3(256), 0, st, y2, nullptr, aff2, y2, aff2, partials,
-                     B, N, C2, C2, nsl, per);
+  hipLaunchKernelGGL((enc_train_dw_kernel<4, 4, 2, false>), dim3(B * nsl), dim3(1024), 0, st, nullptr, nullptr, aff2, y2, aff2, partials,
+                     B, N, nsl, per);
   hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((C2 * C2 + 255) / 256), dim3(256), 0, st, partials, gram, B * nsl, C2 * C2);
   hipLaunchKernelGGL(enc_top_gather_kernel, dim3(kC[4]), dim3(256), 0, st, gp, amax, y2, aff2, S, B, N, kC[4], C2);
   return (int)hipGetLastError();
