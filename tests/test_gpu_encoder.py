@@ -192,3 +192,17 @@ def test_train_pipeline_falls_back_to_the_library_path_outside_its_cover():
     assert x4.grad is not None
     m.features.sd1_bn.momentum = None                                # cumulative-average BatchNorm
     assert not m._train_pipeline_ok(x4.detach())
+
+
+def test_two_rank_syncbn_encoder_matches_single_process(tmp_path):
+    """SyncBatchNorm semantics of the train pipeline (reference train_ae.py:152): two ranks with half of the batch each, the
+    statistic sums all-reduced between a layer's kernel and its fold, == one process with the whole batch."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GWTF_TMP=str(tmp_path), MASTER_ADDR='127.0.0.1')
+    port = 29700 + os.getpid() % 1000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(os.path.dirname(__file__), 'dist_enc_worker.py')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'ENC2' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
