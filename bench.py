@@ -272,8 +272,11 @@ def main():
                     help='process-group backend for the barrier / max-over-ranks (nccl = RCCL; gloo: rehearsal on one GPU)')
     ap.add_argument('--share-device', action='store_true',
                     help='rehearsal: every rank uses cuda:0 (RCCL refuses two ranks on one device, so use --backend gloo)')
+    ap.add_argument('--lib', default=None, help='tuning hook: load this build of libgwtf_hip.so (A/B of two builds in one call)')
     ap.add_argument('--dry-run-spawn', action='store_true', help='print the launcher command instead of running it')
     args = ap.parse_args()
+    if args.lib:
+        _lib.LIB_PATH = args.lib
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))

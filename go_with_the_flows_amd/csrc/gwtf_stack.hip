@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   constexpr int NBUF = 2 * K::LAYER * 4 <= 160 * 1024 - 512 ? 2 : 1;
   __shared__ __align__(16) float lds[NBUF][K::LAYER];
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, i16 = lane & 15;
   // XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one L2), so in launch
   // order every XCD's 4 MiB L2 sees EVERY component's 0.9 MB of weights and every shape's FiLM records: 112 MB of L2 misses
@@ -488,16 +488,21 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   // global -> LDS staging of one coupling (LDS-DMA, 1 KiB per wave-instruction): whole pieces of packed
   // weights, then this shape's FiLM record (its last piece is partial)
   auto stage = [&](int buf, int c) {
-    const float* src_w = pw + (size_t)c * K::PW + lane * 4;
-    const float* src_f = film + ((size_t)b * KC + (size_t)comp * C + c) * K::FS + lane * 4;
+    // wave-uniform base + one 32-bit per-lane byte offset: the global_load_lds address is (SGPR pair + VGPR offset), no 64-bit
+    // vector address arithmetic per piece
+    const float* src_w = pw + (size_t)c * K::PW;
+    const float* src_f = film + ((size_t)b * KC + (size_t)comp * C + c) * K::FS;
+    const unsigned voff = lane * 16u;
 #pragma unroll
     for (int i = 0; i < (K::PW / 256 + 3) / 4; ++i) {
       const int piece = wave + 4 * i;
       if (piece < K::PW / 256)
-        __builtin_amdgcn_global_load_lds((glb_void*)(src_w + piece * 256), (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(src_w + piece * 256) + voff),
+                                         (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
     }
     if (wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
-      __builtin_amdgcn_global_load_lds((glb_void*)(src_f + wave * 256), (lds_void*)&lds[buf][K::PW + wave * 256], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(src_f + wave * 256) + voff),
+                                       (lds_void*)&lds[buf][K::PW + wave * 256], 16, 0, 0);
   };
 
   // this lane's own point (one per lane) and the per-quarter copies used to build the MFMA B operand
