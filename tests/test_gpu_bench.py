@@ -27,6 +27,8 @@ def test_single_gpu_line_has_roofline_and_m1():
     r = line['roofline']
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert line['also']['m1']['value'] > 0 and 0 < line['also']['m1']['roofline']['frac'] < 1
+    ts = line['also']['train_step']                      # the whole training step, timed in a child process
+    assert 'error' not in ts and 5 < ts['ms_per_step'] < 60, ts
 
 
 def test_gpus_2_spawns_itself_and_reports_the_aggregate():
