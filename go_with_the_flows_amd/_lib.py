@@ -73,12 +73,15 @@ _SIGNATURES = {
     'gwtf_enc_train_pack': (ctypes.c_int, [_c_fp] * 3 + [ctypes.c_int, _c_fp]),
     'gwtf_enc_train_xmoments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_fold0': (ctypes.c_int, [_c_fp, ctypes.c_double] + [_c_fp] * 5 + [ctypes.c_float, _c_fp, _c_fp, _c_fp]),
-    'gwtf_enc_train_fold': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 4 + [ctypes.c_float, _c_fp, _c_fp]),
-    'gwtf_enc_train_forward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_enc_train_pool': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_fold': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 4 + [ctypes.c_float, _c_fp, _c_fp, _c_fp]),
+    'gwtf_enc_train_forward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 8 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_pool': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_pack_matrix': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_top_scatter': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_backward_top': (ctypes.c_int, [_c_fp] * 9 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_top': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int, _c_fp]),
     'gwtf_enc_train_bwd_consts': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 5 + [_c_fp]),
-    'gwtf_enc_train_backward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 12 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_backward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 10 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_dw_partial_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'gwtf_enc_train_dw': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 7 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_dw3': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int, ctypes.c_int, _c_fp]),

@@ -110,23 +110,45 @@ __global__ void enc_fold0_kernel(const float* __restrict__ mom12, double n, cons
   if (var < 0) var = 0;
   const double rstd = 1.0 / sqrt(var + (double)GWTF_BN_EPS);
   const double s = gamma[c] * rstd, t = beta[c] - mean * s;
-  aff[c] = (float)s; aff[C0 + c] = (float)t; aff[2 * C0 + c] = (float)mean; aff[3 * C0 + c] = (float)rstd;
+  bool poison = false;               // a non-finite input point: every channel of layer 0 is affected
+  for (int i = 0; i < 9; ++i) poison |= gwtf_nonfinite(mom12[i]);
+  poison |= gwtf_nonfinite((float)s) || gwtf_nonfinite((float)t);
+  const float qnan = __builtin_bit_cast(float, 0x7fc00000);
+  aff[c] = poison ? qnan : (float)s; aff[C0 + c] = poison ? qnan : (float)t;
+  aff[2 * C0 + c] = poison ? qnan : (float)mean; aff[3 * C0 + c] = poison ? qnan : (float)rstd;
   table0[c * 4] = (float)(w0 * s); table0[c * 4 + 1] = (float)(w1 * s); table0[c * 4 + 2] = (float)(w2 * s); table0[c * 4 + 3] = (float)t;
   bn_running_update(rm, rv, c, mean, var, n, momentum);
 }
 
-// sums [2][C] = sum y, sum y^2 over all points (replicas and ranks already summed)
-__global__ void enc_fold_kernel(const float* __restrict__ sums, int C, double n, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float* rm, float* rv, float momentum, float* __restrict__ aff) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double mean = (double)sums[c] / n;
-  double var = (double)sums[C + c] / n - mean * mean;
-  if (var < 0) var = 0;
-  const double rstd = 1.0 / sqrt(var + (double)GWTF_BN_EPS);
-  const double s = gamma[c] * rstd;
-  aff[c] = (float)s; aff[C + c] = (float)(beta[c] - mean * s); aff[2 * C + c] = (float)mean; aff[3 * C + c] = (float)rstd;
-  bn_running_update(rm, rv, c, mean, var, n, momentum);
+// sums [2][C] = sum y, sum y^2 over all points (replicas and ranks already summed).  One workgroup.
+// Non-finite values must reach the loss (the reference's isnan guard, training.py:43-46), but a ReLU compiled without NaN
+// semantics turns a NaN activation into 0: the FOLDS carry the poison instead.  A layer whose statistics are not finite (a NaN
+// anywhere in y_l shows in sum y) -- or whose input layer was already poisoned (aff_prev) -- gets NaN in every entry of its aff;
+// the pooling kernel turns a non-finite aff into NaN codes.
+__global__ __launch_bounds__(512) void enc_fold_kernel(const float* __restrict__ sums, int C, double n, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* rm, float* rv, float momentum,
+                                                       float* __restrict__ aff, const float* __restrict__ aff_prev) {
+  __shared__ int s_bad;
+  if (threadIdx.x == 0) s_bad = aff_prev ? (int)gwtf_nonfinite(aff_prev[0]) : 0;
+  __syncthreads();
+  int bad = 0;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) bad |= (int)(gwtf_nonfinite(sums[c]) || gwtf_nonfinite(sums[C + c]));
+  if (bad) atomicOr(&s_bad, 1);
+  __syncthreads();
+  const bool poison = s_bad != 0;
+  const float qnan = __builtin_bit_cast(float, 0x7fc00000);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double mean = (double)sums[c] / n;
+    double var = (double)sums[C + c] / n - mean * mean;
+    if (var < 0) var = 0;
+    const double rstd = 1.0 / sqrt(var + (double)GWTF_BN_EPS);
+    const double s = gamma[c] * rstd;
+    aff[c] = poison ? qnan : (float)s;
+    aff[C + c] = poison ? qnan : (float)(beta[c] - mean * s);
+    aff[2 * C + c] = poison ? qnan : (float)mean;
+    aff[3 * C + c] = poison ? qnan : (float)rstd;
+    bn_running_update(rm, rv, c, mean, var, n, momentum);
+  }
 }
 
 // f16 hi/lo split of an accumulator-layout tile into elements 4*half..+3 of a B fragment; RELU: max(., 0) first
@@ -166,20 +188,48 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+__device__ __forceinline__ float row_max16(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)));
+  return v;
+}
+
+// order-preserving map float -> unsigned (larger float <-> larger key), and the 64-bit arg-max key: ties go to the smaller n
+__device__ __forceinline__ unsigned ordered_bits(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float from_ordered_bits(unsigned k) {
+  return __builtin_bit_cast(float, (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+__device__ __forceinline__ unsigned long long argmax_key(unsigned ordered, int n) {
+  return ((unsigned long long)ordered << 32) | (unsigned)(0x7fffffff - n);
+}
+
 // ---- forward of one layer: y_out = W . relu(s in + t)  (FIRST: in = x, relu(W_0' x + t_0) from table0) -------------------
-template <int CIN, int COUT, bool FIRST>
+// LAST (the top layer): y is not stored.  Its BatchNorm + ReLU + max over points is monotone in y per channel, so the pooled
+// code only needs max_n y and min_n y per (shape, channel) (which one: the sign of s, known after the fold): 64-bit keys
+// (order-preserving bits of y | inverted point index) combined by integer max -- DPP row max to find the candidates, one
+// exec-masked LDS atomic per (row, tile), one global atomic per (workgroup, channel).
+template <int CIN, int COUT, bool FIRST, bool LAST>
 __global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __restrict__ in, const float* __restrict__ in_tab,
                                                                  const float* __restrict__ units, float* __restrict__ y_out,
-                                                                 float* __restrict__ sums, float* __restrict__ ymax, int B,
-                                                                 int N) {
+                                                                 float* __restrict__ sums, float* __restrict__ ymax,
+                                                                 unsigned long long* __restrict__ kmax,
+                                                                 unsigned long long* __restrict__ kmin, int B, int N) {
   constexpr int NB = 2, KS = CIN / 32, MT = COUT / 16, TM = 16 / KS, NCH = MT / TM;
   static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
   __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
   __shared__ __attribute__((aligned(16))) float tab[FIRST ? 4 * CIN : 2 * CIN];
   __shared__ float wsum[2][COUT];
   __shared__ float wmax[8];
+  __shared__ unsigned long long wkey[LAST ? 2 * COUT : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.y, n_wave0 = blockIdx.x * 256 + wave * 32;
+  if (LAST)
+    for (int t = tid; t < 2 * COUT; t += kThreads) wkey[t] = 0ull;
 
   auto stage = [&](int buf, int g) {
 #pragma unroll
@@ -266,7 +316,7 @@ __global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float v = valid[nb] ? acc[nb][r] : 0.f;
-          if (valid[nb]) y_out[((size_t)b * COUT + ch) * N + n[nb]] = v;
+          if (!LAST && valid[nb]) y_out[((size_t)b * COUT + ch) * N + n[nb]] = v;
           s1 += v;
           s2 = fmaf(v, v, s2);
           amax = fmaxf(amax, fabsf(v));
@@ -277,6 +327,21 @@ __global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __
           atomicAdd(&wsum[0][ch], s1);
           atomicAdd(&wsum[1][ch], s2);
         }
+        if (LAST) {
+          // this lane's best (largest / smallest) of its NB points, then the row's; only the lanes that hold it touch the LDS
+          const float big = 3.0e38f;
+          float hi = -big, lo = big;
+          int nhi = 0, nlo = 0;
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const float v = acc[nb][r];
+            if (valid[nb] && v > hi) { hi = v; nhi = n[nb]; }
+            if (valid[nb] && v < lo) { lo = v; nlo = n[nb]; }
+          }
+          const float rhi = row_max16(hi), rlo = -row_max16(-lo);
+          if (hi == rhi && hi > -big) atomicMax(&wkey[ch], argmax_key(ordered_bits(hi), nhi));
+          if (lo == rlo && lo < big) atomicMax(&wkey[COUT + ch], argmax_key(~ordered_bits(lo), nlo));
+        }
       }
     }
   }
@@ -285,6 +350,11 @@ __global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __
   __syncthreads();
   float* dst = sums + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % kR) * 2 * COUT;
   for (int t = tid; t < 2 * COUT; t += kThreads) atomicAdd(&dst[t], (&wsum[0][0])[t]);
+  if (LAST)
+    for (int t = tid; t < COUT; t += kThreads) {
+      atomicMax(&kmax[(size_t)b * COUT + t], wkey[t]);
+      atomicMax(&kmin[(size_t)b * COUT + t], wkey[COUT + t]);
+    }
   if (tid == 0) {
     float m = wmax[0];
     for (int w = 1; w < 8; ++w) m = fmaxf(m, wmax[w]);
@@ -292,33 +362,24 @@ __global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __
   }
 }
 
-// ---- pooled[b][c] = max_n relu(s y_3 + t), its first arg-max, and y_3 there; one wavefront per (b, c) row -----------------
-__global__ __launch_bounds__(256) void enc_pool_kernel(const float* __restrict__ y, const float* __restrict__ aff,
-                                                       float* __restrict__ pooled, int* __restrict__ amax,
-                                                       float* __restrict__ ystar, int B, int C, int N) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= B * C) return;
-  const int c = row % C;
+// ---- pooled[b][c] = max_n relu(s y_3 + t) = relu(s (s >= 0 ? max_n y_3 : min_n y_3) + t), its (first) arg-max, y_3 there ------
+// A non-finite statistic or extreme (diverged weights, a NaN point) gives NaN, as torch's batch_norm + relu + max would.
+__global__ void enc_pool_finalize_kernel(const unsigned long long* __restrict__ kmax, const unsigned long long* __restrict__ kmin,
+                                         const float* __restrict__ aff, float* __restrict__ pooled, int* __restrict__ amax,
+                                         float* __restrict__ ystar, int B, int C) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * C) return;
+  const int c = i % C;
   const float s = aff[c], t = aff[C + c];
-  const float* src = y + (size_t)row * N;
-  float best = -1.f, yb = 0.f;
-  int bi = 0;
-  for (int n = lane; n < N; n += 64) {
-    const float v = src[n];
-    const float a = fmaxf(fmaf(s, v, t), 0.f);
-    if (a > best) { best = a; bi = n; yb = v; }
-  }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const float ob = __shfl_xor(best, off), oy = __shfl_xor(yb, off);
-    const int oi = __shfl_xor(bi, off);
-    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; yb = oy; }
-  }
-  if (lane == 0) {
-    pooled[row] = best;
-    amax[row] = bi;
-    ystar[row] = yb;
-  }
+  const bool use_max = !(s < 0.f);
+  const unsigned long long key = use_max ? kmax[i] : kmin[i];
+  const unsigned ob = (unsigned)(key >> 32);
+  const float y = from_ordered_bits(use_max ? ob : ~ob);
+  const float a = fmaf(s, y, t);
+  const bool bad = gwtf_nonfinite(a) || gwtf_nonfinite(s) || gwtf_nonfinite(t);
+  pooled[i] = bad ? __builtin_bit_cast(float, 0x7fc00000) : fmaxf(a, 0.f);
+  amax[i] = 0x7fffffff - (int)(unsigned)(key & 0xffffffffu);
+  ystar[i] = y;
 }
 
 // ---- top of the backward: gp = g_pooled where the pooled activation is > 0; the two BatchNorm-backward sums of layer 3 -----
@@ -339,6 +400,121 @@ __global__ void enc_top_kernel(const float* __restrict__ g_pooled, const float* 
   sums[c] = db;
   sums[C + c] = dg;
   atomicMax(reinterpret_cast<int*>(gmax), __builtin_bit_cast(int, mx));
+}
+
+// ---- the arg-max rows of the top layer's backward -------------------------------------------------------------------------
+// Per shape b: the distinct arg-max points get consecutive row numbers (slot_of[b][n] = row or -1), and
+// extra[b][row][:] = sum over the channels c whose arg-max is that point of coef[b][c] W_3[c][:]   (coef = s_c gp[b][c]).
+// Channels are visited in ascending order: deterministic sums.
+// Two kernels: the row tables (this one: per shape the offsets [C + 1] and the channel list [C] of its rows), then one
+// wavefront per row for the sums (enc_top_rows_kernel).
+__global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __restrict__ coef, const int* __restrict__ amax,
+                                                              int* __restrict__ slot_of, int* __restrict__ row_off,
+                                                              int* __restrict__ row_list, int N, int C) {
+  extern __shared__ int dyn[];                 // [N] row of a point | -1
+  __shared__ int s_am[512], s_cnt[512], s_off[512], s_list[512], s_scan[256];
+  __shared__ float s_cf[512];
+  int* slot = dyn;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int n = tid; n < N; n += 256) slot[n] = -1;
+  for (int c = tid; c < C; c += 256) {
+    s_am[c] = amax[(size_t)b * C + c];
+    s_cf[c] = coef[(size_t)b * C + c];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256)
+    if (s_cf[c] != 0.f) slot[s_am[c]] = 0;     // mark
+  __syncthreads();
+  // rows in ascending point order: each thread numbers a contiguous chunk of points
+  const int per = (N + 255) / 256, n0 = tid * per, n1 = min(N, n0 + per);
+  int mine = 0;
+  for (int n = n0; n < n1; ++n) mine += slot[n] == 0;
+  s_scan[tid] = mine;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int v = tid >= off ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  int row = s_scan[tid] - mine;
+  for (int n = n0; n < n1; ++n) {
+    const int r = slot[n] == 0 ? row++ : -1;
+    slot[n] = r;
+    slot_of[(size_t)b * N + n] = r;
+  }
+  const int rows = s_scan[255];
+  __syncthreads();
+  // channel lists per row: count (LDS atomics), offsets (scan), fill, then every row's short list sorted ascending so that the
+  // sums below do not depend on the order the atomics happened to land in
+  for (int r = tid; r < C; r += 256) s_cnt[r] = 0;
+  __syncthreads();
+  for (int c = tid; c < C; c += 256)
+    if (s_cf[c] != 0.f) atomicAdd(&s_cnt[slot[s_am[c]]], 1);
+  __syncthreads();
+  {
+    const int a = 2 * tid < C ? s_cnt[2 * tid] : 0, c2 = 2 * tid + 1 < C ? s_cnt[2 * tid + 1] : 0;
+    s_scan[tid] = a + c2;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+      const int v = tid >= off ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    const int base = s_scan[tid] - (a + c2);
+    if (2 * tid < C) s_off[2 * tid] = base;
+    if (2 * tid + 1 < C) s_off[2 * tid + 1] = base + a;
+  }
+  for (int r = tid; r < C; r += 256) s_cnt[r] = 0;
+  __syncthreads();
+  for (int c = tid; c < C; c += 256)
+    if (s_cf[c] != 0.f) {
+      const int r = slot[s_am[c]];
+      s_list[s_off[r] + atomicAdd(&s_cnt[r], 1)] = c;
+    }
+  __syncthreads();
+  for (int r = tid; r < rows; r += 256) {           // insertion sort: the lists average two entries
+    const int o = s_off[r], k = s_cnt[r];
+    for (int i = 1; i < k; ++i) {
+      const int v = s_list[o + i];
+      int j2 = i - 1;
+      while (j2 >= 0 && s_list[o + j2] > v) { s_list[o + j2 + 1] = s_list[o + j2]; --j2; }
+      s_list[o + j2 + 1] = v;
+    }
+  }
+  __syncthreads();
+  // s_off is an exclusive prefix sum over ALL C entries (rows beyond `rows` have no hits): s_off[r + 1] ends row r
+  for (int r = tid; r < C; r += 256) {
+    row_off[(size_t)b * (C + 2) + r] = s_off[r];
+    row_list[(size_t)b * C + r] = s_list[r];
+  }
+  if (tid == 0) {
+    row_off[(size_t)b * (C + 2) + C] = s_off[C - 1] + s_cnt[C - 1];      // total number of hits
+    row_off[(size_t)b * (C + 2) + C + 1] = rows;
+  }
+}
+
+// extra[b][r][:] = sum over the row's channels (ascending) of coef[b][c] W_3[c][:]; one wavefront per (shape, row), a lane = 4 columns
+__global__ __launch_bounds__(256) void enc_top_rows_kernel(const float* __restrict__ coef, const int* __restrict__ row_off,
+                                                           const int* __restrict__ row_list, const float* __restrict__ W3,
+                                                           float* __restrict__ extra, int B, int C, int CP) {
+  const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (w >= B * C) return;
+  const int b = w / C, r = w % C;
+  const int* ro = row_off + (size_t)b * (C + 2);
+  if (r >= ro[C + 1]) return;
+  const int o = ro[r], end = ro[r + 1];
+  for (int j = 4 * lane; j < CP; j += 256) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = o; k < end; ++k) {
+      const int c = row_list[(size_t)b * C + k];
+      const float g = coef[(size_t)b * C + c];
+      const float4 wv = *reinterpret_cast<const float4*>(&W3[(size_t)c * CP + j]);
+      a.x = fmaf(g, wv.x, a.x); a.y = fmaf(g, wv.y, a.y); a.z = fmaf(g, wv.z, a.z); a.w = fmaf(g, wv.w, a.w);
+    }
+    *reinterpret_cast<float4*>(&extra[((size_t)b * C + r) * CP + j]) = a;
+  }
 }
 
 // ---- per-channel constants of dy = s gm + Q y + R and the power-of-two operand scale ---------------------------------------
@@ -377,8 +553,13 @@ __global__ __launch_bounds__(512) void enc_bwd_consts_kernel(const float* __rest
 }
 
 // ---- backward of one layer: dL/da_{l-1} = W_l^T dy_l, masked by a_{l-1} > 0; sums for the layer below -------------------------
-// CIN = C_{l-1} (rows of the product), COUT = C_l (contraction).  TOP: gm_l from (gp, amax); BOTTOM: layer l-1 = 0 (y_0 from x,
-// nothing stored, the extra sums sum gm_0 x_d for dW_0).
+// CIN = C_{l-1} (rows of the product), COUT = C_l (contraction).  BOTTOM: layer l-1 = 0 (y_0 from x, nothing stored, the extra
+// sums sum gm_0 x_d for dW_0).
+// TOP (layer 3, COUT == CIN): dy_3 = s gm_3 + Q y_3 + R with y_3 = W_3 a_2 makes the product linear in a_2,
+//     dL/da_2 (p) = M a_2(p) + v + sum over {c : argmax(b, c) = p} s_c gp[b][c] W_3[c][:],   M = W_3^T diag(Q) W_3,  v = W_3^T R,
+// a 256-wide contraction on a_2 (read from y_2: neither y_3 nor a 512-wide B fragment is needed) plus, for the <= 512 arg-max
+// points of a shape, one precomputed row each (`extra` [B][ex_rows][CIN], `slot_of` [B][N] = row or -1; enc_top_scatter_kernel).
+// The fragment images hold M times a power of two; bconst = v [CIN] followed by {down}.
 template <int CIN, int COUT, int NB, bool TOP, bool BOTTOM>
 __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
                                                                  const float* __restrict__ gp, const int* __restrict__ amax,
@@ -386,14 +567,13 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
                                                                  const float* __restrict__ y_prev, const float* __restrict__ aff_prev,
                                                                  const float* __restrict__ w0, float* __restrict__ dA_prev,
                                                                  float* __restrict__ sums, float* __restrict__ gmax_prev, int B,
-                                                                 int N) {
+                                                                 int N, int ex_rows) {
+  static_assert(!TOP || CIN == COUT, "the top layer contracts over its own input channels");
   constexpr int KS = COUT / 32, MT = CIN / 16, TM = 16 / KS, NCH = MT / TM, NS = BOTTOM ? 5 : (TOP ? 3 : 2);
   static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
   __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
   __shared__ __attribute__((aligned(16))) float bc[3 * COUT];
   __shared__ __attribute__((aligned(16))) float ap[4 * CIN];
-  __shared__ __attribute__((aligned(16))) float topg[TOP ? COUT : 4];
-  __shared__ __attribute__((aligned(16))) int topi[TOP ? COUT : 4];
   __shared__ __attribute__((aligned(16))) float w0s[BOTTOM ? CIN * 4 : 4];
   __shared__ float wsum[NS][CIN];
   __shared__ float wmax[8];
@@ -409,44 +589,45 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
     }
   };
   stage(0, 0);
-  for (int t = tid; t < 3 * COUT; t += kThreads) bc[t] = bconst[t];
+  for (int t = tid; t < (TOP ? CIN : 3 * COUT); t += kThreads) bc[t] = bconst[t];
   for (int t = tid; t < 4 * CIN; t += kThreads) ap[t] = aff_prev[t];
-  if (TOP)
-    for (int t = tid; t < COUT; t += kThreads) {
-      topg[t] = gp[(size_t)b * COUT + t];
-      topi[t] = amax[(size_t)b * COUT + t];
-    }
   if (BOTTOM)
     for (int t = tid; t < CIN; t += kThreads) {
       w0s[4 * t] = w0[3 * t]; w0s[4 * t + 1] = w0[3 * t + 1]; w0s[4 * t + 2] = w0[3 * t + 2]; w0s[4 * t + 3] = 0.f;
     }
   for (int t = tid; t < NS * CIN; t += kThreads) (&wsum[0][0])[t] = 0.f;
-  const float up = bconst[3 * COUT], down = bconst[3 * COUT + 1];
+  const float up = TOP ? 1.0f : bconst[3 * COUT], down = TOP ? bconst[CIN] : bconst[3 * COUT + 1];
 
-  int n[NB];
+  int n[NB], slot[NB];
   bool valid[NB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     n[nb] = n_wave0 + 16 * nb + i16;
     valid[nb] = n[nb] < N;
+    slot[nb] = (TOP && valid[nb]) ? amax[(size_t)b * N + n[nb]] : -1;          // TOP: `amax` carries slot_of [B][N]
   }
   __syncthreads();
 
-  // prologue: dy_l (scaled by `up`) for the lane's k-slots, split into the B fragments
+  // prologue: the B fragments for the lane's k-slots -- dy_l (scaled by `up`), or (TOP) a_{l-1} itself
   f16x8 bhi[KS][NB], blo[KS][NB];
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       const int c0 = 32 * ks + 16 * half + 4 * q;
+      if (TOP) {
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(&ap[c0]), t4 = *reinterpret_cast<const f32x4*>(&ap[CIN + c0]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+          f32x4 a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r] = fmaf(s4[r], valid[nb] ? y_prev[((size_t)b * CIN + c0 + r) * N + n[nb]] : 0.f, t4[r]);
+          split_into<true>(a, bhi[ks][nb], blo[ks][nb], half);
+        }
+        continue;
+      }
       const f32x4 s4 = *reinterpret_cast<const f32x4*>(&bc[c0]) * up, q4 = *reinterpret_cast<const f32x4*>(&bc[COUT + c0]) * up,
                   r4 = *reinterpret_cast<const f32x4*>(&bc[2 * COUT + c0]) * up;
-      f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
-      i32x4 a4 = {0, 0, 0, 0};
-      if (TOP) {
-        g4 = *reinterpret_cast<const f32x4*>(&topg[c0]);
-        a4 = *reinterpret_cast<const i32x4*>(&topi[c0]);
-      }
 #pragma unroll
       for (int nb = 0; nb < NB; ++nb) {
         f32x4 d;
@@ -454,7 +635,7 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
         for (int r = 0; r < 4; ++r) {
           const size_t idx = ((size_t)b * COUT + c0 + r) * N + n[nb];
           const float yv = valid[nb] ? y_l[idx] : 0.f;
-          const float gm = TOP ? (n[nb] == a4[r] ? g4[r] : 0.f) : (valid[nb] ? up_g[idx] : 0.f);
+          const float gm = valid[nb] ? up_g[idx] : 0.f;
           d[r] = valid[nb] ? fmaf(s4[r], gm, fmaf(q4[r], yv, r4[r])) : 0.f;
         }
         split_into<false>(d, bhi[ks][nb], blo[ks][nb], half);
@@ -487,6 +668,12 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
       tile_mfma<KS, NB>(L + t * KS * 512, lane, bhi, blo, acc);
       const f32x4 sp = *reinterpret_cast<const f32x4*>(&ap[j0]), tp = *reinterpret_cast<const f32x4*>(&ap[CIN + j0]),
                   mp = *reinterpret_cast<const f32x4*>(&ap[2 * CIN + j0]), rp = *reinterpret_cast<const f32x4*>(&ap[3 * CIN + j0]);
+      f32x4 ex[NB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {     // TOP: the arg-max rows of this point (`gp` carries `extra`)
+        ex[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (TOP && slot[nb] >= 0) ex[nb] = *reinterpret_cast<const f32x4*>(&gp[((size_t)b * ex_rows + slot[nb]) * CIN + j0]);
+      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + r;
@@ -502,7 +689,7 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
           }
           const float pre = fmaf(sp[r], yv, tp[r]);
           const bool on = valid[nb] && pre > 0.f;
-          const float gm = on ? acc[nb][r] * down : 0.f;
+          const float gm = on ? (TOP ? fmaf(acc[nb][r], down, bc[j] + ex[nb][r]) : acc[nb][r] * down) : 0.f;
           if (TOP) sx0 += on ? pre : 0.f;                  // sum_p a_{l-1}: the R term of dW_3 (gwtf_enc_train_dw3)
           if (!BOTTOM && valid[nb]) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
           sb += gm;
@@ -769,6 +956,14 @@ extern "C" int gwtf_enc_train_pack(const float* W, float* units_fwd, float* unit
   return (int)hipGetLastError();
 }
 
+// a (rows x kdim) row-major matrix -> fragment images (rows % 16 == 0, kdim % 32 == 0): the top layer's M = W_3^T diag(Q) W_3
+extern "C" int gwtf_enc_train_pack_matrix(const float* W, float* units, int rows, int kdim, void* stream) {
+  if (!W || !units || rows <= 0 || kdim <= 0 || rows % 16 || kdim % 32) return GWTF_E_BADARG;
+  const int total = (rows / 16) * (kdim / 32) * 2 * 64;
+  hipLaunchKernelGGL(enc_train_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, units, rows, kdim, 0);
+  return (int)hipGetLastError();
+}
+
 extern "C" int gwtf_enc_train_xmoments(const float* x, float* mom, int B, int N, void* stream) {
   if (!x || !mom || B <= 0 || N <= 0) return GWTF_E_BADARG;
   hipLaunchKernelGGL(enc_xmom_kernel, dim3((N + 1023) / 1024, B), dim3(256), 0, (hipStream_t)stream, x, mom, B, N);
@@ -785,30 +980,47 @@ extern "C" int gwtf_enc_train_fold0(const float* mom12, double n_total, const fl
 }
 
 extern "C" int gwtf_enc_train_fold(const float* sums, int layer, double n_total, const float* gamma, const float* beta,
-                                   float* running_mean, float* running_var, float momentum, float* aff, void* stream) {
-  if (!sums || !gamma || !beta || !aff || layer < 1 || layer > 3 || n_total <= 0) return GWTF_E_BADARG;
-  const int C = kC[layer + 1];
-  hipLaunchKernelGGL(enc_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sums, C, n_total, gamma, beta,
-                     running_mean, running_var, momentum, aff);
+                                   float* running_mean, float* running_var, float momentum, float* aff, const float* aff_prev,
+                                   void* stream) {
+  if (!sums || !gamma || !beta || !aff || !aff_prev || layer < 1 || layer > 3 || n_total <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(enc_fold_kernel, dim3(1), dim3(512), 0, (hipStream_t)stream, sums, kC[layer + 1], n_total, gamma, beta,
+                     running_mean, running_var, momentum, aff, aff_prev);
   return (int)hipGetLastError();
 }
 
 extern "C" int gwtf_enc_train_forward(int layer, const float* in, const float* in_tab, const float* units, float* y_out,
-                                      float* sums, float* ymax, int B, int N, void* stream) {
-  if (!in || !in_tab || !units || !y_out || !sums || !ymax || B <= 0 || N <= 0 || layer < 1 || layer > 3) return GWTF_E_BADARG;
+                                      float* sums, float* ymax, unsigned long long* kmax, unsigned long long* kmin, int B, int N,
+                                      void* stream) {
+  if (!in || !in_tab || !units || !sums || !ymax || B <= 0 || N <= 0 || layer < 1 || layer > 3) return GWTF_E_BADARG;
+  if (layer < 3 ? !y_out : (!kmax || !kmin)) return GWTF_E_BADARG;
   const dim3 grid((N + 255) / 256, B), block(kThreads);
   hipStream_t st = (hipStream_t)stream;
-  if (layer == 1) hipLaunchKernelGGL((enc_train_fwd_kernel<64, 128, true>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, B, N);
-  else if (layer == 2) hipLaunchKernelGGL((enc_train_fwd_kernel<128, 256, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, B, N);
-  else hipLaunchKernelGGL((enc_train_fwd_kernel<256, 512, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, B, N);
+  if (layer == 1) hipLaunchKernelGGL((enc_train_fwd_kernel<64, 128, true, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
+  else if (layer == 2) hipLaunchKernelGGL((enc_train_fwd_kernel<128, 256, false, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
+  else hipLaunchKernelGGL((enc_train_fwd_kernel<256, 512, false, true>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
   return (int)hipGetLastError();
 }
 
-extern "C" int gwtf_enc_train_pool(const float* y3, const float* aff3, float* pooled, int* amax, float* ystar, int B, int N,
-                                   void* stream) {
-  if (!y3 || !aff3 || !pooled || !amax || !ystar || B <= 0 || N <= 0) return GWTF_E_BADARG;
+extern "C" int gwtf_enc_train_pool(const unsigned long long* kmax, const unsigned long long* kmin, const float* aff3, float* pooled,
+                                   int* amax, float* ystar, int B, void* stream) {
+  if (!kmax || !kmin || !aff3 || !pooled || !amax || !ystar || B <= 0) return GWTF_E_BADARG;
   const int C = kC[4];
-  hipLaunchKernelGGL(enc_pool_kernel, dim3((B * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, y3, aff3, pooled, amax, ystar, B, C, N);
+  hipLaunchKernelGGL(enc_pool_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, kmax, kmin, aff3, pooled,
+                     amax, ystar, B, C);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_enc_train_top_scatter(const float* coef, const int* amax, const float* W3, float* extra, int* slot_of,
+                                          int* tables, int B, int N, void* stream) {
+  if (!coef || !amax || !W3 || !extra || !slot_of || !tables || B <= 0 || N <= 0 || (size_t)N * sizeof(int) > 48 * 1024)
+    return GWTF_E_BADARG;
+  const int C = kC[4];
+  int* row_off = tables;                          // [B][C + 2]
+  int* row_list = tables + (size_t)B * (C + 2);   // [B][C]
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(enc_top_scatter_kernel, dim3(B), dim3(256), (size_t)N * sizeof(int), st, coef, amax, slot_of, row_off, row_list,
+                     N, C);
+  hipLaunchKernelGGL(enc_top_rows_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, coef, row_off, row_list, W3, extra, B, C, kC[3]);
   return (int)hipGetLastError();
 }
 
@@ -829,26 +1041,34 @@ extern "C" int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_
   return (int)hipGetLastError();
 }
 
-extern "C" int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax,
-                                       const float* bconst, const float* units_bwd, const float* y_prev, const float* aff_prev,
-                                       const float* w0, float* dA_prev, float* sums, float* gmax_prev, int B, int N, void* stream) {
-  if (!y_l || !bconst || !units_bwd || !y_prev || !aff_prev || !sums || B <= 0 || N <= 0 || layer < 1 || layer > 3)
+extern "C" int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, const float* bconst,
+                                       const float* units_bwd, const float* y_prev, const float* aff_prev, const float* w0,
+                                       float* dA_prev, float* sums, float* gmax_prev, int B, int N, void* stream) {
+  if (!y_l || !up_g || !bconst || !units_bwd || !y_prev || !aff_prev || !sums || B <= 0 || N <= 0 || layer < 1 || layer > 2)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 block(kThreads);
-  if (layer == 3) {
-    if (!gp || !amax || !dA_prev || !gmax_prev) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_bwd_kernel<256, 512, 1, true, false>), dim3((N + 127) / 128, B), block, 0, st, y_l, up_g, gp, amax,
-                       bconst, units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N);
-  } else if (layer == 2) {
-    if (!up_g || !dA_prev || !gmax_prev) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_bwd_kernel<128, 256, 2, false, false>), dim3((N + 255) / 256, B), block, 0, st, y_l, up_g, gp, amax,
-                       bconst, units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N);
+  const dim3 block(kThreads), grid((N + 255) / 256, B);
+  if (layer == 2) {
+    if (!dA_prev || !gmax_prev) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_bwd_kernel<128, 256, 2, false, false>), grid, block, 0, st, y_l, up_g, nullptr, nullptr, bconst,
+                       units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N, 0);
   } else {
-    if (!up_g || !w0) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_bwd_kernel<64, 128, 2, false, true>), dim3((N + 255) / 256, B), block, 0, st, y_l, up_g, gp, amax,
-                       bconst, units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N);
+    if (!w0) return GWTF_E_BADARG;
+    hipLaunchKernelGGL((enc_train_bwd_kernel<64, 128, 2, false, true>), grid, block, 0, st, y_l, up_g, nullptr, nullptr, bconst,
+                       units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N, 0);
   }
+  return (int)hipGetLastError();
+}
+
+// layer 3 in the M form (see enc_train_bwd_kernel): units_m = fragment images of M * 2^k, mconst = v [256] | {2^-k},
+// extra / slot_of from gwtf_enc_train_top_scatter
+extern "C" int gwtf_enc_train_backward_top(const float* y2, const float* aff2, const float* units_m, const float* mconst,
+                                           const float* extra, const int* slot_of, float* dA2, float* sums, float* gmax2, int B,
+                                           int N, void* stream) {
+  if (!y2 || !aff2 || !units_m || !mconst || !extra || !slot_of || !dA2 || !sums || !gmax2 || B <= 0 || N <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL((enc_train_bwd_kernel<256, 256, 2, true, false>), dim3((N + 255) / 256, B), dim3(kThreads), 0,
+                     (hipStream_t)stream, nullptr, nullptr, extra, slot_of, mconst, units_m, y2, aff2, nullptr, dA2, sums, gmax2, B, N,
+                     kC[4]);
   return (int)hipGetLastError();
 }
 

@@ -76,18 +76,20 @@ class _EncoderTrainFn(torch.autograd.Function):
                 units_b.append(torch.empty(n_units, **f32))
                 check(L.gwtf_enc_train_pack(P(Ws[l]), P(units_f[l]), P(units_b[l]), l, st))
             ys, ymax = [None], torch.zeros(4, **f32)
+            keys = torch.zeros(2, B, C[4], device=dev, dtype=torch.int64)        # arg-max / arg-min keys of y_3 (never stored)
             for l in (1, 2, 3):
-                y = torch.empty(B, C[l + 1], N, **f32)
+                y = torch.empty(B, C[l + 1], N, **f32) if l < 3 else None
                 sums = torch.zeros(R, 2, C[l + 1], **f32)
                 check(L.gwtf_enc_train_forward(l, P(x if l == 1 else ys[l - 1]), P(table0 if l == 1 else aff[l - 1]),
-                                               P(units_f[l]), P(y), P(sums), P(ymax[l:l + 1]), B, N, st))
+                                               P(units_f[l]), P(y), P(sums), P(ymax[l:l + 1]),
+                                               keys[0].data_ptr() if l == 3 else 0, keys[1].data_ptr() if l == 3 else 0, B, N, st))
                 check(L.gwtf_enc_train_fold(P(over_ranks(sums.sum(0))), l, n_total, P(gam[l]), P(bet[l]), P(rm[l]), P(rv[l]),
-                                            float(bns[l].momentum), P(aff[l]), st))
+                                            float(bns[l].momentum), P(aff[l]), P(aff[l - 1]), st))
                 ys.append(y)
             pooled = torch.empty(B, C[4], **f32)
             amax = torch.empty(B, C[4], device=dev, dtype=torch.int32)
             ystar = torch.empty(B, C[4], **f32)
-            check(L.gwtf_enc_train_pool(P(ys[3]), P(aff[3]), P(pooled), amax.data_ptr(), P(ystar), B, N, st))
+            check(L.gwtf_enc_train_pool(keys[0].data_ptr(), keys[1].data_ptr(), P(aff[3]), P(pooled), amax.data_ptr(), P(ystar), B, st))
             for bn in bns:
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
                     bn.num_batches_tracked.add_(1)
@@ -125,32 +127,46 @@ class _EncoderTrainFn(torch.autograd.Function):
             gmax = torch.zeros(4, **f32)
             check(L.gwtf_enc_train_top(P(g_pooled), P(pooled), P(b['ystar']), P(aff[3]), P(gp), P(red), P(gmax[3:4]), B, st))
             partials = torch.empty(max(L.gwtf_enc_train_dw_partial_floats(l, B, N) for l in (1, 2, 3)), **f32)
-            up = None                                   # masked dL/da_l of the layer being processed
-            for l in (3, 2, 1):
+            # ---- layer 3 in the M form (csrc/gwtf_encoder_train.hip): dy_3 = s gm_3 + Q y_3 + R with y_3 = W_3 a_2 ----
+            grads[10], grads[11] = red[1].clone(), red[0].clone()
+            bconst = torch.empty(3 * C[4] + 4, **f32)
+            check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), 3, n_total, P(gam[3]), P(aff[3]), 0, 0, P(bconst), st))
+            s3, q3, r3 = (bconst[i * C[4]:(i + 1) * C[4]] for i in range(3))
+            W3 = Ws[3]
+            M = (W3 * q3[:, None]).t() @ W3                                        # (256, 256), symmetric
+            k = 8.0 - torch.floor(torch.log2(M.abs().max().clamp_min(1e-37)))      # power-of-two operand scale, on the device
+            units_m = torch.empty(L.gwtf_enc_train_units_floats(3) // 2, **f32)
+            check(L.gwtf_enc_train_pack_matrix(P((M * torch.exp2(k)).contiguous()), P(units_m), C[3], C[3], st))
+            mconst = torch.cat([W3.t() @ r3, torch.exp2(-k).reshape(1), torch.zeros(3, **f32)])
+            extra = torch.empty(B, C[4], C[3], **f32)
+            slot_of = torch.empty(B, N, device=dev, dtype=torch.int32)
+            tables = torch.empty(B * (2 * C[4] + 2), device=dev, dtype=torch.int32)
+            check(L.gwtf_enc_train_top_scatter(P((gp * s3[None, :]).contiguous()), b['amax'].data_ptr(), P(W3), P(extra),
+                                               slot_of.data_ptr(), tables.data_ptr(), B, N, st))
+            up = torch.empty(B, C[3], N, **f32)                                    # masked dL/da_2
+            sums = torch.zeros(R, 3, C[3], **f32)
+            check(L.gwtf_enc_train_backward_top(P(ys[2]), P(aff[2]), P(units_m), P(mconst), P(extra), slot_of.data_ptr(), P(up),
+                                                P(sums), P(gmax[2:3]), B, N, st))
+            red = sums.sum(0)
+            # dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2  (gwtf_enc_train_dw3)
+            gram, S = torch.empty(C[3], C[3], **f32), torch.empty(C[4], C[3], **f32)
+            check(L.gwtf_enc_train_dw3(P(gp), b['amax'].data_ptr(), P(ys[2]), P(aff[2]), P(partials), P(gram), P(S), B, N, st))
+            grads[9] = (s3[:, None] * S + q3[:, None] * (W3 @ gram) + r3[:, None] * red[2][None, :]).view_as(params[9])
+            for l in (2, 1):
                 grads[3 * l + 1], grads[3 * l + 2] = red[1].clone(), red[0].clone()          # bn.weight, bn.bias of layer l
                 bconst = torch.empty(3 * C[l + 1] + 4, **f32)
                 check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), l, n_total, P(gam[l]), P(aff[l]),
                                                   P(gmax[l:l + 1]), P(b['ymax'][l:l + 1]), P(bconst), st))
-                top = l == 3
                 dA = torch.empty(B, C[l], N, **f32) if l > 1 else None
-                sums = torch.zeros(R, {1: 5, 2: 2, 3: 3}[l], C[l], **f32)
-                check(L.gwtf_enc_train_backward(l, P(ys[l]), P(up), P(gp if top else None), b['amax'].data_ptr() if top else 0,
-                                                P(bconst), P(b['units_b'][l]), P(x if l == 1 else ys[l - 1]), P(aff[l - 1]),
-                                                P(Ws[0] if l == 1 else None), P(dA), P(sums),
+                sums = torch.zeros(R, 5 if l == 1 else 2, C[l], **f32)
+                check(L.gwtf_enc_train_backward(l, P(ys[l]), P(up), P(bconst), P(b['units_b'][l]), P(x if l == 1 else ys[l - 1]),
+                                                P(aff[l - 1]), P(Ws[0] if l == 1 else None), P(dA), P(sums),
                                                 P(gmax[l - 1:l]) if l > 1 else 0, B, N, st))
-                red_below = sums.sum(0)
-                if top:     # dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2  (csrc/gwtf_encoder_train.hip: gwtf_enc_train_dw3)
-                    gram, S = torch.empty(C[3], C[3], **f32), torch.empty(C[4], C[3], **f32)
-                    check(L.gwtf_enc_train_dw3(P(gp), b['amax'].data_ptr(), P(ys[2]), P(aff[2]), P(partials), P(gram), P(S),
-                                               B, N, st))
-                    s3, q3, r3 = (bconst[i * C[4]:(i + 1) * C[4], None] for i in range(3))
-                    dW = s3 * S + q3 * (Ws[3] @ gram) + r3 * red_below[2][None, :]
-                else:
-                    dW = torch.empty(C[l + 1], C[l], **f32)
-                    check(L.gwtf_enc_train_dw(l, P(ys[l]), P(up), P(bconst), P(x if l == 1 else ys[l - 1]),
-                                              P(b['table0'] if l == 1 else aff[l - 1]), P(partials), P(dW), B, N, st))
+                dW = torch.empty(C[l + 1], C[l], **f32)
+                check(L.gwtf_enc_train_dw(l, P(ys[l]), P(up), P(bconst), P(x if l == 1 else ys[l - 1]),
+                                          P(b['table0'] if l == 1 else aff[l - 1]), P(partials), P(dW), B, N, st))
                 grads[3 * l] = dW.view_as(params[3 * l])
-                red = red_below
+                red = sums.sum(0)
                 up = dA
             # layer 0 (3 -> 64): every sum its gradient needs is already there
             grads[1], grads[2] = red[1].clone(), red[0].clone()

@@ -343,30 +343,48 @@ int gwtf_enc_train_xmoments(const float* x, float* mom, int B, int N, void* stre
 /* layer 0: batch statistics of y_0 = W_0 x from the summed moments mom12; updates the running statistics (NULL: skip) */
 int gwtf_enc_train_fold0(const float* mom12, double n_total, const float* W0, const float* gamma, const float* beta,
                          float* running_mean, float* running_var, float momentum, float* aff, float* table0, void* stream);
-/* sums [2][C[layer+1]] = sum y, sum y^2 -> aff of that layer's BatchNorm; running statistics updated (momentum, unbiased var) */
+/* sums [2][C[layer+1]] = sum y, sum y^2 -> aff of that layer's BatchNorm; running statistics updated (momentum, unbiased var).
+ * aff_prev = the aff of the layer below: non-finite statistics there or here poison this whole aff with NaN (NaN propagation) */
 int gwtf_enc_train_fold(const float* sums, int layer, double n_total, const float* gamma, const float* beta,
-                        float* running_mean, float* running_var, float momentum, float* aff, void* stream);
+                        float* running_mean, float* running_var, float momentum, float* aff, const float* aff_prev,
+                        void* stream);
 /* y_out (B, C[layer+1], N) = W_layer . relu(s in + t); in = x and in_tab = table0 for layer 1, else y_{layer-1} and its aff.
- * sums [64][2][C[layer+1]] += {sum y, sum y^2}; ymax[0] = max |y| (bit pattern max, zero on entry) */
+ * sums [64][2][C[layer+1]] += {sum y, sum y^2}; ymax[0] = max |y| (bit pattern max, zero on entry).
+ * layer 3 stores no y: kmax / kmin [B][512] (zero on entry) receive 64-bit arg-max / arg-min keys of y_3 per (shape, channel) --
+ * all the max-pool needs, because BatchNorm + ReLU is monotone in y per channel (y_out may be NULL; kmax / kmin NULL otherwise) */
 int gwtf_enc_train_forward(int layer, const float* in, const float* in_tab, const float* units, float* y_out, float* sums,
-                           float* ymax, int B, int N, void* stream);
-/* pooled (B,512) = max_n relu(s y3 + t), amax = its (first) arg-max, ystar = y3 there */
-int gwtf_enc_train_pool(const float* y3, const float* aff3, float* pooled, int* amax, float* ystar, int B, int N, void* stream);
+                           float* ymax, unsigned long long* kmax, unsigned long long* kmin, int B, int N, void* stream);
+/* pooled (B,512) = max_n relu(s y3 + t) from the keys (max or min by the sign of s), amax = its first arg-max, ystar = y3 there;
+ * NaN where a statistic or the extreme is not finite */
+int gwtf_enc_train_pool(const unsigned long long* kmax, const unsigned long long* kmin, const float* aff3, float* pooled, int* amax,
+                        float* ystar, int B, void* stream);
 /* gp = g_pooled where pooled > 0; sums [2][512] = {sum gp, sum gp yhat*}; gmax[0] = max |gp| (zero on entry) */
 int gwtf_enc_train_top(const float* g_pooled, const float* pooled, const float* ystar, const float* aff3, float* gp, float* sums,
                        float* gmax, int B, void* stream);
 /* layer = 0..3 (BatchNorm of y_layer): sums [2][C[layer+1]] = {sum gm, sum gm yhat} over all points and ranks -> bconst;
- * gmax / ymax (may be NULL for layer 0): the maxima the operand scale is derived from */
+ * gmax / ymax (may be NULL): the maxima the operand scale is derived from */
 int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, const float* gamma, const float* aff,
                               const float* gmax, const float* ymax, float* bconst, void* stream);
-/* dA_prev (B, C[layer], N) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
- * (y_l, up_g = masked dL/da_layer) or, layer 3, (gp, amax).  y_prev / aff_prev: y_{layer-1} and its aff (layer 1: x, aff_0, and
- * w0 = raw W_0).  sums [64][2 (layer 3: 3, layer 1: 5)][C[layer]] += {sum gm, sum gm yhat (layer 3: , sum a) (layer 1: , sum gm x_d)} of the
- * layer below;
+/* Top layer: with dy_3 = s gm_3 + Q y_3 + R and y_3 = W_3 a_2,  dL/da_2(p) = M a_2(p) + v + (rows of the arg-max points),
+ * M = W_3^T diag(Q) W_3, v = W_3^T R (two small library GEMMs on the caller's side).
+ *   gwtf_enc_train_pack_matrix   fragment images of M * 2^k (rows x kdim row-major, here 256 x 256)
+ *   gwtf_enc_train_top_scatter   coef [B][512] = s_c gp[b][c] -> slot_of [B][N] (row of a point, or -1) and
+ *                                extra [B][512][256]: row r of shape b = sum of coef[b][c] W_3[c][:] over the channels whose
+ *                                arg-max is that point (only the used rows are written); tables: B (2 * 512 + 2) ints of scratch
+ *   gwtf_enc_train_backward_top  dA2 (B,256,N) = (M a_2 + v + extra) masked by a_2 > 0; mconst = v [256] | {2^-k};
+ *                                sums [64][3][256] += {sum gm_2, sum gm_2 yhat_2, sum a_2}; gmax2[0] = max |dA2| */
+int gwtf_enc_train_pack_matrix(const float* W, float* units, int rows, int kdim, void* stream);
+int gwtf_enc_train_top_scatter(const float* coef, const int* amax, const float* W3, float* extra, int* slot_of, int* tables,
+                               int B, int N, void* stream);
+int gwtf_enc_train_backward_top(const float* y2, const float* aff2, const float* units_m, const float* mconst, const float* extra,
+                                const int* slot_of, float* dA2, float* sums, float* gmax2, int B, int N, void* stream);
+/* layer = 1, 2: dA_prev (B, C[layer], N) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
+ * (y_l, up_g = masked dL/da_layer).  y_prev / aff_prev: y_{layer-1} and its aff (layer 1: x, aff_0, and w0 = raw W_0).
+ * sums [64][2 (layer 1: 5)][C[layer]] += {sum gm, sum gm yhat (layer 1: , sum gm x_d)} of the layer below;
  * gmax_prev[0] = max |dA_prev| */
-int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, const float* gp, const int* amax,
-                            const float* bconst, const float* units_bwd, const float* y_prev, const float* aff_prev,
-                            const float* w0, float* dA_prev, float* sums, float* gmax_prev, int B, int N, void* stream);
+int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, const float* bconst, const float* units_bwd,
+                            const float* y_prev, const float* aff_prev, const float* w0, float* dA_prev, float* sums,
+                            float* gmax_prev, int B, int N, void* stream);
 /* layer = 1, 2: dW (C[layer+1], C[layer]) = sum over this rank's points of dy_layer a_{layer-1}^T; partials: scratch of
  * gwtf_enc_train_dw_partial_floats floats; tab_prev = aff_{layer-1} (layer 1: table0, y_prev = x).  N % 4 == 0. */
 size_t gwtf_enc_train_dw_partial_floats(int layer, int B, int N);
@@ -374,7 +392,7 @@ int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const floa
                       const float* tab_prev, float* partials, float* dW, int B, int N, void* stream);
 /* layer 3 through the Gram matrix: gram (256,256) = sum_p a_2 a_2^T, S (512,256)[c] = sum_b gp[b][c] a_2(b, amax[b][c]); then
  * dW_3 = s (.) S + Q (.) (W_3 gram) + R (x) sum_p a_2  (s, Q, R = bconst of layer 3; sum_p a_2 = row 2 of the sums that
- * gwtf_enc_train_backward(layer 3) accumulates). */
+ * gwtf_enc_train_backward_top accumulates). */
 int gwtf_enc_train_dw3(const float* gp, const int* amax, const float* y2, const float* aff2, float* partials, float* gram,
                        float* S, int B, int N, void* stream);
 

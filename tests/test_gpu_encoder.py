@@ -206,3 +206,16 @@ def test_two_rank_syncbn_encoder_matches_single_process(tmp_path):
            '--master-port', str(port), os.path.join(os.path.dirname(__file__), 'dist_enc_worker.py')]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'ENC2' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_train_pipeline_propagates_non_finite_weights():
+    """A diverged encoder weight must reach the loss as NaN (the reference's isnan guard, training.py:43-46), not be laundered
+    by the max-pool keys or a ReLU compiled without NaN semantics."""
+    for bad in (float('nan'), float('inf')):
+        m = encoders.PointNetCloudEncoder(3, 64, [128, 256, 512])
+        load_synth_(m, 51)
+        m = m.to(DEV).train()
+        with torch.no_grad():
+            m.features.sd1.weight[0, 3, 5] = bad
+        pooled = m.forward_max(dev(synth_inputs(2, 64, 4, 52)[0]))
+        assert not bool(torch.isfinite(pooled).all())
