@@ -72,6 +72,17 @@ def _gather(engine, raw=None):
     }
 
 
+def _gather_film(raw, C, f, G):
+    """The FiLM-head slices of _gather for a (stacked) arena holding C couplings in all: what _film_train reads."""
+    rv = raw.reshape(C, 2, -1)
+    o_film, FS = 8 * f + f * f, f * G + 5 * f + f * f
+    films = rv[:, :, o_film:o_film + 2 * FS].reshape(C, 2, 2, FS)
+    o_hbn, o_l1, o_b1 = f * G, f * G + 4 * f, f * G + 4 * f + f * f
+    return {'raw': raw, 'L0': films[..., :o_hbn].reshape(C, 2, 2, f, G),
+            'hbn': list(films[..., o_hbn:o_l1].reshape(C, 2, 2, 4, f).unbind(3)),
+            'L1': films[..., o_l1:o_b1].reshape(C, 2, 2, f, f), 'b1': films[..., o_b1:]}
+
+
 def branch_poison(raw, C):
     """(C,2): 0 for a branch record whose parameters / buffers are all finite, NaN otherwise (0 * sum)."""
     return raw.detach().view(C, 2, -1).sum(-1) * 0.0
@@ -648,10 +659,10 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
     if rows_total < 2:
         raise ValueError('train-mode BatchNorm needs more than 1 shape per (global) batch (torch raises the same)')
     Ps = [_gather(e) for e in engines]
-    films = [_film_train(P, g_all, eps) for P in Ps]
-    a = torch.cat([q[0][row0:row0 + B] for q in films], dim=1)          # (B, K*C, 2, f)
-    bsh = torch.cat([q[1][row0:row0 + B] for q in films], dim=1)
     raw = Ps[0]['raw'].unsqueeze(0) if K == 1 else torch.stack([P['raw'] for P in Ps])
+    # the FiLM heads of all K stacks in ONE set of batched products: views of the stacked arena, K*C couplings
+    film_a, film_b, film_mean, film_var = _film_train(_gather_film(raw, K * C, f, G), g_all, eps)
+    a, bsh = film_a[row0:row0 + B], film_b[row0:row0 + B]                # (B, K*C, 2, f)
     sink = GRAD_SINK['reducer']
     if sink is not None:
         # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
@@ -664,8 +675,8 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
                                                                float(rows_total) * N, distributed)
     lists = (ps, mus, lvs)                                   # (K,C,B,3,N) each; ps / lvs differentiable
     bn_batch = bn_batch.clone()
-    bn_batch[:, :, :, 2:4, 0] = torch.stack([q[2] for q in films])
-    bn_batch[:, :, :, 2:4, 1] = torch.stack([q[3] for q in films])
+    bn_batch[:, :, :, 2:4, 0] = film_mean.view(K, C, 2, 2, f)
+    bn_batch[:, :, :, 2:4, 1] = film_var.view(K, C, 2, 2, f)
     return out, logdet, lists, bn_batch
 
 
