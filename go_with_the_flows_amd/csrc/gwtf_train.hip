@@ -684,6 +684,33 @@ extern "C" int gwtf_mtrain_backward(const GwtfTrainCtx* t) {
   return rc;
 }
 
+// ---- running statistics of all BatchNorm modules of a stack in ONE launch ---------------------------------------------------
+// table [n][3] u64 = device pointers {running_mean, running_var, num_batches_tracked (int64) or 0} of module i; src [n][2][f] =
+// batch {mean, unbiased var} (the pipeline's bn_batch); momentum [n].  running = (1 - m) running + m batch, counter += 1:
+// torch.nn.BatchNorm1d's update (reference flows.py:27-42 modules in train mode), instead of five _foreach_ calls over n tensors.
+namespace {
+__global__ void bn_running_update_kernel(const unsigned long long* __restrict__ table, const float* __restrict__ src,
+                                         const float* __restrict__ momentum, int n, int f) {
+  const int i = blockIdx.x;
+  float* rm = reinterpret_cast<float*>(table[3 * (size_t)i]);
+  float* rv = reinterpret_cast<float*>(table[3 * (size_t)i + 1]);
+  long long* nbt = reinterpret_cast<long long*>(table[3 * (size_t)i + 2]);
+  const float m = momentum[i];
+  for (int j = threadIdx.x; j < f; j += blockDim.x) {
+    rm[j] = (1.0f - m) * rm[j] + m * src[((size_t)i * 2 + 0) * f + j];
+    rv[j] = (1.0f - m) * rv[j] + m * src[((size_t)i * 2 + 1) * f + j];
+  }
+  if (nbt && threadIdx.x == 0) *nbt += 1;
+}
+}  // namespace
+
+extern "C" int gwtf_bn_running_update(const unsigned long long* table, const float* src, const float* momentum, int n, int f,
+                                      void* stream) {
+  if (!table || !src || !momentum || n <= 0 || f <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, table, src, momentum, n, f);
+  return (int)hipGetLastError();
+}
+
 // which half of xbuf / g_bufs holds the final coordinates / dL/dp of component k: base + half * K*B*3*N + k * B*3*N
 extern "C" int gwtf_mtrain_final_forward_half(int C) { return (C - 1) & 1; }
 extern "C" int gwtf_mtrain_final_backward_half(int C, int mode) { return (mode == GWTF_MODE_INVERSE ? C - 1 : 0) & 1; }

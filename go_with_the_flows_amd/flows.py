@@ -350,29 +350,52 @@ class StackEngine:
     def _update_running_stats(self, bn_batch):
         """running = (1-m)*running + m*batch with the unbiased batch variance (torch.nn.BatchNorm1d semantics)."""
         stamp = sum(c._stamp for c in self.couplings)
-        if self._bn_cache is None or self._bn_cache[0] != stamp:     # module / buffer lists per momentum value, cached
+        if self._bn_cache is None or self._bn_cache[0] != stamp:
+            # (re)derive the pointer rows; the device table is rebuilt only when a pointer really changed (load_state_dict copies
+            # in place and keeps them), because building it is a host-to-device copy -- not allowed while a hipGraph is captured
             mods = self._bn_modules()
-            groups = {}
+            rows, moms, touched = [], [], []
             for i, m in enumerate(mods):
                 if m.track_running_stats and m.running_mean is not None:
                     if m.momentum is None:
                         raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported by the fused '
                                                   'running-statistic update; the reference never sets it (flows.py:27-42)')
-                    groups.setdefault(float(m.momentum), []).append(i)
-            plan = [(mom, idx, [mods[i].running_mean for i in idx], [mods[i].running_var for i in idx])
-                    for mom, idx in groups.items()]
-            self._bn_cache = (stamp, len(mods), plan, [m.num_batches_tracked for m in mods if m.num_batches_tracked is not None])
-        _, n_mods, plan, counters = self._bn_cache
+                    nbt = m.num_batches_tracked
+                    rows.append((i, m.running_mean.data_ptr(), m.running_var.data_ptr(), nbt.data_ptr() if nbt is not None else 0,
+                                 float(m.momentum)))
+                    touched += [m.running_mean, m.running_var] + ([nbt] if nbt is not None else [])
+            old = self._bn_cache
+            if old is not None and old[3] == rows and old[2][0] is not None and old[2][0].device == bn_batch.device:
+                self._bn_cache = (stamp, len(mods), old[2], rows, touched)
+            elif torch.cuda.is_current_stream_capturing():
+                self._bn_cache = (stamp, len(mods), None, rows, touched)       # this capture takes the _foreach_ route below
+            else:
+                dev = bn_batch.device
+                table = torch.tensor([r[1:4] for r in rows], dtype=torch.int64).to(dev) if rows else None
+                momentum = torch.tensor([r[4] for r in rows], dtype=torch.float32).to(dev) if rows else None
+                index = None if len(rows) == len(mods) else torch.tensor([r[0] for r in rows], dtype=torch.int64, device=dev)
+                self._bn_cache = (stamp, len(mods), (table, momentum, index), rows, touched)
+        _, n_mods, dev_tabs, rows, touched = self._bn_cache
+        if not rows:
+            return
         with torch.no_grad():
             flat = bn_batch.reshape(n_mods, 2, self.f)
-            means, variances = flat[:, 0].unbind(0), flat[:, 1].unbind(0)
-            for mom, idx, rms, rvs in plan:
-                whole = len(idx) == n_mods
-                torch._foreach_mul_(rms, 1.0 - mom)
-                torch._foreach_add_(rms, list(means) if whole else [means[i] for i in idx], alpha=mom)
-                torch._foreach_mul_(rvs, 1.0 - mom)
-                torch._foreach_add_(rvs, list(variances) if whole else [variances[i] for i in idx], alpha=mom)
-            torch._foreach_add_(counters, 1)
+            if dev_tabs is None:      # no device table yet (first call fell inside a graph capture): plain _foreach_ updates
+                mods = self._bn_modules()
+                for i, _rm, _rv, _nbt, mom in rows:
+                    mods[i].running_mean.mul_(1.0 - mom).add_(flat[i, 0], alpha=mom)
+                    mods[i].running_var.mul_(1.0 - mom).add_(flat[i, 1], alpha=mom)
+                    if mods[i].num_batches_tracked is not None:
+                        mods[i].num_batches_tracked.add_(1)
+                return
+            table, momentum, index = dev_tabs
+            if index is not None:
+                flat = flat.index_select(0, index)
+            flat = flat.contiguous()
+            with torch.cuda.device(flat.device):
+                _lib.check(_lib.lib().gwtf_bn_running_update(table.data_ptr(), _lib._ptr(flat, 'bn_batch'), _lib._ptr(momentum, 'momentum'),
+                                                            table.shape[0], self.f, _lib._stream(flat)))
+            torch._C._increment_version(touched)      # written through raw pointers: the packed-weight caches key on versions
 
     def _run_train(self, p, g, mode, want_lists):
         """model.train() forward without autograd: statistics over all B*N points, running statistics updated with the

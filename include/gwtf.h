@@ -224,6 +224,10 @@ typedef struct GwtfTrainCtx {
   float* g_raw;              /* [K][C][raw record]   zero; receives dW0, dgamma0, dbeta0, dW1, dW2, db2 */
   void* stream;
 } GwtfTrainCtx;
+/* running = (1 - m) running + m batch for n BatchNorm modules in one launch (torch.nn.BatchNorm1d's train-mode buffer update):
+ * table [n][3] = device pointers {running_mean [f], running_var [f], num_batches_tracked (int64, += 1) or 0}; src [n][2][f] =
+ * batch {mean, unbiased var} (bn_batch of the train pipeline); momentum [n]. */
+int gwtf_bn_running_update(const unsigned long long* table, const float* src, const float* momentum, int n, int f, void* stream);
 size_t gwtf_mtrain_dw1_floats(int f, int B, int N);
 int gwtf_mtrain_phase(const GwtfTrainCtx* ctx, int phase, int step);
 int gwtf_mtrain_forward(const GwtfTrainCtx* ctx);
