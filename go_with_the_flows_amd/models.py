@@ -121,6 +121,39 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
             return self.p_prior_mus, self.p_prior_logvar
         raise ValueError(f'unknown p_decoder_base_type {self.p_decoder_base_type!r}')
 
+    def _base_gaussian_repeated(self, g_sample, times):
+        """_base_gaussian evaluated ONCE with the buffer side effects of `times` evaluations on the same batch: every tracked
+        BatchNorm of p_prior in train mode gets running = (1-m) running + m batch applied `times - 1` more times (the batch
+        statistics recomputed from the module's input, unbiased variance) and num_batches_tracked += times - 1."""
+        bns = [mod for mod in getattr(self, 'p_prior', nn.Module()).modules()
+               if isinstance(mod, nn.modules.batchnorm._BatchNorm) and mod.training and mod.track_running_stats]
+        if times <= 1 or not bns or self.p_decoder_base_type == 'fixed':
+            return self._base_gaussian(g_sample)
+        seen, hooks = {}, []
+        for mod in bns:
+            hooks.append(mod.register_forward_pre_hook(lambda md, args: seen.__setitem__(md, args[0].detach())))
+        try:
+            out = self._base_gaussian(g_sample)
+        finally:
+            for h in hooks:
+                h.remove()
+        with torch.no_grad():
+            for mod in bns:
+                x = seen.get(mod)
+                if x is None or mod.momentum is None:
+                    for _ in range(times - 1):           # cumulative-average BatchNorm: no closed form kept here, just re-run
+                        self._base_gaussian(g_sample)
+                    return out
+                dims = [d for d in range(x.dim()) if d != 1]
+                mean, var = x.mean(dims), x.var(dims, unbiased=True)
+                keep = (1.0 - mod.momentum) ** (times - 1)
+                # .data: the batch-norm node saved these buffers for its backward (it only reads them in eval mode); the replayed
+                # updates must not trip autograd's version check -- K real passes update them in place between passes as well
+                mod.running_mean.data.mul_(keep).add_(mean, alpha=1.0 - keep)
+                mod.running_var.data.mul_(keep).add_(var, alpha=1.0 - keep)
+                mod.num_batches_tracked.data.add_(times - 1)
+        return out
+
     def one_flow_decode(self, p_input, g_sample, pc_decoder, n_sampled_points):
         """models.py:153-207: lists for ONE component (inverse on p_input when training, direct on a base draw otherwise)."""
         B, P = g_sample.shape[0], self.p_latent_space_size
@@ -259,11 +292,12 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
         g_sample = output_encoder['g_posterior_samples']
         logits = self.get_weights(g_sample, warmup)
         B, K, P = g_sample.shape[0], self.n_components, self.p_latent_space_size
-        mu0, lv0 = [], []
-        for _ in range(K):                   # the reference evaluates p_prior once per component (running statistics!)
-            m, v = self._base_gaussian(g_sample)
-            mu0.append(m.expand(B, P, 1)[:, :, 0])
-            lv0.append(v.expand(B, P, 1)[:, :, 0])
+        # The reference evaluates p_prior once per component (models.py:169-193 inside the K loop of flow_mixture.py:163-166): K
+        # identical outputs, and K running-statistic updates with the same batch statistics.  One evaluation here; its BatchNorm
+        # modules replay the other K - 1 buffer updates (same values as K passes would leave, to rounding).
+        m, v = self._base_gaussian_repeated(g_sample, K)
+        mu0 = [m.expand(B, P, 1)[:, :, 0]] * K
+        lv0 = [v.expand(B, P, 1)[:, :, 0]] * K
         z, logdet = self.mixture_stack().forward_all(p_input, g_sample, mode='inverse')
         self.finish_encode(output_encoder)
         return output_encoder, {'z': z, 'logdet': logdet, 'mu0': torch.stack(mu0), 'lv0': torch.stack(lv0), 'logits': logits}
