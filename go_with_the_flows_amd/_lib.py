@@ -91,6 +91,7 @@ _SIGNATURES = {
     'gwtf_prior_forward': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_prior_backward': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_bn_running_update': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_gather_table': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_mtrain_dw1_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'gwtf_mtrain_phase': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'gwtf_mtrain_forward': (ctypes.c_int, [ctypes.c_void_p]),

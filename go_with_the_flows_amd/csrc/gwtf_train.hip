@@ -711,6 +711,25 @@ extern "C" int gwtf_bn_running_update(const unsigned long long* table, const flo
   return (int)hipGetLastError();
 }
 
+// ---- the raw arena of a stack gathered from its ~1300 parameter / buffer tensors in ONE launch -----------------------------------
+// table [n][3] u64 = {source device pointer, destination offset (floats), number of floats}; one workgroup per tensor (they are
+// small: at most f G floats).  torch.cat of the same views is a launch per 128 inputs.
+namespace {
+__global__ void gather_table_kernel(const unsigned long long* __restrict__ table, float* __restrict__ dst, int n) {
+  const unsigned long long* row = table + 3 * (size_t)blockIdx.x;
+  const float* __restrict__ src = reinterpret_cast<const float*>(row[0]);
+  float* __restrict__ out = dst + row[1];
+  const size_t m = row[2];
+  for (size_t i = threadIdx.x; i < m; i += blockDim.x) out[i] = src[i];
+}
+}  // namespace
+
+extern "C" int gwtf_gather_table(const unsigned long long* table, float* dst, int n, void* stream) {
+  if (!table || !dst || n <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(gather_table_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, table, dst, n);
+  return (int)hipGetLastError();
+}
+
 // which half of xbuf / g_bufs holds the final coordinates / dL/dp of component k: base + half * K*B*3*N + k * B*3*N
 extern "C" int gwtf_mtrain_final_forward_half(int C) { return (C - 1) & 1; }
 extern "C" int gwtf_mtrain_final_backward_half(int C, int mode) { return (mode == GWTF_MODE_INVERSE ? C - 1 : 0) & 1; }

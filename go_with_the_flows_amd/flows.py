@@ -246,7 +246,29 @@ class StackEngine:
         return self._cat_detached()
 
     def _cat_detached(self):
-        return torch.cat(self._flat)
+        """The flat arena from the cached detached views: one pointer-table kernel (csrc/gwtf_train.hip) on a HIP device --
+        torch.cat would be a launch per 128 inputs, eleven for an 11-Triple decoder.  The device table is rebuilt only when a
+        source pointer changed (it is a host-to-device copy: not allowed inside a hipGraph capture, where torch.cat stands in)."""
+        flat = self._flat
+        if not flat[0].is_cuda:
+            return torch.cat(flat)
+        rows, off = [], 0
+        tab = getattr(self, '_gather_tab', None)
+        if tab is None or tab[0] is not flat:
+            for t, n in zip(flat, self._sizes):
+                rows.append((t.data_ptr(), off, n))
+                off += n
+            if tab is not None and tab[1] == rows:
+                tab = self._gather_tab = (flat, rows, tab[2], off)
+            elif torch.cuda.is_current_stream_capturing():
+                return torch.cat(flat)
+            else:
+                tab = self._gather_tab = (flat, rows, torch.tensor(rows, dtype=torch.int64).to(flat[0].device), off)
+        _, rows, table, total = tab
+        out = torch.empty(total, device=flat[0].device, dtype=torch.float32)
+        with torch.cuda.device(out.device):
+            _lib.check(_lib.lib().gwtf_gather_table(table.data_ptr(), out.data_ptr(), len(rows), _lib._stream(out)))
+        return out
 
     def _collect(self):
         self._key(False)

@@ -228,6 +228,9 @@ typedef struct GwtfTrainCtx {
  * table [n][3] = device pointers {running_mean [f], running_var [f], num_batches_tracked (int64, += 1) or 0}; src [n][2][f] =
  * batch {mean, unbiased var} (bn_batch of the train pipeline); momentum [n]. */
 int gwtf_bn_running_update(const unsigned long long* table, const float* src, const float* momentum, int n, int f, void* stream);
+/* dst[offset_i .. + numel_i) = src_i for n small tensors in one launch: table [n][3] = {src device pointer, offset, numel}
+ * (floats).  Builds a stack's raw arena from its parameter / buffer tensors (the host mirror's torch.cat, one launch). */
+int gwtf_gather_table(const unsigned long long* table, float* dst, int n, void* stream);
 size_t gwtf_mtrain_dw1_floats(int f, int B, int N);
 int gwtf_mtrain_phase(const GwtfTrainCtx* ctx, int phase, int step);
 int gwtf_mtrain_forward(const GwtfTrainCtx* ctx);
