@@ -245,7 +245,7 @@ int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* pa
                         float* g_in, float* dw1_ws, float* g_sd0, int B, int N, int f, int pattern, void* stream);
 
 /* The sd1 weight gradient dW1[br][j][i] = sum_p dL/dacc[br][j](p) * h[br][i](p) is accumulated INSIDE the backward kernels
- * (points on the MFMA K axis, csrc/gwtf_bwd.hip); every workgroup leaves a [2][FP][FP] partial in the workspace.
+ * (points on the MFMA K axis, csrc/gwtf_bwd.hip); every workgroup leaves a compact [2][f][f] partial in the workspace.
  *   gwtf_dw1_partials(B, N)             partials one backward pass writes
  *   gwtf_dw1_workspace_floats(f, B, N)  floats of one pass's workspace region
  *   gwtf_dw1_reduce_scratch_floats(f)   floats of scratch the reduction needs AFTER the last region of the same buffer
