@@ -285,10 +285,14 @@ class PointNetCloudEncoder(nn.Module):
         list the kernels were built for, no gradient wanted for the points themselves, N a multiple of 4."""
         if not self.training or x.dim() != 3 or x.shape[1] != 3 or x.shape[2] % 4 or x.shape[0] == 0:
             return False
+        if x.shape[2] > 12288:               # the arg-max row tables of the top layer's backward index the points of a shape in LDS
+            return False
         if torch.is_grad_enabled() and x.requires_grad:
             return False
         bns = [m for m in self.features.children() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
-        if any(bn.momentum is None or not bn.affine for bn in bns):
+        if any(bn.momentum is None or not bn.affine or not bn.training for bn in bns):     # a frozen (eval) BatchNorm: library path
+            return False
+        if len({_bn_sync(bn) for bn in bns}) > 1:                                            # mixed plain / synchronised modules
             return False
         w, n = self._widths_c()
         return bool(_lib.lib().gwtf_enc_train_supported(w, n))

@@ -129,6 +129,13 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
                if isinstance(mod, nn.modules.batchnorm._BatchNorm) and mod.training and mod.track_running_stats]
         if times <= 1 or not bns or self.p_decoder_base_type == 'fixed':
             return self._base_gaussian(g_sample)
+        import torch.distributed as dist
+        if any(isinstance(mod, nn.SyncBatchNorm) for mod in bns) and dist.is_available() and dist.is_initialized() \
+                and dist.get_world_size() > 1:
+            out = self._base_gaussian(g_sample)          # synchronised statistics are not this rank's alone: really run K passes
+            for _ in range(times - 1):
+                self._base_gaussian(g_sample)
+            return out
         seen, hooks = {}, []
         for mod in bns:
             hooks.append(mod.register_forward_pre_hook(lambda md, args: seen.__setitem__(md, args[0].detach())))
