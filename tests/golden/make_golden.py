@@ -275,6 +275,33 @@ def g9_train_gradients():
     save('g9_train_gradients', **out)
 
 
+def g18_train_gradients_at_config_depth():
+    """Train-mode gradients of the genuine reference at the airplane config's full depth (11 Triples = 33 couplings, f = 37,
+    G = 128): every coupling's batch statistics depend on all couplings before it, so this is where errors of the backward
+    pipeline would compound.  fp32 as the reference runs and fp64 for the noise floor.  Stored: outputs, loss, input gradients,
+    the L2 norm of every parameter gradient, and the full gradients of three couplings (first, middle, last)."""
+    L, f, G, B, N = 11, 37, 128, 3, 96
+    p, g = synth_inputs(B, N, G, 1801)
+    keep = ('flows.0.nvp1.', 'flows.5.nvp2.', 'flows.10.nvp3.')
+    out = {'dims': np.array([L, f, G, B, N]), 'p': p, 'g': g}
+    for dt, suffix in ((torch.float32, ''), (torch.float64, '_f64')):
+        ref, mine = rdec.LocalCondRNVPDecoder(L, f, G), ours.LocalCondRNVPDecoder(L, f, G)
+        load_into(ref, mine, 1800)
+        ref = ref.to(dt).train()
+        pt, gt = T(p).to(dt).requires_grad_(True), T(g).to(dt).requires_grad_(True)
+        ps, mus, lvs = ref(pt, gt, mode='inverse')
+        loss = 0.5 * (sum(lvs) + ps[0] ** 2).sum() / B
+        loss.backward()
+        out['loss' + suffix] = npy(loss).astype(np.float64)
+        out['z' + suffix], out['logdet' + suffix] = npy(ps[0]).astype(np.float32), npy(sum(lvs)).astype(np.float32)
+        out['dp' + suffix], out['dg' + suffix] = npy(pt.grad).astype(np.float32), npy(gt.grad).astype(np.float32)
+        out['gnorm' + suffix] = np.array([float(v.grad.double().norm()) for _, v in ref.named_parameters()])
+        for k, v in ref.named_parameters():
+            if k.startswith(keep):
+                out['grad' + suffix + '::' + k] = npy(v.grad).astype(np.float32)
+    save('g18_train_depth_11x37x128', **out)
+
+
 def g10_optimizer():
     """Three steps of the reference's Adam (both amsgrad settings, with weight decay and the LRUpdater schedule)."""
     from lib.networks.optimizers import Adam as RefAdam, LRUpdater
@@ -566,6 +593,7 @@ CASES = {
     'g7': g7_model_training_forward,
     'g8': g8_gradients,
     'g9': g9_train_gradients,
+    'g18': g18_train_gradients_at_config_depth,
     'g10': g10_optimizer,
     'g11': g11_encoder,
     'g17': g17_encoder_train,
