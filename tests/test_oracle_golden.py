@@ -222,6 +222,34 @@ def test_torch_port_train_mode_gradients_match_reference():
             assert maxabs(tst[key[6:]].grad.numpy(), ref) / (np.abs(ref).max() + 1e-12) < 2e-4, key
 
 
+def test_torch_port_train_mode_gradients_at_config_depth_fp64():
+    """The port in fp64 against the reference's fp64 run at the airplane decoder's full depth (33 couplings, golden g18): the two
+    agree to 1e-8 where their fp32 runs scatter by 1e-3 -- the formulas are the same, the fp32 differences are rounding."""
+    import torch
+    from oracle import torch_port as tp
+    D = golden('g18_train_depth_11x37x128')
+    L, f, G, B, N = (int(v) for v in D['dims'])
+    _, st = decoder_and_state(L, f, G, 1800)
+    tst = {}
+    for k, v in st.items():
+        t = torch.from_numpy(v).clone()
+        t = t.double() if t.is_floating_point() else t
+        tst[k] = t.requires_grad_(t.is_floating_point() and not k.endswith(('running_mean', 'running_var', 'eps')))
+    pt, gt = torch.from_numpy(D['p']).double().requires_grad_(True), torch.from_numpy(D['g']).double().requires_grad_(True)
+    z, ld = tp.decoder_fused(pt, gt, tst, L, 'inverse', grad=True, training=True)
+    loss = 0.5 * (ld + z ** 2).sum() / B
+    loss.backward()
+    assert abs(float(loss.detach()) - float(D["loss_f64"])) / abs(float(D["loss_f64"])) < 1e-10
+    # the golden keeps its fp64 arrays rounded to fp32 once: 6e-8 relative is the floor of these comparisons
+    assert maxabs(z.detach().numpy(), D['z_f64']) / np.abs(D['z_f64']).max() < 2e-7
+    assert maxabs(pt.grad.numpy(), D['dp_f64']) / np.abs(D['dp_f64']).max() < 2e-7
+    assert maxabs(gt.grad.numpy(), D['dg_f64']) / np.abs(D['dg_f64']).max() < 2e-7
+    for key in D.files:
+        if key.startswith('grad_f64::'):
+            ref = D[key]
+            assert maxabs(tst[key[10:]].grad.numpy(), ref) / (np.abs(ref).max() + 1e-30) < 2e-7, key
+
+
 SCHED = dict(cycle_length=4, min_lr=1e-3, max_lr=1e-2, beta1=0.9, min_beta2=0.9, max_beta2=0.99)
 
 
