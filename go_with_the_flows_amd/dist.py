@@ -45,11 +45,59 @@ def sum_over_ranks(t):
     return t
 
 
-def all_reduce_gradients(module, average=True, force=False):
+def all_reduce_direct(flat, group=None):
+    """Sum `flat` over the ranks with the DIRECT algorithm: reduce-scatter + all-gather done as point-to-point
+    messages between every pair of ranks, not around a ring.  On an MI355X node every GPU has its own xGMI link to each of the
+    other seven (7 x ~153 GB/s, no switch), so a rank can send its W - 1 chunks to their owners at the same time over W - 1
+    different links and the whole exchange is two steps of n / W elements per link -- a ring all-reduce moves 2 (W - 1) / W n
+    elements through EVERY link in 2 (W - 1) dependent steps.  In place; `flat` is a contiguous 1-D tensor of any length (the
+    chunk grid is padded on the fly).  Uses only batched isend / irecv, which RCCL ('nccl') and gloo both provide."""
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat
+    rank = dist.get_rank(group)
+    n = flat.numel()
+    chunk = (n + world - 1) // world
+    bounds = [(min(n, r * chunk), min(n, (r + 1) * chunk)) for r in range(world)]
+    lo, hi = bounds[rank]
+    peers = [r for r in range(world) if r != rank]
+    to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    # step 1 (reduce-scatter): chunk r of every rank goes to rank r; mine arrives from everybody else
+    inbox = [torch.empty(hi - lo, dtype=flat.dtype, device=flat.device) for _ in peers]
+    ops = []
+    for r, buf in zip(peers, inbox):
+        a, b = bounds[r]
+        if b > a:
+            ops.append(dist.P2POp(dist.isend, flat[a:b], to_global(r), group))
+        if hi > lo:
+            ops.append(dist.P2POp(dist.irecv, buf, to_global(r), group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    mine = flat[lo:hi]
+    for buf in inbox:                      # fixed order of additions: rank 0's, rank 1's, ... -- the same sum on every run
+        mine.add_(buf)
+    # step 2 (all-gather): the reduced chunk goes to everybody, theirs arrive in place
+    ops = []
+    for r in peers:
+        a, b = bounds[r]
+        if hi > lo:
+            ops.append(dist.P2POp(dist.isend, mine, to_global(r), group))
+        if b > a:
+            ops.append(dist.P2POp(dist.irecv, flat[a:b], to_global(r), group))
+    for w in (dist.batch_isend_irecv(ops) if ops else []):
+        w.wait()
+    return flat
+
+
+def all_reduce_gradients(module, average=True, force=False, algorithm='ring'):
     """Data-parallel gradient exchange as ONE flat fp32 buffer (19-104 MB per step for the shipped
     configs): flatten every .grad, a single all-reduce over the default group (RCCL on ROCm: backend 'nccl'), divide
     by the world size (DDP semantics, reference train_ae.py:153), scatter back.  A drop-in for DistributedDataParallel
-    when the model is used without the DDP wrapper; with DDP, its bucketed all-reduce does the same job."""
+    when the model is used without the DDP wrapper; with DDP, its bucketed all-reduce does the same job.
+    algorithm: 'ring' = the library's all-reduce (RCCL picks its own schedule); 'direct' = all_reduce_direct, the point-to-point
+    reduce-scatter + all-gather sized for the xGMI mesh."""
+    if algorithm not in ('ring', 'direct'):
+        raise ValueError(f'unknown gradient exchange algorithm {algorithm!r}')
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force):
         return 0          # force=True still runs the collective on a 1-rank group (exercises the RCCL path on one GPU)
     params = [p for p in module.parameters() if p.grad is not None]
@@ -57,7 +105,10 @@ def all_reduce_gradients(module, average=True, force=False):
         return 0
     grads = [p.grad for p in params]
     flat = torch.cat([g.reshape(-1) for g in grads])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if algorithm == 'direct':
+        all_reduce_direct(flat)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average:
         flat.div_(dist.get_world_size())
     # scatter back with ONE multi-tensor copy (a per-parameter copy_ is ~650 launches for the airplane model)

@@ -36,7 +36,10 @@ def main():
     assert 'EncoderTrainFn' in type(pooled.grad_fn).__name__
     (pooled * torch.from_numpy(wgt[b0:b1]).cuda()).sum().backward()
     grads = torch.cat([q.grad.reshape(-1) for q in m.parameters()])
+    from go_with_the_flows_amd.dist import all_reduce_direct
+    direct = all_reduce_direct(grads.clone())                  # point-to-point reduce-scatter + all-gather on device tensors
     dist.all_reduce(grads)                                     # what DDP does (it also divides by the world size)
+    assert float((direct - grads).abs().max()) <= 1e-6 * float(grads.abs().max())
     bufs = torch.cat([v.reshape(-1).float() for k, v in m.state_dict().items() if 'running' in k])
     np.savez(os.path.join(os.environ['GWTF_TMP'], f'enc{rank}.npz'), pooled=pooled.detach().cpu().numpy(),
              grads=grads.cpu().numpy(), bufs=bufs.cpu().numpy())

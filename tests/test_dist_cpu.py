@@ -55,3 +55,39 @@ def _worker(rank, world, port, tmp):
 def test_two_rank_gloo_sharding(tmp_path):
     port = 29500 + os.getpid() % 2000
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+
+
+def _direct_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from go_with_the_flows_amd.dist import init_from_env, all_reduce_direct, all_reduce_gradients
+    init_from_env('gloo')
+    for n in (1, 2, 5, 1000, 4099):                      # fewer elements than ranks, ragged last chunk, empty chunks
+        g = torch.Generator().manual_seed(100 * n + rank)
+        mine = torch.randn(n, generator=g)
+        want = mine.clone()
+        dist.all_reduce(want, op=dist.ReduceOp.SUM)
+        got = all_reduce_direct(mine.clone())
+        assert torch.allclose(got, want, rtol=1e-6, atol=1e-6), (n, rank)
+        # every rank must end with bit-identical values (DDP semantics: replicas stay in sync)
+        ref = got.clone()
+        dist.broadcast(ref, src=0)
+        assert torch.equal(got, ref), (n, rank)
+    # through the module-level entry point: gradients averaged over the ranks
+    lin = torch.nn.Linear(7, 3)
+    with torch.no_grad():
+        for p in lin.parameters():
+            p.grad = torch.full_like(p, float(rank + 1))
+    n_flat = all_reduce_gradients(lin, average=True, algorithm='direct')
+    assert n_flat == 7 * 3 + 3
+    mean = sum(r + 1.0 for r in range(world)) / world
+    assert all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in lin.parameters())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_direct_reduce_scatter_all_gather_equals_all_reduce(world):
+    """The point-to-point (xGMI-mesh) gradient exchange against the library all-reduce, 2 and 3 gloo ranks."""
+    port = 31500 + os.getpid() % 2000 + world
+    mp.spawn(_direct_worker, args=(world, port), nprocs=world, join=True)
