@@ -22,6 +22,7 @@
 // reduction), and writes it to a per-workgroup partial that gwtf_dw1_reduce sums in a fixed order: nothing of size
 // O(B N f) is written to HBM any more (it was 100-150 MB per coupling).
 #include "gwtf_device.h"
+#include "gwtf_dw1.h"
 
 namespace {
 
@@ -646,49 +647,20 @@ extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, cons
 // `passes` consecutive regions of gwtf_dw1_partials(B, N) partials each: coupling path [+ statistics path]); fixed
 // summation order -> deterministic.  64 outputs per workgroup x 4 slices of the partial axis, combined through LDS.
 namespace {
-constexpr int kDw1Stage = 64;    // stage 1 folds the partials into this many sums (fixed partition -> deterministic)
+constexpr int kDw1Stage = gwtf_dw1::kStage;
 
-// stage 1: grid (element tiles of 256, kDw1Stage); out[chunk][e] = sum over the chunk's partials of ws[p][e], e over the
-// whole [2][f][f] record (coalesced); thousands of workgroups stream the workspace at HBM rate
+// stage 1: grid (element tiles of 256, kDw1Stage, K); thousands of workgroups stream the workspace at HBM rate
 __global__ __launch_bounds__(256) void dw1_fold_kernel(const float* __restrict__ ws, int n_partials, float* __restrict__ mid,
                                                        int rec, size_t ws_sk) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= rec) return;
-  ws += blockIdx.z * ws_sk;        // blockIdx.z = mixture component (K-batched train pipeline)
-  mid += blockIdx.z * ws_sk;
-  const int per = (n_partials + kDw1Stage - 1) / kDw1Stage;
-  const int p0 = blockIdx.y * per, p1 = min(n_partials, p0 + per);
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  int p = p0;
-  for (; p + 3 < p1; p += 4)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] += ws[(size_t)(p + u) * rec + e];
-  for (; p < p1; ++p) s[0] += ws[(size_t)p * rec + e];
-  mid[(size_t)blockIdx.y * rec + e] = (s[0] + s[1]) + (s[2] + s[3]);
+  // blockIdx.z = mixture component (K-batched train pipeline)
+  gwtf_dw1::fold_block(ws + blockIdx.z * ws_sk, n_partials, mid + blockIdx.z * ws_sk, rec, blockIdx.x, blockIdx.y, threadIdx.x);
 }
 
-// stage 2: 64 outputs per workgroup x 4 slices of the kDw1Stage sums, combined through LDS; crops FP -> f
+// stage 2: grid (tiles of 64 outputs, K)
 __global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict__ mid, float* __restrict__ out, int FP, int f,
                                                          size_t branch_stride, size_t ws_sk, size_t out_sk) {
   __shared__ float part[4][64];
-  mid += blockIdx.y * ws_sk;       // blockIdx.y = mixture component
-  out += blockIdx.y * out_sk;
-  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int t = blockIdx.x * 64 + e;
-  const bool on = t < 2 * f * f;
-  const int br = on ? t / (f * f) : 0, j = on ? (t / f) % f : 0, i = on ? t % f : 0;
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  if (on) {
-    const float* src = mid + (size_t)br * f * f + (size_t)j * f + i;      // compact [2][f][f] records
-    const size_t stride = (size_t)2 * f * f;
-#pragma unroll
-    for (int c = sl * (kDw1Stage / 4); c < (sl + 1) * (kDw1Stage / 4); c += 4)
-#pragma unroll
-      for (int u = 0; u < 4; ++u) s[u] += src[(size_t)(c + u) * stride];
-  }
-  part[sl][e] = (s[0] + s[1]) + (s[2] + s[3]);
-  __syncthreads();
-  if (sl == 0 && on) out[(size_t)br * branch_stride + (size_t)j * f + i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+  gwtf_dw1::reduce_block(mid + blockIdx.y * ws_sk, out + blockIdx.y * out_sk, f, branch_stride, blockIdx.x, threadIdx.x, part);
 }
 }  // namespace
 

@@ -1,0 +1,50 @@
+// gwtf_dw1.h -- the two stages of the dW1 partial reduction as device functions, shared by the stand-alone kernels
+// (gwtf_bwd.hip: gwtf_dw1_reduce) and by the train pipeline's merged tail kernels (gwtf_train.hip), which run them beside the
+// sd0 fold / the gradient combine in ONE launch each.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace gwtf_dw1 {
+
+constexpr int kStage = 64;    // stage 1 folds the partials into this many sums (fixed partition -> deterministic)
+
+// stage 1, block (bx = element tile of 256, by = chunk < kStage, component already applied to ws / mid):
+// mid[by][e] = sum over the chunk's partials of ws[p][e], e over the whole compact [2][f][f] record (coalesced)
+__device__ __forceinline__ void fold_block(const float* __restrict__ ws, int n_partials, float* __restrict__ mid, int rec, int bx,
+                                           int by, int tid) {
+  const int e = bx * 256 + tid;
+  if (e >= rec) return;
+  const int per = (n_partials + kStage - 1) / kStage;
+  const int p0 = by * per, p1 = min(n_partials, p0 + per);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int p = p0;
+  for (; p + 3 < p1; p += 4)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s[u] += ws[(size_t)(p + u) * rec + e];
+  for (; p < p1; ++p) s[0] += ws[(size_t)p * rec + e];
+  mid[(size_t)by * rec + e] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// stage 2, block bx = 64 outputs x 4 slices of the kStage sums, combined through LDS (`part`: 4 x 64 floats of the caller's
+// LDS; all 256 threads of the block must call)
+__device__ __forceinline__ void reduce_block(const float* __restrict__ mid, float* __restrict__ out, int f, size_t branch_stride,
+                                             int bx, int tid, float (*part)[64]) {
+  const int e = tid & 63, sl = tid >> 6;
+  const int t = bx * 64 + e;
+  const bool on = t < 2 * f * f;
+  const int br = on ? t / (f * f) : 0, j = on ? (t / f) % f : 0, i = on ? t % f : 0;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if (on) {
+    const float* src = mid + (size_t)br * f * f + (size_t)j * f + i;      // compact [2][f][f] records
+    const size_t stride = (size_t)2 * f * f;
+#pragma unroll
+    for (int c = sl * (kStage / 4); c < (sl + 1) * (kStage / 4); c += 4)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) s[u] += src[(size_t)(c + u) * stride];
+  }
+  part[sl][e] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (sl == 0 && on) out[(size_t)br * branch_stride + (size_t)j * f + i] = (part[0][e] + part[1][e]) + (part[2][e] + part[3][e]);
+}
+
+}  // namespace gwtf_dw1

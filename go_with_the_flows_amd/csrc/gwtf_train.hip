@@ -13,6 +13,7 @@
 // Everything here is O(f) or O(B*f) work: latency, not throughput.
 #include <hip/hip_runtime.h>
 #include "gwtf_layout.h"
+#include "gwtf_dw1.h"
 #include "../../include/gwtf.h"
 
 namespace {
@@ -342,17 +343,18 @@ __device__ inline KeptMoments kept_moments(const float (&mom)[9], int k0, int k1
 // g_sd0 replicas -> dW0, dgamma0, dbeta0, and this workgroup's share of the five sums the moment gradients need.
 // Every (branch, feature) is independent up to those sums: grid = (branch, tile of 16 features), block = 16 slices (over
 // the replicas) x 16 features; the partial sums go to `part` [2][FP/16][5] doubles and combine_kernel finishes the job.
-__global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
+// block (bx = branch, by = tile of 16 features of n_by, bz = mixture component)
+__device__ __forceinline__ void fold0_bwd_block(
     const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
     const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP,
-    const GwtfKS ks) {
-  raw_c += blockIdx.z * ks.raw;      // blockIdx.z = mixture component
-  mom_rep += blockIdx.z * ks.mom;
-  g_sd0 += blockIdx.z * ks.gsd0;
-  g_raw_c += blockIdx.z * ks.raw;
-  part += blockIdx.z * (ks.gmom / 2);   // ks.gmom counts floats, part is double
+    const GwtfKS& ks, int bx, int by, int bz, int n_by) {
+  raw_c += bz * ks.raw;
+  mom_rep += bz * ks.mom;
+  g_sd0 += bz * ks.gsd0;
+  g_raw_c += bz * ks.raw;
+  part += bz * (ks.gmom / 2);   // ks.gmom counts floats, part is double
   const int t = threadIdx.x % 16, sl = threadIdx.x / 16;
-  const int br = blockIdx.x, j = blockIdx.y * 16 + t;
+  const int br = bx, j = by * 16 + t;
   __shared__ float mom_part[kF1Slices][9];
   __shared__ double gs_part[kF1Slices][16][3];
   __shared__ double red[16][5];   // per feature: gE0, gE1, gC00, gC01, gC11 contributions
@@ -428,23 +430,32 @@ __global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
     double acc = 0.0;
 #pragma unroll
     for (int u = 0; u < 16; ++u) acc += red[u][t];
-    part[((size_t)br * gridDim.y + blockIdx.y) * 5 + t] = acc;
+    part[((size_t)br * n_by + by) * 5 + t] = acc;
   }
+}
+
+__global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
+    const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
+    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP,
+    const GwtfKS ks) {
+  fold0_bwd_block(raw_c, mom_rep, n_total, pat, g_sd0, g_raw_c, part, f, G, FP, ks, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
 }
 
 // g_in = g_a + g_b + d(moments)/dx:  gM_a + sum_b Q_ab x_b,  Q_aa = 2 gM_aa, Q_ab = gM_ab.  The nine moment gradients gM
 // are finished here from fold0_bwd_kernel's partial sums (every workgroup redoes the ~100 loads: cheaper than one more
 // single-workgroup kernel in the dependency chain).
-__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ x, const float* __restrict__ ga,
-                                                      const float* __restrict__ gb, const float* __restrict__ mom_rep,
-                                                      const double* __restrict__ part, int n_part, double n_total, int pat,
-                                                      float* __restrict__ g_in, int B, int N, const GwtfKS ks) {
-  x += blockIdx.z * ks.x;            // blockIdx.z = mixture component
-  ga += blockIdx.z * ks.pts;
-  gb += blockIdx.z * ks.pts;
-  g_in += blockIdx.z * ks.pts;
-  mom_rep += blockIdx.z * ks.mom;
-  part += blockIdx.z * (ks.gmom / 2);
+// block (bx of n_bx = slice of the points, by = shape, bz = mixture component)
+__device__ __forceinline__ void combine_block(const float* __restrict__ x, const float* __restrict__ ga,
+                                              const float* __restrict__ gb, const float* __restrict__ mom_rep,
+                                              const double* __restrict__ part, int n_part, double n_total, int pat,
+                                              float* __restrict__ g_in, int B, int N, const GwtfKS& ks, int bx, int by, int bz,
+                                              int n_bx) {
+  x += bz * ks.x;
+  ga += bz * ks.pts;
+  gb += bz * ks.pts;
+  g_in += bz * ks.pts;
+  mom_rep += bz * ks.mom;
+  part += bz * (ks.gmom / 2);
   __shared__ float s_mom[9];
   __shared__ double s_r5[5];
   __shared__ float s_gm[16];
@@ -479,15 +490,59 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
   }
   __syncthreads();
   const float* gm = s_gm;
-  const int b = blockIdx.y;
+  const int b = by;
   const float q00 = 2.f * gm[3], q01 = gm[4], q02 = gm[5], q11 = 2.f * gm[6], q12 = gm[7], q22 = 2.f * gm[8];
-  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+  for (int n = bx * blockDim.x + threadIdx.x; n < N; n += n_bx * blockDim.x) {
     const size_t o0 = ((size_t)b * 3 + 0) * N + n, o1 = o0 + N, o2 = o1 + N;
     const float x0 = x[o0], x1 = x[o1], x2 = x[o2];
     g_in[o0] = ga[o0] + gb[o0] + gm[0] + q00 * x0 + q01 * x1 + q02 * x2;
     g_in[o1] = ga[o1] + gb[o1] + gm[1] + q01 * x0 + q11 * x1 + q12 * x2;
     g_in[o2] = ga[o2] + gb[o2] + gm[2] + q02 * x0 + q12 * x1 + q22 * x2;
   }
+}
+
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ x, const float* __restrict__ ga,
+                                                      const float* __restrict__ gb, const float* __restrict__ mom_rep,
+                                                      const double* __restrict__ part, int n_part, double n_total, int pat,
+                                                      float* __restrict__ g_in, int B, int N, const GwtfKS ks) {
+  combine_block(x, ga, gb, mom_rep, part, n_part, n_total, pat, g_in, B, N, ks, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// The tail of a backward level is four small kernels in a row -- sd0 fold, gradient combine, the two stages of the dW1 partial
+// reduction -- of which only the combine feeds the next level.  Two launches instead of four: the sd0 fold runs beside stage 1 of
+// the reduction (they are independent), the combine beside stage 2.  Blocks [0, n_role0) take the first role.
+__global__ __launch_bounds__(256) void bwd_tail1_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep,
+                                                        double n_total, int pat, const float* __restrict__ g_sd0,
+                                                        float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP,
+                                                        const GwtfKS ks, int K, const float* __restrict__ ws, int n_partials,
+                                                        float* __restrict__ mid, int rec) {
+  const int n_by = FP / 16, n_role0 = 2 * n_by * K;
+  if ((int)blockIdx.x < n_role0) {
+    const int b = blockIdx.x;
+    fold0_bwd_block(raw_c, mom_rep, n_total, pat, g_sd0, g_raw_c, part, f, G, FP, ks, b % 2, (b / 2) % n_by, b / (2 * n_by), n_by);
+    return;
+  }
+  const int b = blockIdx.x - n_role0, gx = (rec + 255) / 256;
+  const int bx = b % gx, by = (b / gx) % gwtf_dw1::kStage, bz = b / (gx * gwtf_dw1::kStage);
+  gwtf_dw1::fold_block(ws + bz * ks.dw1, n_partials, mid + bz * ks.dw1, rec, bx, by, threadIdx.x);
+}
+
+__global__ __launch_bounds__(256) void bwd_tail2_kernel(const float* __restrict__ x, const float* __restrict__ ga,
+                                                        const float* __restrict__ gb, const float* __restrict__ mom_rep,
+                                                        const double* __restrict__ part, int n_part, double n_total, int pat,
+                                                        float* __restrict__ g_in, int B, int N, const GwtfKS ks, int K, int n_bx,
+                                                        const float* __restrict__ mid, float* __restrict__ dW1, int f,
+                                                        size_t branch_stride) {
+  __shared__ float red[4][64];
+  const int n_role0 = n_bx * B * K;
+  if ((int)blockIdx.x < n_role0) {
+    const int b = blockIdx.x;
+    combine_block(x, ga, gb, mom_rep, part, n_part, n_total, pat, g_in, B, N, ks, b % n_bx, (b / n_bx) % B, b / (n_bx * B), n_bx);
+    return;
+  }
+  const int b = blockIdx.x - n_role0, gx = (2 * f * f + 63) / 64;
+  const int bx = b % gx, bz = b / gx;
+  gwtf_dw1::reduce_block(mid + bz * ks.dw1, dW1 + bz * ks.raw, f, branch_stride, bx, threadIdx.x, red);
 }
 
 }  // namespace
@@ -651,16 +706,24 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
     int rc = gwtf_internal_stats_backward_k(x_in, g_stats, pw_c, pb_c, t->g_xb, t->dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0,
                                             K, B, N, f, pat, ks, t->stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(fold0_bwd_kernel, dim3(2, FP / 16, K), dim3(kF1Slices * 16), 0, st, t->raw + (size_t)c * d.RC, mom,
-                       t->n_total, pat, g_sd0, g_raw_c, reinterpret_cast<double*>(g_mom), f, G, FP, ks);
+    // sd0 fold + stage 1 of the dW1 reduction (both passes' partials are complete now) in one launch
+    const int rec = 2 * f * f, n_partials = 2 * gwtf_dw1_partials(B, N);
+    float* mid = t->dw1_ws + (size_t)n_partials * rec;
+    const unsigned blocks = 2u * (FP / 16) * K + (unsigned)((rec + 255) / 256) * gwtf_dw1::kStage * K;
+    hipLaunchKernelGGL(bwd_tail1_kernel, dim3(blocks), dim3(256), 0, st, t->raw + (size_t)c * d.RC, mom, t->n_total, pat, g_sd0, g_raw_c,
+                       reinterpret_cast<double*>(g_mom), f, G, FP, ks, K, t->dw1_ws, n_partials, mid, rec);
     return (int)hipGetLastError();
   }
-  // GWTF_PHASE_BWD_C
-  const int bx = (N + 255) / 256;
-  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B, K), dim3(256), 0, st, x_in, t->g_xa, t->g_xb, mom,
-                     reinterpret_cast<const double*>(g_mom), 2 * (FP / 16), t->n_total, pat, nxt, B, N, ks);
+  // GWTF_PHASE_BWD_C: gradient combine + stage 2 of the dW1 reduction in one launch
+  const int bxn = (N + 255) / 256, n_bx = bxn < 64 ? bxn : 64;
   const GwtfRaw R(f, G);
-  return gwtf_internal_dw1_reduce_k(t->dw1_ws, 2, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, K, ks.dw1, ks.raw, t->stream);
+  const int rec = 2 * f * f, n_partials = 2 * gwtf_dw1_partials(B, N);
+  const float* mid = t->dw1_ws + (size_t)n_partials * rec;
+  const unsigned blocks = (unsigned)n_bx * B * K + (unsigned)((2 * f * f + 63) / 64) * K;
+  hipLaunchKernelGGL(bwd_tail2_kernel, dim3(blocks), dim3(256), 0, st, x_in, t->g_xa, t->g_xb, mom,
+                     reinterpret_cast<const double*>(g_mom), 2 * (FP / 16), t->n_total, pat, nxt, B, N, ks, K, n_bx, mid,
+                     g_raw_c + R.sd1_w(), f, R.branch_size());
+  return (int)hipGetLastError();
 }
 
 extern "C" int gwtf_mtrain_forward(const GwtfTrainCtx* t) {
