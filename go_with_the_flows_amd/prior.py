@@ -140,8 +140,15 @@ class GlobalRNVPDecoder(nn.Module):
         return torch.cat([q.reshape(-1) for q in parts])
 
     def _fused_ok(self, g):
+        bns = self._bn_modules()
+        if self.training and any(isinstance(bn, nn.SyncBatchNorm) for bn in bns):
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # synchronised statistics (train_ae.py:152) are over ALL ranks' rows: the single-launch kernel sees this rank's
+                # only -- the module path below runs torch's SyncBatchNorm
+                return False
         return (g.is_cuda and g.dim() == 2 and 2 <= g.shape[1] == self.g_n_features and g.shape[0] <= 128 and
-                2 * self.n_flows <= 64 and all(bn.track_running_stats and bn.momentum is not None for bn in self._bn_modules()))
+                2 * self.n_flows <= 64 and all(bn.track_running_stats and bn.momentum is not None for bn in bns))
 
     def _forward_fused(self, g, mode):
         if mode not in ('direct', 'inverse'):

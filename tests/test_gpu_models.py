@@ -212,3 +212,17 @@ def test_training_loop_reduces_the_loss_eager_and_graphed():
         assert last < first - 0.05 * abs(first), (graphed, first, last)
         finals.append(last)
     assert abs(finals[0] - finals[1]) < 0.25 * abs(finals[0])      # same regime (the noise draws differ between the two runs)
+
+
+def test_two_rank_whole_model_training_step_matches_single_process(tmp_path):
+    """Data-parallel semantics of the WHOLE model (reference train_ae.py:152-153: SyncBatchNorm + averaged gradients): two ranks
+    with half of the batch each == one process with the whole batch -- the encoder's train pipeline, the K-batched decoder
+    pipeline, the FiLM heads over the all-gathered latents, the prior flow and the per-shape heads all in one step."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GWTF_TMP=str(tmp_path), MASTER_ADDR='127.0.0.1')
+    port = 29800 + os.getpid() % 1000
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(os.path.dirname(__file__), 'dist_model_worker.py')]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'MODEL2' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
