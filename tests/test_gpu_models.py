@@ -226,3 +226,38 @@ def test_two_rank_whole_model_training_step_matches_single_process(tmp_path):
            '--master-port', str(port), os.path.join(os.path.dirname(__file__), 'dist_model_worker.py')]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'MODEL2' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+def test_eval_after_training_steps_sees_every_update():
+    """Parameters are written through raw pointers by the fused optimiser and running statistics by the pointer-table kernel: every
+    packed-weight cache must notice.  Two training steps, then an eval pass == the eval pass of a FRESH model loaded from the
+    trained model's state_dict."""
+    from go_with_the_flows_amd import optim
+    D = golden('g13_full_model')
+    g_in, p_in, noise = dev(D['gcloud']), dev(D['pcloud']), dev(D['noise_g'])
+    m, cfg = build()
+    m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+    crit = models.Flow_Mixture_Loss(**cfg)
+    opt = optim.Adam(m.parameters(), lr=1e-3, amsgrad=True)
+    m.eval()
+    with torch.no_grad():
+        before = crit.fused(*m.forward_fused(g_in, p_in))[0].item()          # fills the eval caches
+    m.train()
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        crit.fused(*m.forward_fused(g_in, p_in))[0].backward()
+        opt.step()
+    m.eval()
+    with torch.no_grad():
+        enc, dec = m.forward_fused(g_in, p_in)
+        after = crit.fused(enc, dec)[0].item()
+    fresh, _ = build()
+    fresh.load_state_dict(m.state_dict())
+    fresh.reparameterize = m.reparameterize
+    fresh.eval()
+    with torch.no_grad():
+        enc2, dec2 = fresh.forward_fused(g_in, p_in)
+        want = crit.fused(enc2, dec2)[0].item()
+    assert abs(after - before) > 1e-6 * abs(before)                          # the steps did change the model
+    assert abs(after - want) <= 1e-6 * abs(want), (after, want)
+    assert torch.equal(dec['z'], dec2['z']) and torch.equal(dec['logdet'], dec2['logdet'])
