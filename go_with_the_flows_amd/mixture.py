@@ -62,6 +62,26 @@ class MixtureStack:
         pw, film, eps = self._film(g.contiguous().float())
         return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode)
 
+    def forward_all_lists(self, p, g, mode='inverse'):
+        """Every component on every point, train-mode BatchNorm, WITH the reference's per-coupling lists: -> (out, logdet (K,B,3,N),
+        (ps, mus, logvars) each (K, C, B, 3, N) direct-ordered; ps / logvars differentiable in every slot, a gradient through mus
+        raises) -- the K list-API decoder calls of flow_mixture.py:163-166 as ONE pass of the K-batched pipeline.  None when that
+        pipeline does not apply (eval-mode BatchNorm, the cross-check chain): the caller then takes the per-decoder route."""
+        e0 = self.engines[0]
+        e0._check(p, g)
+        if not e0.couplings[0].training or any(getattr(e, 'force_autograd_chain', False) for e in self.engines):
+            return None
+        from .autograd import train_density_forward_multi
+        from .flows import _sharded
+        needs_grad = torch.is_grad_enabled() and (p.requires_grad or g.requires_grad or any(
+            t.requires_grad for d in self.decoders for t in d.parameters()))
+        with torch.set_grad_enabled(needs_grad):
+            out, logdet, lists, bn_batch = train_density_forward_multi(self.engines, p, g, mode, distributed=_sharded())
+        for k, e in enumerate(self.engines):
+            e._update_running_stats(bn_batch[k])
+            e._last_lists = None
+        return out, logdet, lists
+
     def forward_partition(self, p, g, counts, mode='direct'):
         """Sampling path: the N points are laid out component by component, ``counts[k]`` points for component k
         (sum == N); each point goes through ONE component.  -> (out, logdet), each (B,3,N)."""

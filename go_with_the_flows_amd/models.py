@@ -186,14 +186,16 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
         size = p_input.shape[2] if n_sampled_points is None else n_sampled_points
         if images is not None and self.train_mode == 'p_rnvp_mc_g_rnvp_vae_ic':
             raise NotImplementedError('image-conditioned encoding (ResNet-18) is outside the point-flow path')
-        output_encoder = self.encode(g_input)
+        # training: the prior flow (a latency chain on one compute unit) runs on a side stream beside the decoders, as in
+        # forward_fused; its lists are joined in before the outputs are handed back
+        output_encoder = self.encode(g_input, defer_prior=self.mode == 'training')
         g_sample = (output_encoder['g_posterior_samples'] if self.mode in ('training', 'autoencoding')
                     else output_encoder['g_prior_samples'][-1])
         if labeled_samples:
             samples, labels, logits = self.decode(p_input, g_sample, size, labeled_samples, warmup)
-            return output_encoder, samples, labels, logits
+            return self.finish_encode(output_encoder), samples, labels, logits
         output_decoder, logits = self.decode(p_input, g_sample, size, labeled_samples, warmup)
-        return output_encoder, output_decoder, logits
+        return self.finish_encode(output_encoder), output_decoder, logits
 
 
 class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
@@ -271,7 +273,9 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
             assert p_input.shape[0] == 1                     # evaluation feeds one shape at a time (flow_mixture.py:146)
             flows_idx = self._draw_components(logits[0], n_sampled_points)
             sizes = [int((flows_idx == t).sum()) for t in range(K)]
-        output_decoder = [self.one_flow_decode(p_input, g_sample, self.pc_decoder[i], sizes[i]) for i in range(K)]
+        output_decoder = self._decode_training_batched(p_input, g_sample, sizes) if self.mode == 'training' else None
+        if output_decoder is None:
+            output_decoder = [self.one_flow_decode(p_input, g_sample, self.pc_decoder[i], sizes[i]) for i in range(K)]
         if not labeled_samples:
             return output_decoder, logits
         samples = torch.zeros_like(p_input)
@@ -281,6 +285,29 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
             samples[:, :, mask] = output_decoder[t]['p_prior_samples'][-1]
             labels[:, mask] = t + 1
         return samples, labels, logits
+
+    def _decode_training_batched(self, p_input, g_sample, sizes):
+        """The K one_flow_decode calls of the training pass (flow_mixture.py:163-166) as ONE pass of the K-batched train pipeline:
+        the same K dicts of lists (entries are slices of stacked tensors).  None when it does not apply (eval-mode BatchNorm, CPU
+        tensors, sub-sampled clouds): the per-decoder calls then run."""
+        if not p_input.is_cuda or any(sz != p_input.shape[2] for sz in sizes) or not self.pc_decoder[0].training:
+            return None
+        res = self.mixture_stack().forward_all_lists(p_input, g_sample, mode='inverse')
+        if res is None:
+            return None
+        z, logdet, (ps, mus, lvs) = res                          # (K,B,3,N), (K,B,3,N), (K,C,B,3,N) each
+        B, P, n = g_sample.shape[0], self.p_latent_space_size, p_input.shape[2]
+        mu0, lv0 = self._base_gaussian_repeated(g_sample, self.n_components)
+        out = []
+        for k in range(self.n_components):
+            # slot 0 of the samples IS the stack's output and sum(logvars[1:]) IS its log-det: handing the loss those two tensors
+            # (the list entries hold the same values) keeps the gradient off the per-slot route, whose backward would materialise
+            # a (K, C, B, 3, N) gradient tensor per list
+            out.append({'p_prior_mus': [mu0.expand(B, P, n)] + list(mus[k].unbind(0)),
+                        'p_prior_logvars': [lv0.expand(B, P, n)] + list(lvs[k].unbind(0)),
+                        'p_prior_samples': [z[k]] + list(ps[k].unbind(0))[1:] + [p_input],
+                        '_sum_flow_logvars': logdet[k]})
+        return out
 
     # -- the fused path ------------------------------------------------------------------------------------------------
     def mixture_stack(self):
@@ -331,7 +358,9 @@ class FlowMixtureNLL(nn.Module):
 
     def forward(self, output_decoder, mixture_weights_logits):
         z = torch.stack([o['p_prior_samples'][0] for o in output_decoder])
-        logdet = torch.stack([sum(o['p_prior_logvars'][1:]) for o in output_decoder])
+        # the batched training decode attaches the stack's own log-det (= sum of the list's flow entries, same values)
+        logdet = torch.stack([o['_sum_flow_logvars'] if '_sum_flow_logvars' in o else sum(o['p_prior_logvars'][1:])
+                              for o in output_decoder])
         mu0 = torch.stack([o['p_prior_mus'][0][:, :, 0] for o in output_decoder])
         lv0 = torch.stack([o['p_prior_logvars'][0][:, :, 0] for o in output_decoder])
         return flow_mixture_nll(z, logdet, mu0, lv0, mixture_weights_logits)[0]

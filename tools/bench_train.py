@@ -21,6 +21,8 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--points', type=int, default=2048)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--graph', action='store_true', help='capture forward + backward in one hipGraph')
+ap.add_argument('--api', default='fused', choices=['fused', 'list'],
+                help="fused: forward_fused + Flow_Mixture_Loss.fused; list: the reference's own call, model(g, p) -> lists -> loss")
 ap.add_argument('--lib', default=None, help='A/B: load this build of libgwtf_hip.so instead of the in-tree one')
 ap.add_argument('--parts', default='epd', help='debug: which parts run (e=encoder, p=prior flow, d=decoders)')
 a = ap.parse_args()
@@ -51,7 +53,10 @@ g_fix = torch.randn(a.batch, CFG['g_latent_space_size'], device='cuda')
 
 def fwd_bwd():
     opt.zero_grad(set_to_none=True)
-    if a.parts == 'epd':
+    if a.parts == 'epd' and a.api == 'list':
+        output_prior, output_decoder, logits = model(g_in, p_in)             # training.py:43-47 of the reference
+        loss, pnll, gnll, gent = crit(output_prior, output_decoder, logits)
+    elif a.parts == 'epd':
         enc, dec = model.forward_fused(g_in, p_in)
         loss, pnll, gnll, gent = crit.fused(enc, dec)
     else:                                   # debug: isolate one part of the step
