@@ -261,3 +261,35 @@ def test_eval_after_training_steps_sees_every_update():
     assert abs(after - before) > 1e-6 * abs(before)                          # the steps did change the model
     assert abs(after - want) <= 1e-6 * abs(want), (after, want)
     assert torch.equal(dec['z'], dec2['z']) and torch.equal(dec['logdet'], dec2['logdet'])
+
+
+def test_list_api_training_decode_is_one_batched_pass_and_equals_the_per_decoder_calls():
+    """model(g, p) in training mode returns the reference's K dicts of lists from ONE pass of the K-batched pipeline; values and
+    gradients -- including gradients entering through INNER list slots -- equal the K separate one_flow_decode calls."""
+    D = golden('g13_full_model')
+    g_in, p_in, noise = dev(D['gcloud']), dev(D['pcloud']), dev(D['noise_g'])
+    outs = []
+    for batched in (True, False):
+        m, cfg = build()
+        m.train()
+        m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+        if not batched:
+            m._decode_training_batched = lambda *a, **k: None            # the per-decoder route
+        enc, dec, logits = m(g_in, p_in)
+        assert ('_sum_flow_logvars' in dec[0]) == batched
+        crit = models.Flow_Mixture_Loss(**cfg)
+        loss = crit(enc, dec, logits)[0]
+        extra = ((dec[1]['p_prior_samples'][3] * 0.37).sum() + (dec[2]['p_prior_logvars'][4] * -0.21).sum()
+                 + (dec[0]['p_prior_samples'][0] ** 2).sum() * 0.01)
+        (loss + extra).backward()
+        outs.append((loss.item(), [host(t) for t in dec[1]['p_prior_samples']], [host(t) for t in dec[2]['p_prior_logvars']],
+                     {k: host(v.grad) for k, v in m.named_parameters() if v.grad is not None},
+                     {k: host(v) for k, v in m.state_dict().items() if 'running' in k}))
+    (l0, s0, v0, g0, r0), (l1, s1, v1, g1, r1) = outs
+    assert abs(l0 - l1) <= 1e-6 * abs(l1)
+    assert all(maxabs(a, b) < 1e-5 * max(1.0, np.abs(b).max()) for a, b in zip(s0, s1))
+    assert all(maxabs(a, b) < 1e-5 for a, b in zip(v0, v1))
+    assert set(g0) == set(g1)
+    gmax = max(np.abs(v).max() for v in g1.values())
+    assert max(maxabs(g0[k], g1[k]) for k in g1) < 2e-3 * gmax
+    assert all(maxabs(r0[k], r1[k]) < 1e-5 * max(1.0, np.abs(r1[k]).max()) for k in r1)
