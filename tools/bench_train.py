@@ -21,8 +21,9 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--points', type=int, default=2048)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--graph', action='store_true', help='capture forward + backward in one hipGraph')
-ap.add_argument('--api', default='fused', choices=['fused', 'list'],
-                help="fused: forward_fused + Flow_Mixture_Loss.fused; list: the reference's own call, model(g, p) -> lists -> loss")
+ap.add_argument('--api', default='fused', choices=['fused', 'list', 'both'],
+                help="fused: forward_fused + Flow_Mixture_Loss.fused; list: the reference's own call, model(g, p) -> lists -> loss; "
+                     "both: fused, then a second graph of the list call in the same process")
 ap.add_argument('--lib', default=None, help='A/B: load this build of libgwtf_hip.so instead of the in-tree one')
 ap.add_argument('--parts', default='epd', help='debug: which parts run (e=encoder, p=prior flow, d=decoders)')
 a = ap.parse_args()
@@ -51,9 +52,12 @@ p_in = torch.from_numpy(synth_inputs(a.batch, a.points, 4, 2)[0]).cuda()
 g_fix = torch.randn(a.batch, CFG['g_latent_space_size'], device='cuda')
 
 
+API = ['list' if a.api == 'list' else 'fused']
+
+
 def fwd_bwd():
     opt.zero_grad(set_to_none=True)
-    if a.parts == 'epd' and a.api == 'list':
+    if a.parts == 'epd' and API[0] == 'list':
         output_prior, output_decoder, logits = model(g_in, p_in)             # training.py:43-47 of the reference
         loss, pnll, gnll, gent = crit(output_prior, output_decoder, logits)
     elif a.parts == 'epd':
@@ -119,3 +123,19 @@ if a.graph:
         opt.step()
     ms = timed(replay_step, a.steps)
     print(f'hipGraph: {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s')
+    if a.api == 'both':
+        API[0] = 'list'
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        graph_list = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph_list):
+            fwd_bwd()
+
+        def replay_list():
+            graph_list.replay()
+            opt.step()
+        ms = timed(replay_list, a.steps)
+        print(f'hipGraph list API: {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s')
