@@ -529,7 +529,7 @@ class TrainMixtureFn(torch.autograd.Function):
     n_total: number of points the statistics cover over all ranks; sharded: statistics are all-reduced between phases."""
 
     @staticmethod
-    def forward(ctx, p, raw, a, bsh, K, C, f, G, pattern0, eps, mode, n_total, sharded):
+    def forward(ctx, p, raw, a, bsh, K, C, f, G, pattern0, eps, mode, n_total, sharded, want_lists=True):
         L = _lib.lib()
         p, raw = p.contiguous(), raw.contiguous()
         B, _, N = p.shape
@@ -550,12 +550,16 @@ class TrainMixtureFn(torch.autograd.Function):
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
         t.eps, t.n_total = float(eps), float(n_total)
         bufs = dict(moments=zeros(C + 1, K, R * 16), ystats=zeros(C, K, R * 2 * FP * 2), bn_batch=zeros(K, C, 2, 4, 2, f),
-                    film_rec=new(B, K * C, FS), xbuf=new(2, K, B, 3, N), logdet=new(K, B, 3, N), lists=new(3, K, C, B, 3, N))
+                    film_rec=new(B, K * C, FS), xbuf=new(2, K, B, 3, N), logdet=new(K, B, 3, N),
+                    # the per-coupling inputs (ps) are what the backward recomputes from; mus / logvars only when the caller
+                    # wants the reference's lists (36 B per point, coupling and component less to write otherwise)
+                    lists=new(3 if want_lists else 1, K, C, B, 3, N))
         t.p, t.raw, t.packed_w, t.packed_b, t.film_raw = p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr(), film_raw.data_ptr()
         for name in ('moments', 'ystats', 'bn_batch', 'film_rec', 'xbuf', 'logdet'):
             setattr(t, name, bufs[name].data_ptr())
         lists = bufs['lists']
-        t.ps, t.mus, t.logvars = lists[0].data_ptr(), lists[1].data_ptr(), lists[2].data_ptr()
+        t.ps = lists[0].data_ptr()
+        t.mus, t.logvars = (lists[1].data_ptr(), lists[2].data_ptr()) if want_lists else (None, None)
         t.stream = _lib._stream(p)
         with torch.cuda.device(dev):
             if not sharded:
@@ -578,6 +582,9 @@ class TrainMixtureFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         # ps / logvars list slots are differentiable (the backward kernels add a slot's gradient where its coupling is
         # processed); a gradient through a mus slot raises
+        if not want_lists:
+            empty = lists.new_empty(0)
+            return out, bufs['logdet'], lists[0], empty, empty, bufs['bn_batch']
         return out, bufs['logdet'], lists[0], lists[1], lists[2], bufs['bn_batch']
 
     @staticmethod
@@ -630,7 +637,7 @@ class TrainMixtureFn(torch.autograd.Function):
         dp = bufs['g_bufs'][L.gwtf_mtrain_final_backward_half(C, _lib._MODES[mode])]
         dp = dp[0] if K == 1 else dp.sum(0)                    # the K components read the same clouds
         gfr = bufs['g_film_raw']
-        return (dp, bufs['g_raw'], gfr[:, :, :, 0, :f], gfr[:, :, :, 1, :f]) + (None,) * 9
+        return (dp, bufs["g_raw"], gfr[:, :, :, 0, :f], gfr[:, :, :, 1, :f]) + (None,) * 10
 
 
 def _rank_rows(g):
@@ -643,7 +650,7 @@ def _rank_rows(g):
     return _AllGatherRows.apply(g), sum(sizes[:dist.get_rank()]), sum(sizes)
 
 
-def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False):
+def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False, want_lists=True):
     """Train-mode density pass of K stacks (the components of a mixture, or one decoder) through the fused pipeline.
     -> out, logdet (K,B,3,N), lists = (ps, mus, lvs) each (K,C,B,3,N) with ps / lvs differentiable, bn_batch (K,C,2,4,2,f)
     incl. the FiLM BatchNorm statistics."""
@@ -672,8 +679,8 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
             if P['raw'].requires_grad:
                 P['raw'].register_hook(lambda grad, e=e: sink.on_flat_gradient(grad, e))
     out, logdet, ps, mus, lvs, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
-                                                               float(rows_total) * N, distributed)
-    lists = (ps, mus, lvs)                                   # (K,C,B,3,N) each; ps / lvs differentiable
+                                                               float(rows_total) * N, distributed, want_lists)
+    lists = (ps, mus, lvs) if want_lists else None           # (K,C,B,3,N) each; ps / lvs differentiable
     bn_batch = bn_batch.clone()
     bn_batch[:, :, :, 2:4, 0] = film_mean.view(K, C, 2, 2, f)
     bn_batch[:, :, :, 2:4, 1] = film_var.view(K, C, 2, 2, f)

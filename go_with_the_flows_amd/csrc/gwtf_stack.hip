@@ -480,7 +480,9 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   logdet += comp * out_stride_k;
   if (LISTS) {
     const size_t ls = out_stride_k ? (size_t)C * B * 3 * N : 0;
-    ps += comp * ls; mus += comp * ls; lvs += comp * ls;
+    ps += comp * ls;
+    if (mus) mus += comp * ls;      // the train pipeline's fused consumers keep ps only (the backward's inputs): mus / lvs may be null
+    if (lvs) lvs += comp * ls;
   }
   pw += (size_t)comp * C * K::PW;
   const int KC = jobs.K * C;     // FiLM records per shape: [b][component][coupling]
@@ -562,8 +564,8 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
       for (int d = 0; d < 3; ++d) {
         const size_t o = (((size_t)c * B + b) * 3 + d) * N + n_own;
         ps[o] = xo[d];
-        mus[o] = mu_d[d];
-        lvs[o] = lv_d[d];
+        if (mus) mus[o] = mu_d[d];
+        if (lvs) lvs[o] = lv_d[d];
       }
     }
 #pragma unroll
@@ -598,8 +600,8 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     for (int d = 0; d < 3; ++d) {
       const size_t o = (((size_t)c_last * B + b) * 3 + d) * N + n_own;
       ps[o] = xo[d];
-      mus[o] = mu_last[d];
-      lvs[o] = lv_last[d];
+      if (mus) mus[o] = mu_last[d];
+      if (lvs) lvs[o] = lv_last[d];
     }
   }
   if (own_valid) {
@@ -722,8 +724,8 @@ static int stack_dispatch(const float* p, const float* packed_w, const float* fi
   if (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) return GWTF_E_BADARG;
   if (pattern0 < 0 || pattern0 > 5) return GWTF_E_BADARG;
   if (ex.c_count < 0 || (ex.c_count > 0 && (ex.c_first < 0 || ex.c_first >= C))) return GWTF_E_BADARG;
-  const bool any = ps || mus || logvars, all = ps && mus && logvars;
-  if (any && !all) return GWTF_E_BADARG;
+  const bool any = ps || mus || logvars, all = ps && mus && logvars, ps_only = ps && !mus && !logvars;
+  if (any && !all && !ps_only) return GWTF_E_BADARG;     // the three lists, none, or the coordinates alone (train pipeline)
   long pts = 0;
   for (int k = 0; k < K; ++k) {
     const int b0 = segments ? segments[2 * k] : 0, e0 = segments ? segments[2 * k + 1] : N;

@@ -626,8 +626,8 @@ bool ctx_ok(const GwtfTrainCtx* t, bool backward) {
   if (!t->p || !t->raw || !t->packed_w || !t->film_raw || !t->film_rec || !t->moments || !t->ystats || !t->bn_batch || !t->xbuf ||
       !t->logdet)
     return false;
-  const bool any = t->ps || t->mus || t->logvars, all = t->ps && t->mus && t->logvars;
-  if (any && !all) return false;
+  const bool any = t->ps || t->mus || t->logvars, all = t->ps && t->mus && t->logvars, ps_only = t->ps && !t->mus && !t->logvars;
+  if (any && !all && !ps_only) return false;
   if (backward && (!t->ps || !t->packed_b || !t->g_out || !t->g_ld || !t->g_bufs || !t->g_xa || !t->g_xb || !t->dw1_ws ||
                    !t->g_film || !t->g_sd0 || !t->g_bias || !t->g_stats || !t->g_mom || !t->g_film_raw || !t->g_raw))
     return false;

@@ -50,7 +50,7 @@ class MixtureStack:
             from .flows import _sharded
             multi = _sharded()
             with torch.set_grad_enabled(needs_grad):
-                out, logdet, _, bn_batch = train_density_forward_multi(self.engines, p, g, mode, distributed=multi)
+                out, logdet, _, bn_batch = train_density_forward_multi(self.engines, p, g, mode, distributed=multi, want_lists=False)
             for k, e in enumerate(self.engines):
                 e._update_running_stats(bn_batch[k])
                 e._last_lists = None

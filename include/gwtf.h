@@ -206,7 +206,7 @@ typedef struct GwtfTrainCtx {
   float* bn_batch;           /* [K][C][2][4][2][f]   batch {mean, unbiased var} of sd0_bn (kind 0) and sd1_bn (kind 1) */
   float* xbuf;               /* [2][K][B][3][N]      ping-pong coordinates; result in half gwtf_mtrain_final_forward_half(C) */
   float* logdet;             /* [K][B][3][N] */
-  float* ps; float* mus; float* logvars;   /* [K][C][B][3][N] each, or all NULL (required for the backward: ps) */
+  float* ps; float* mus; float* logvars;   /* [K][C][B][3][N] each, or all NULL, or ps alone (required for the backward: ps) */
   /* backward only */
   const float* g_out;        /* [K][B][3][N]  dL/d out */
   const float* g_ld;         /* [K][B][3][N]  dL/d logdet */
