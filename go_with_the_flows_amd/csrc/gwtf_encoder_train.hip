@@ -366,7 +366,7 @@ __global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __
 // A non-finite statistic or extreme (diverged weights, a NaN point) gives NaN, as torch's batch_norm + relu + max would.
 __global__ void enc_pool_finalize_kernel(const unsigned long long* __restrict__ kmax, const unsigned long long* __restrict__ kmin,
                                          const float* __restrict__ aff, float* __restrict__ pooled, int* __restrict__ amax,
-                                         float* __restrict__ ystar, int B, int C) {
+                                         float* __restrict__ ystar, int B, int C, int N) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * C) return;
   const int c = i % C;
@@ -378,7 +378,10 @@ __global__ void enc_pool_finalize_kernel(const unsigned long long* __restrict__ 
   const float a = fmaf(s, y, t);
   const bool bad = gwtf_nonfinite(a) || gwtf_nonfinite(s) || gwtf_nonfinite(t);
   pooled[i] = bad ? __builtin_bit_cast(float, 0x7fc00000) : fmaxf(a, 0.f);
-  amax[i] = 0x7fffffff - (int)(unsigned)(key & 0xffffffffu);
+  // a key that never received a point (every y of the row NaN) decodes to an index far outside the cloud: clamp, the backward
+  // indexes per-point tables with it
+  const int idx = 0x7fffffff - (int)(unsigned)(key & 0xffffffffu);
+  amax[i] = key == 0ull ? 0 : min(max(idx, 0), N - 1);
   ystar[i] = y;
 }
 
@@ -418,7 +421,8 @@ __global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __res
   const int b = blockIdx.x, tid = threadIdx.x;
   for (int n = tid; n < N; n += 256) slot[n] = -1;
   for (int c = tid; c < C; c += 256) {
-    s_am[c] = amax[(size_t)b * C + c];
+    const int am = amax[(size_t)b * C + c];
+    s_am[c] = min(max(am, 0), N - 1);           // defensive: the table below is indexed with it
     s_cf[c] = coef[(size_t)b * C + c];
   }
   __syncthreads();
@@ -1002,11 +1006,11 @@ extern "C" int gwtf_enc_train_forward(int layer, const float* in, const float* i
 }
 
 extern "C" int gwtf_enc_train_pool(const unsigned long long* kmax, const unsigned long long* kmin, const float* aff3, float* pooled,
-                                   int* amax, float* ystar, int B, void* stream) {
-  if (!kmax || !kmin || !aff3 || !pooled || !amax || !ystar || B <= 0) return GWTF_E_BADARG;
+                                   int* amax, float* ystar, int B, int N, void* stream) {
+  if (!kmax || !kmin || !aff3 || !pooled || !amax || !ystar || B <= 0 || N <= 0) return GWTF_E_BADARG;
   const int C = kC[4];
   hipLaunchKernelGGL(enc_pool_finalize_kernel, dim3((B * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, kmax, kmin, aff3, pooled,
-                     amax, ystar, B, C);
+                     amax, ystar, B, C, N);
   return (int)hipGetLastError();
 }
 

@@ -89,7 +89,7 @@ class _EncoderTrainFn(torch.autograd.Function):
             pooled = torch.empty(B, C[4], **f32)
             amax = torch.empty(B, C[4], device=dev, dtype=torch.int32)
             ystar = torch.empty(B, C[4], **f32)
-            check(L.gwtf_enc_train_pool(keys[0].data_ptr(), keys[1].data_ptr(), P(aff[3]), P(pooled), amax.data_ptr(), P(ystar), B, st))
+            check(L.gwtf_enc_train_pool(keys[0].data_ptr(), keys[1].data_ptr(), P(aff[3]), P(pooled), amax.data_ptr(), P(ystar), B, N, st))
             for bn in bns:
                 if bn.track_running_stats and bn.num_batches_tracked is not None:
                     bn.num_batches_tracked.add_(1)

@@ -364,7 +364,7 @@ int gwtf_enc_train_forward(int layer, const float* in, const float* in_tab, cons
 /* pooled (B,512) = max_n relu(s y3 + t) from the keys (max or min by the sign of s), amax = its first arg-max, ystar = y3 there;
  * NaN where a statistic or the extreme is not finite */
 int gwtf_enc_train_pool(const unsigned long long* kmax, const unsigned long long* kmin, const float* aff3, float* pooled, int* amax,
-                        float* ystar, int B, void* stream);
+                        float* ystar, int B, int N, void* stream);
 /* gp = g_pooled where pooled > 0; sums [2][512] = {sum gp, sum gp yhat*}; gmax[0] = max |gp| (zero on entry) */
 int gwtf_enc_train_top(const float* g_pooled, const float* pooled, const float* ystar, const float* aff3, float* gp, float* sums,
                        float* gmax, int B, void* stream);
