@@ -224,3 +224,32 @@ def test_train_pipeline_propagates_non_finite_weights():
         pooled.sum().backward()
         torch.cuda.synchronize()
         assert any(not bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+
+
+@pytest.mark.parametrize('B,N', [(1, 4), (1, 36), (5, 132), (2, 2500), (3, 516)])
+def test_train_pipeline_odd_shapes_against_library_path(B, N):
+    """Cloud sizes around every tile boundary of the pipeline (32-point k-steps, 128/256-point workgroups, the SVR config's
+    2500 points, a single shape): pooled code, arg-max, gradients and running statistics against the library path."""
+    import copy
+    m = encoders.PointNetCloudEncoder(3, 64, [128, 256, 512])
+    load_synth_(m, 60 + N)
+    m = m.to(DEV).train()
+    lib = copy.deepcopy(m)
+    x = dev(synth_inputs(B, N, 4, 61 + N)[0])
+    wgt = torch.randn(B, 512, device=DEV, generator=torch.Generator(DEV).manual_seed(N))
+    assert m._train_pipeline_ok(x)
+    pooled, amax = m.forward_max(x, return_indices=True)
+    (pooled * wgt).sum().backward()
+    feat = lib.features(x)
+    ref, ref_idx = torch.max(feat, dim=2)
+    (ref * wgt).sum().backward()
+    scale = max(1.0, float(ref.detach().abs().max()))
+    assert float((pooled - ref).detach().abs().max()) < 5e-5 * scale
+    # the arg-max may differ only where two points tie to rounding: the feature at OUR index must be the maximum too
+    picked = torch.gather(feat.detach(), 2, amax.long().unsqueeze(2)).squeeze(2)
+    assert float((picked - ref.detach()).abs().max()) < 5e-5 * scale
+    for (name, p), q in zip(m.named_parameters(), lib.parameters()):
+        gs = float(q.grad.abs().max())
+        assert float((p.grad - q.grad).abs().max()) < 2e-3 * gs + 1e-6, (B, N, name)
+    for (name, a), b in zip(m.named_buffers(), lib.buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5), name
