@@ -221,6 +221,12 @@ class StackEngine:
         self._flat_key, self._flat = None, None
         self._bn_cache = None
 
+    def __reduce__(self):
+        """copy.deepcopy / pickle of a module that owns an engine: a FRESH engine over the (copied) couplings.  Every cache in
+        here -- detached views of the parameters, device pointer tables, packed weights -- describes the original's tensors; a
+        field-by-field copy would keep reading them (a deep copy of a model taken after it ran would ignore its own weights)."""
+        return (StackEngine, (self.couplings,))
+
     def raw_arena(self):
         """Parameters + BatchNorm buffers of all couplings as one flat tensor (autograd-aware torch.cat).  The list
         of sources is cached (module traversal costs more than the copy); it is rebuilt when .to()/.cuda()/

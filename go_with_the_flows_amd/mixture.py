@@ -23,6 +23,10 @@ class MixtureStack:
         self.K, self.C, self.f, self.G = len(self.engines), e0.C, e0.f, e0.G
         self._cat_key, self._cat = None, None
 
+    def __reduce__(self):
+        """copy.deepcopy / pickle: a fresh stack over the (copied) decoders -- the caches here belong to the original's tensors."""
+        return (MixtureStack, (self.decoders,))
+
     def packed(self):
         packs = [e.packed(False) for e in self.engines]
         key = tuple(id(pk[0]) for pk in packs)

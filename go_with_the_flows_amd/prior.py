@@ -188,9 +188,9 @@ class GlobalRNVPDecoder(nn.Module):
         if not self._fused_ok(g):
             return _PriorResult(self.forward(g, mode), None, None)
         cur = torch.cuda.current_stream(g.device)
-        side = getattr(self, '_side_stream', None)
-        if side is None or side.device != g.device:
-            side = self._side_stream = torch.cuda.Stream(device=g.device)
+        side = _SIDE_STREAMS.get(g.device)              # per device, not per module: a stream is not module state (deepcopy, pickle)
+        if side is None:
+            side = _SIDE_STREAMS[g.device] = torch.cuda.Stream(device=g.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
             res = self._forward_fused(g, mode)
@@ -212,6 +212,9 @@ class GlobalRNVPDecoder(nn.Module):
                 gs, mus, logvars = a + gs, b + mus, c + logvars
                 cur = gs[0]
         return gs, mus, logvars
+
+
+_SIDE_STREAMS = {}
 
 
 class _PriorResult:

@@ -293,3 +293,41 @@ def test_list_api_training_decode_is_one_batched_pass_and_equals_the_per_decoder
     gmax = max(np.abs(v).max() for v in g1.values())
     assert max(maxabs(g0[k], g1[k]) for k in g1) < 2e-3 * gmax
     assert all(maxabs(r0[k], r1[k]) < 1e-5 * max(1.0, np.abs(r1[k]).max()) for k in r1)
+
+
+def test_deepcopy_and_pickle_of_a_used_model_follow_their_own_weights(tmp_path):
+    """copy.deepcopy(model) / torch.save(model) taken AFTER the model ran (EMA copies, best-model snapshots): every cache inside
+    -- detached parameter views, device pointer tables, packed weights, side streams -- must be rebuilt for the copy, which then
+    follows ITS parameters.  (A field-by-field copy of the engines kept reading the original's tensors.)"""
+    import copy
+    from go_with_the_flows_amd import optim
+    D = golden('g13_full_model')
+    g_in, p_in, noise = dev(D['gcloud']), dev(D['pcloud']), dev(D['noise_g'])
+    m, cfg = build()
+    m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+    crit = models.Flow_Mixture_Loss(**cfg)
+    opt = optim.Adam(m.parameters(), lr=1e-3)
+    m.train()
+    crit.fused(*m.forward_fused(g_in, p_in))[0].backward()            # fills the train-path caches
+    opt.step()
+    m.eval()
+    with torch.no_grad():
+        base = crit.fused(*m.forward_fused(g_in, p_in))[0].item()    # ... and the eval-path caches
+    del m.reparameterize                                             # a lambda is not picklable; re-attached below
+    path = str(tmp_path / 'model.pt')
+    torch.save(m, path)
+    clones = {'deepcopy': copy.deepcopy(m), 'pickle': torch.load(path, weights_only=False)}
+    for how, c in clones.items():
+        with torch.no_grad():
+            for q in c.parameters():
+                q.mul_(1.03)
+        fresh, _ = build()
+        fresh.load_state_dict(c.state_dict())
+        vals = []
+        for mod in (c, fresh):
+            mod.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
+            mod.eval()
+            with torch.no_grad():
+                vals.append(crit.fused(*mod.forward_fused(g_in, p_in))[0].item())
+        assert abs(vals[0] - vals[1]) <= 1e-6 * abs(vals[1]), (how, vals)
+        assert abs(vals[0] - base) > 1e-4 * abs(base), how           # and they did move away from the original
