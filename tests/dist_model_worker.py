@@ -55,6 +55,18 @@ def main():
     dist.all_reduce(lt)
     np.savez(os.path.join(os.environ['GWTF_TMP'], f'model{rank}.npz'), grads=grads.cpu().numpy(), loss=float(lt) / world,
              state=flat_state(m))
+    # the reference's own wrapping and call (train_ae.py:152-153, training.py:43-54): SyncBatchNorm + DistributedDataParallel around
+    # the model, model(g, p) -> lists -> criterion -> backward; DDP's averaged gradients must equal the flat all-reduce's
+    m2, cfg2 = build()
+    m2 = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m2)
+    m2.reparameterize = lambda mu, logvar: noise[b0:b1] * torch.exp(0.5 * logvar) + mu
+    ddp = torch.nn.parallel.DistributedDataParallel(m2, find_unused_parameters=True)
+    crit2 = models.Flow_Mixture_Loss(**cfg2)
+    output_prior, output_decoder, logits = ddp(g_all[b0:b1], p_all[b0:b1])
+    crit2(output_prior, output_decoder, logits)[0].backward()
+    ddp_grads = torch.cat([q.grad.reshape(-1) for q in m2.parameters() if q.grad is not None])
+    ddp_err = float((ddp_grads - grads).abs().max() / grads.abs().max())
+    assert ddp_grads.numel() == grads.numel() and ddp_err < 1e-5, ddp_err
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
@@ -75,6 +87,7 @@ def main():
             key = name.split('.')[0]
             per[key] = max(per.get(key, 0.0), float(np.abs(a - b).max() / (np.abs(g1).max() + 1e-12)))
             off += n
+        print('DDP list-API step == flat all-reduce step', flush=True)
         print('MODEL2', ' '.join(f'{k}={v:.2e}' for k, v in res.items()), '|', ' '.join(f'{k}={v:.1e}' for k, v in per.items()), flush=True)
         assert res['loss'] < 1e-5 and res['grads'] < 2e-3 and res['running'] < 1e-4, res
 
