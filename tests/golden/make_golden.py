@@ -477,6 +477,29 @@ def g13_full_model():
     print('contract_model.json', len(keys), 'entries')
 
 
+def g19_autoencoding():
+    """Labelled reconstruction of ONE shape in 'autoencoding' mode (what evaluate_ae.py runs for the autoencoding configs:
+    posterior mean as the shape code, models.py:111-133; per-point component draw + direct decoding, flow_mixture.py:146-177),
+    numpy draw seeded, base noise recorded."""
+    from go_with_the_flows_amd import models as omodels
+    cfg = dict(MODEL_CFG, util_mode='autoencoding')
+    ref, mine = Flow_Mixture_Model(**cfg), omodels.Flow_Mixture_Model(**cfg)
+    load_into(ref, mine, 1310)
+    ref.eval()
+    G, Ns = MODEL_CFG['g_latent_space_size'], 40
+    gcloud, _ = synth_inputs(4, 48, G, 1301)
+    pcloud, _ = synth_inputs(4, 48, G, 1302)
+    rng = np.random.default_rng(1900)
+    noise_p = rng.standard_normal((1, 3, Ns)).astype(np.float32)
+    ref.reparameterize = lambda mu, logvar: T(noise_p[:, :, :mu.shape[2]]) * torch.exp(0.5 * logvar) + mu
+    np.random.seed(1920)
+    with torch.no_grad():
+        enc, samples, labels, logits = ref(T(gcloud[1:2, :, :Ns]), T(pcloud[1:2, :, :Ns]), None, Ns, True, False)
+    save('g19_autoencoding', gcloud=gcloud[1:2, :, :Ns], pcloud=pcloud[1:2, :, :Ns], noise_p=noise_p, samples=npy(samples),
+         labels=npy(labels), logits=npy(logits), g_code=npy(enc['g_posterior_mus']),
+         n_lists=np.array([len(enc['g_prior_samples']), len(enc['g_prior_mus'])]))
+
+
 def _pure_functions(relpath, names):
     """Execute the named top-level functions of a reference file from its own source, skipping the imports of the
     un-built CUDA extension (lib/metrics/StructuralLosses: nvcc-only) that keep the whole module from importing here.
@@ -599,6 +622,7 @@ CASES = {
     'g17': g17_encoder_train,
     'g12': g12_prior,
     'g13': g13_full_model,
+    'g19': g19_autoencoding,
     'g14': g14_evaluation_metrics,
     # the decoders of BASELINE.json's configs at their FULL depth (33 / 33 / 18 couplings), genuine reference, fp32 + fp64
     'g15_airplane': lambda: decoder_case('g15_depth_11x37x128', 11, 37, 128, 2, 256, 1500, full_lists=False, train_too=False),

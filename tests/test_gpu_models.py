@@ -331,3 +331,21 @@ def test_deepcopy_and_pickle_of_a_used_model_follow_their_own_weights(tmp_path):
                 vals.append(crit.fused(*mod.forward_fused(g_in, p_in))[0].item())
         assert abs(vals[0] - vals[1]) <= 1e-6 * abs(vals[1]), (how, vals)
         assert abs(vals[0] - base) > 1e-4 * abs(base), how           # and they did move away from the original
+
+
+def test_labelled_autoencoding_matches_reference():
+    """'autoencoding' mode (evaluate_ae.py on the autoencoding configs): the posterior MEAN is the shape code, then the per-point
+    component draw and direct decoding of flow_mixture.py:146-177 (golden g19: numpy draw seeded, base noise recorded)."""
+    D = golden('g19_autoencoding')
+    m, cfg = build(util_mode='autoencoding')
+    m.eval()
+    noise_p = dev(D['noise_p'])
+    m.reparameterize = lambda mu, logvar: noise_p[:, :, :mu.shape[2]] * torch.exp(0.5 * logvar) + mu
+    Ns = D['samples'].shape[2]
+    np.random.seed(1920)
+    with torch.no_grad():
+        enc, samples, labels, logits = m(dev(D['gcloud']), dev(D['pcloud']), None, Ns, True, False)
+    assert maxabs(host(enc['g_posterior_mus']), D['g_code']) < 1e-5 and maxabs(host(logits), D['logits']) < 1e-5
+    assert np.array_equal(host(labels), D['labels'])
+    assert maxabs(host(samples), D['samples']) < TOL_COORD * max(1.0, float(np.abs(D['samples']).max()))
+    assert [len(enc['g_prior_samples']), len(enc['g_prior_mus'])] == list(D['n_lists'])
