@@ -66,9 +66,10 @@ def test_training_mode_forward_and_loss_match_reference(base_type, training):
         assert abs(got - want) < 2e-5 * max(1.0, abs(want))
 
 
-def test_fused_training_step_is_differentiable_and_matches_list_api():
+@pytest.mark.parametrize('base_type', ['free', 'freevar', 'fixed'])
+def test_fused_training_step_is_differentiable_and_matches_list_api(base_type):
     D = golden('g13_full_model')
-    m, cfg = build()
+    m, cfg = build(p_decoder_base_type=base_type)
     m.train()
     noise = dev(D['noise_g'])
     m.reparameterize = lambda mu, logvar: noise * torch.exp(0.5 * logvar) + mu
@@ -85,11 +86,13 @@ def test_fused_training_step_is_differentiable_and_matches_list_api():
     l2.backward()
     assert abs(float(l1) - float(l2)) < 1e-4 * abs(float(l1))
     names = [n for n, p in m.named_parameters() if p.grad is not None]
-    assert set(names) == set(g1) and len(names) > 600
+    assert set(names) == set(g1) and len(names) > 590        # 'fixed' has no p_prior parameters
     # per parameter, relative to its own scale with a floor (gradients that are analytically ~0 -- a bias in front of a
     # BatchNorm -- are pure rounding noise), and globally
-    worst = max(float((p.grad - g1[n]).abs().max() / (g1[n].abs().max() + 1e-3)) for n, p in m.named_parameters() if n in g1)
-    assert worst < 1e-3
+    worst, wn = max((float((p.grad - g1[n]).abs().max() / (g1[n].abs().max() + 1e-3)), n) for n, p in m.named_parameters() if n in g1)
+    # two evaluations whose batch statistics (B*N = 192 points) are summed with float atomics in different orders: single entries of a
+    # FiLM weight gradient move by up to ~2e-3 of the tensor's largest entry from run to run; the global norm below is the tight check
+    assert worst < 5e-3, (wn, worst, float(g1[wn].abs().max()))
     gnorm = float(torch.sqrt(sum((v ** 2).sum() for v in g1.values())))
     dnorm = float(torch.sqrt(sum(((p.grad - g1[n]) ** 2).sum() for n, p in m.named_parameters() if n in g1)))
     assert dnorm < 1e-5 * gnorm
