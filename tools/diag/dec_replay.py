@@ -1,0 +1,65 @@
+"""Whole-model inputs replayed through the decoders alone: is the run-to-run deviation inside the K-batched pipeline?"""
+import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import json, os, numpy as np, torch
+from go_with_the_flows_amd import models
+from go_with_the_flows_amd.synth import load_synth_
+G = 'tests/golden'
+D = np.load(os.path.join(G, 'g13_full_model.npz'))
+dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+cfg = dict(json.load(open(os.path.join(G, 'contract_model.json')))['cfg'], p_decoder_base_type='freevar')
+m = models.Flow_Mixture_Model(**cfg); load_synth_(m, 1310); m = m.cuda().train()
+noise = dev(D['noise_g']); m.reparameterize = lambda mu, lv: noise * torch.exp(0.5 * lv) + mu
+crit = models.Flow_Mixture_Loss(**cfg)
+state = {k: v.clone() for k, v in m.state_dict().items()}
+gcloud, pcloud = dev(D['gcloud']), dev(D['pcloud'])
+enc, dec = m.forward_fused(gcloud, pcloud)
+dec['z'].retain_grad(); dec['logdet'].retain_grad()
+crit.fused(enc, dec)[0].backward()
+Gz, Gld, gs = dec['z'].grad.clone(), dec['logdet'].grad.clone(), enc['g_posterior_samples'].detach().clone()
+rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+def census(name, step, n=40):
+    outs = []
+    for _ in range(n):
+        m.load_state_dict(state); m.zero_grad(set_to_none=True)
+        step()
+        outs.append(torch.cat([p.grad.reshape(-1) for p in m.pc_decoder[0].parameters()]).clone())
+    bad = sum(rel(o, outs[0]) > 1e-5 for o in outs[1:])
+    print('%-28s deviating %d of %d  (max %.1e)' % (name, bad, n - 1, max(rel(o, outs[0]) for o in outs[1:])), flush=True)
+
+def dec_only(Gz=Gz, Gld=Gld):
+    g = gs.clone().requires_grad_(True)
+    z, ld = m.mixture_stack().forward_all(pcloud, g, mode='inverse')
+    ((z * Gz).sum() + (ld * Gld).sum()).backward()
+
+def full_linear():
+    enc, dec = m.forward_fused(gcloud, pcloud)
+    ((dec['z'] * Gz).sum() + (dec['logdet'] * Gld).sum() + enc['g_prior_samples'][-1].sum() * 0).backward()
+
+def full():
+    enc, dec = m.forward_fused(gcloud, pcloud)
+    crit.fused(enc, dec)[0].backward()
+
+census('decoders only', dec_only)
+census('decoders only, Gld=0', lambda: dec_only(Gld=torch.zeros_like(Gld)))
+census('decoders only, Gz=0', lambda: dec_only(Gz=torch.zeros_like(Gz)))
+census('full forward, linear loss', full_linear)
+census('full', full)
+
+# uninitialised reads?  every torch.empty poisoned with NaN, then with a large constant
+_empty = torch.empty
+def poisoned(value):
+    def f(*a, **k):
+        t = _empty(*a, **k)
+        if t.is_floating_point() and t.is_cuda:
+            t.fill_(value)
+        return t
+    return f
+for val in (float('nan'), 1e30, 0.0):
+    torch.empty = poisoned(val)
+    m.load_state_dict(state); m.zero_grad(set_to_none=True)
+    dec_only()
+    gr = torch.cat([p.grad.reshape(-1) for p in m.pc_decoder.parameters()])
+    print('poison', val, 'non-finite grads:', int((~torch.isfinite(gr)).sum()), flush=True)
+    census('decoders only, empty=%s' % val, dec_only)
+torch.empty = _empty
