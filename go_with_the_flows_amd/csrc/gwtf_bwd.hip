@@ -39,11 +39,20 @@ struct BCfg {
   static constexpr int PB_LDS = W1T + 2 * FP * 4;
 };
 
-// STATS = false: backward of the coupling itself.  STATS = true: backward of the train-mode statistics pass
-// (gwtf_train_stats): the upstream is g_stats[branch][{d/dSum y, d/dSum y^2}][FP], i.e. dL/dy(p) = gS + 2 gQ y(p) for every
-// point, y = un-biased accumulator (no FiLM record, no tail); everything after dacc is shared.
+// VAR selects what one pass over the points does:
+//   BW_DIRECT  backward of the coupling itself (BatchNorm as a fixed affine map: the eval-mode backward, and the first half of
+//              the two-pass train-mode chain of the per-coupling autograd nodes).
+//   BW_STATS   backward of the train-mode statistics pass (gwtf_train_stats): the upstream is g_stats[branch][{d/dSum y,
+//              d/dSum y^2}][FP], i.e. dL/dy(p) = gS + 2 gQ y(p) for every point, y = un-biased accumulator (no FiLM record, no
+//              tail); everything after dacc is shared.
+//   BW_LIGHT / BW_MERGED   the train pipeline's two passes.  g_stats depends on the coupling path only through the per-shape sums of
+//              dacc and dacc-weighted activations (the FiLM-record gradients, fold1_bwd_kernel), so LIGHT recomputes the forward and
+//              the tail's backward and leaves ONLY those sums (and the sd2 bias sums); MERGED then runs the expensive part -- dh = W1^T
+//              dy, the sd0 sums, dx, the dW1 partial -- ONCE on dy = dacc + gS + 2 gQ (acc - c) instead of once per path (both are
+//              linear in dy): per level one full pass and one forward-sized pass instead of two full ones, and one set of dW1 partials.
 // waves per SIMD the register allocation is held to: the LDS footprint admits three workgroups per CU up to FP = 48
-template <int MB, int NB, bool STATS>
+enum { BW_DIRECT = 0, BW_STATS = 1, BW_LIGHT = 2, BW_MERGED = 3 };
+template <int MB, int NB, int VAR>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3 : 1))) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
@@ -56,6 +65,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
   using K = Cfg<MB>;
   using KB = BCfg<MB>;
   constexpr int FP = K::FP;
+  constexpr bool STATS = VAR == BW_STATS, LIGHT = VAR == BW_LIGHT, MERGED = VAR == BW_MERGED;
   {
     // blockIdx.y = mixture component of the K-batched train pipeline (all strides 0, Ctot == C for a single stack)
     const size_t comp = blockIdx.y;
@@ -65,6 +75,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
     g_in += comp * ks_.pts;
     dw1_ws += comp * ks_.dw1;
     g_sd0 += comp * ks_.gsd0;
+    if (MERGED) g_stats += comp * ks_.gstats;
     if (!STATS) {
       g_out += comp * ks_.pts;
       g_ld += comp * ks_.pts;
@@ -78,7 +89,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
       g_stats += comp * ks_.gstats;
     }
   }
-  __shared__ __align__(16) float lds[K::PW + K::FSP + KB::PB_LDS];
+  __shared__ __align__(16) float lds[K::PW + K::FSP + (LIGHT ? 0 : KB::PB_LDS)];
   __shared__ float s_film[2][3][FP], s_sd0[2][3][FP], s_bias[4];
   // dW1 machinery: coordinates of the workgroup's points, per-wave |dacc| maxima, the transposed dacc image
   constexpr int PTS = 64 * NB;                      // points per workgroup
@@ -116,10 +127,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
     }
     if (!STATS && wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
       __builtin_amdgcn_global_load_lds((glb_void*)(src_f + wave * 256), (lds_void*)&lds[K::PW + wave * 256], 16, 0, 0);
-    for (int piece = wave; piece * 256 < KB::W1T; piece += 4)        // W1T of branch 0 (W1T is a multiple of 256 floats)
+    for (int piece = wave; !LIGHT && piece * 256 < KB::W1T; piece += 4)        // W1T of branch 0 (W1T is a multiple of 256 floats)
       __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + piece * 256 + lane * 4),
                                        (lds_void*)&lds[K::PW + K::FSP + piece * 256], 16, 0, 0);
-    for (int piece = wave; piece * 256 < 2 * FP * 4; piece += 4) {   // SD0N of both branches
+    for (int piece = wave; !LIGHT && piece * 256 < 2 * FP * 4; piece += 4) {   // SD0N of both branches
       if (piece * 256 + lane * 4 < 2 * FP * 4)
         __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + 2 * KB::W1T + piece * 256 + lane * 4),
                                          (lds_void*)&lds[K::PW + K::FSP + KB::W1T + piece * 256], 16, 0, 0);
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
   float gin[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) gin[d] = STATS ? 0.f : (d == w0 ? gx[0] : ((!keep2 && d == w1) ? gx[1] : go[d] * keep_scale));
-  if (!STATS) {  // sd2 bias gradient: sum of dt over the wave's valid points
+  if (!STATS && !MERGED) {  // sd2 bias gradient: sum of dt over the wave's valid points
     float bsum[4] = {own_valid ? dt[0][0] : 0.f, own_valid ? dt[0][1] : 0.f, own_valid ? dt[1][0] : 0.f,
                      own_valid ? dt[1][1] : 0.f};
 #pragma unroll
@@ -268,6 +279,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
           }
           continue;
         }
+        if (MERGED) {     // dy = dacc (coupling path) + gS + 2 gQ y (statistics path), y = acc - c; the FiLM sums were LIGHT's job
+          const float gs = ft < f ? g_stats[(br * 2 + 0) * FP + ft] : 0.f, gq2 = ft < f ? 2.0f * g_stats[(br * 2 + 1) * FP + ft] : 0.f;
+          const float cc = fe[16 * m + r];
+#pragma unroll
+          for (int nb = 0; nb < NB; ++nb) {
+            const int n = n_wave0 + 16 * nb + i16;
+            const float a = acc[br][m][nb][r];
+            const float da = a > 0.f ? fmaf(u0[r], d0[nb], u1[r] * d1[nb]) : 0.f;
+            acc[br][m][nb][r] = n < N ? da + fmaf(gq2, a - cc, gs) : 0.f;
+          }
+          continue;
+        }
         float sdc = 0.f, sdu0 = 0.f, sdu1 = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -289,6 +312,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
         }
       }
     }
+    if (LIGHT) continue;
     // dh[16mi + 4q + r][point] = sum_j W1p[j][16mi + ..] dacc[j][point] on the f16 MFMA with the three-product split.
     // Gradients have no natural scale (a 1/(B N) loss normalisation puts them near the f16 subnormals), so the WORKGROUP
     // rescales dacc by a power of two that brings its largest magnitude to [2^8, 2^9) and undoes it on dh and dW1: exact.
@@ -455,7 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
     if (d == k0) gin[d] += dxa_own;
     if (keep2 && d == k1) gin[d] += dxb_own;
   }
-  if (own_valid) {
+  if (!LIGHT && own_valid) {
 #pragma unroll
     for (int d = 0; d < 3; ++d) g_in[((size_t)b * 3 + d) * N + n_own] = gin[d];
   }
@@ -465,10 +489,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3
   float* gf = g_film + ((size_t)b * C + c) * (2 * 3 * FP);
   float* gs = g_sd0 + (size_t)(blockIdx.x % GWTF_STAT_REPLICAS) * (2 * 3 * FP);
   for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
-    if (!STATS) atomicAdd(&gf[t], (&s_film[0][0][0])[t]);
-    atomicAdd(&gs[t], (&s_sd0[0][0][0])[t]);
+    if (!STATS && !MERGED) atomicAdd(&gf[t], (&s_film[0][0][0])[t]);
+    if (!LIGHT) atomicAdd(&gs[t], (&s_sd0[0][0][0])[t]);
   }
-  if (!STATS && threadIdx.x < 4) atomicAdd(&g_bias[(blockIdx.x % GWTF_STAT_REPLICAS) * 4 + threadIdx.x], s_bias[threadIdx.x]);
+  if (!STATS && !MERGED && threadIdx.x < 4) atomicAdd(&g_bias[(blockIdx.x % GWTF_STAT_REPLICAS) * 4 + threadIdx.x], s_bias[threadIdx.x]);
 }
 
 // folded parameters (what autograd differentiates) -> forward + backward packed records, see gwtf_layout.h
@@ -532,14 +556,14 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
   }
 }
 
-template <int MB, bool STATS>
+template <int MB, int VAR>
 int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
                const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0, float* g_bias,
                const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, int mode, int K,
                const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
-#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, STATS>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c)
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, VAR>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B
   return (int)hipGetLastError();
@@ -572,7 +596,7 @@ static int bwd_grid(int B, int N) {
   return B * ((N + pts - 1) / pts);
 }
 
-static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+static int bwd_dispatch(int var, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                         const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0,
                         float* g_bias, const float* g_stats, int c, int B, int N, int C, int f, int pat, float eps, int mode,
                         int K, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
@@ -580,16 +604,24 @@ static int bwd_dispatch(bool stats, const float* x_in, const float* g_out, const
   const int nb = bwd_points_per_wg(B, N) / 64;
   hipStream_t st = (hipStream_t)stream;
 #define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, K, ks, g_ps_c, g_lvs_c, st
+#define GWTF_V(MB_)                                                                                     \
+  switch (var) {                                                                                        \
+    case BW_DIRECT: return launch_bwd<MB_, BW_DIRECT>(nb, GWTF_A);                                      \
+    case BW_STATS: return launch_bwd<MB_, BW_STATS>(nb, GWTF_A);                                        \
+    case BW_LIGHT: return launch_bwd<MB_, BW_LIGHT>(nb, GWTF_A);                                        \
+    default: return launch_bwd<MB_, BW_MERGED>(nb, GWTF_A);                                             \
+  }
   switch (gwtf_padded_width(f) / 16) {
-    case 1: return stats ? launch_bwd<1, true>(nb, GWTF_A) : launch_bwd<1, false>(nb, GWTF_A);
-    case 2: return stats ? launch_bwd<2, true>(nb, GWTF_A) : launch_bwd<2, false>(nb, GWTF_A);
-    case 3: return stats ? launch_bwd<3, true>(nb, GWTF_A) : launch_bwd<3, false>(nb, GWTF_A);
-    case 4: return stats ? launch_bwd<4, true>(nb, GWTF_A) : launch_bwd<4, false>(nb, GWTF_A);
-    case 5: return stats ? launch_bwd<5, true>(nb, GWTF_A) : launch_bwd<5, false>(nb, GWTF_A);
-    case 6: return stats ? launch_bwd<6, true>(nb, GWTF_A) : launch_bwd<6, false>(nb, GWTF_A);
+    case 1: GWTF_V(1)
+    case 2: GWTF_V(2)
+    case 3: GWTF_V(3)
+    case 4: GWTF_V(4)
+    case 5: GWTF_V(5)
+    case 6: GWTF_V(6)
     default: return GWTF_E_BADARG;       // f > 96: the backward working set (forward + backward records) exceeds the LDS
   }
 #undef GWTF_A
+#undef GWTF_V
 }
 
 extern "C" int gwtf_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
@@ -611,7 +643,7 @@ extern "C" int gwtf_coupling_backward_lists(const float* x_in, const float* g_ou
     return GWTF_E_BADARG;
   GwtfKS ks = {};
   ks.Cper = ks.Ctot = C;
-  return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
+  return bwd_dispatch(BW_DIRECT, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
                       B, N, C, f, (pattern0 + c) % 6, eps, mode, 1, ks, g_ps_c, g_lvs_c, stream);
 }
 
@@ -620,13 +652,30 @@ int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, con
                                       const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
                                       float* g_sd0, float* g_bias, int c, int K, int B, int N, int f, int pattern0, float eps,
                                       int mode, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
-  return bwd_dispatch(false, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
+  return bwd_dispatch(BW_DIRECT, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
                       B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c, g_lvs_c, stream);
+}
+// The train pipeline's two passes (BW_LIGHT / BW_MERGED above).  light: only g_film and g_bias are written; merged: g_in, the dW1
+// partials and g_sd0, with the statistics path's upstream g_stats [K][2][2][FP] added to dacc.
+int gwtf_internal_light_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                                   const float* film, float* g_film, float* g_bias, int c, int K, int B, int N, int f,
+                                   int pattern0, float eps, int mode, const GwtfKS& ks, const float* g_ps_c,
+                                   const float* g_lvs_c, void* stream) {
+  return bwd_dispatch(BW_LIGHT, x_in, g_out, g_ld, packed_w_c, packed_w_c /*unused*/, film, g_film /*unused*/, g_film /*unused*/,
+                      g_film, g_film /*unused*/, g_bias, nullptr, c, B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c,
+                      g_lvs_c, stream);
+}
+int gwtf_internal_merged_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                                    const float* packed_b_c, const float* film, const float* g_stats, float* g_in, float* dw1_ws,
+                                    float* g_sd0, int c, int K, int B, int N, int f, int pattern0, float eps, int mode,
+                                    const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
+  return bwd_dispatch(BW_MERGED, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_sd0 /*unused*/, g_sd0,
+                      g_sd0 /*unused*/, g_stats, c, B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c, g_lvs_c, stream);
 }
 int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
                                    float* g_in, float* dw1_ws, float* g_sd0, int K, int B, int N, int f, int pattern,
                                    const GwtfKS& ks, void* stream) {
-  return bwd_dispatch(true, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dw1_ws,
+  return bwd_dispatch(BW_STATS, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dw1_ws,
                       g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, K, ks,
                       nullptr, nullptr, stream);
 }

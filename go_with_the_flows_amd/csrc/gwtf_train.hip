@@ -161,6 +161,14 @@ int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, con
 int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
                                    float* g_in, float* dw1_ws, float* g_sd0, int K, int B, int N, int f, int pattern,
                                    const GwtfKS& ks, void* stream);
+int gwtf_internal_light_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                                   const float* film, float* g_film, float* g_bias, int c, int K, int B, int N, int f,
+                                   int pattern0, float eps, int mode, const GwtfKS& ks, const float* g_ps_c,
+                                   const float* g_lvs_c, void* stream);
+int gwtf_internal_merged_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
+                                    const float* packed_b_c, const float* film, const float* g_stats, float* g_in, float* dw1_ws,
+                                    float* g_sd0, int c, int K, int B, int N, int f, int pattern0, float eps, int mode,
+                                    const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream);
 int gwtf_internal_dw1_reduce_k(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N, int K,
                                size_t ws_sk, size_t out_sk, void* stream);
 
@@ -441,7 +449,7 @@ __global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
   fold0_bwd_block(raw_c, mom_rep, n_total, pat, g_sd0, g_raw_c, part, f, G, FP, ks, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
 }
 
-// g_in = g_a + g_b + d(moments)/dx:  gM_a + sum_b Q_ab x_b,  Q_aa = 2 gM_aa, Q_ab = gM_ab.  The nine moment gradients gM
+// g_in = g_a [+ g_b: a second pass's share, null when one merged pass wrote g_a] + d(moments)/dx:  gM_a + sum_b Q_ab x_b,  Q_aa = 2 gM_aa, Q_ab = gM_ab.  The nine moment gradients gM
 // are finished here from fold0_bwd_kernel's partial sums (every workgroup redoes the ~100 loads: cheaper than one more
 // single-workgroup kernel in the dependency chain).
 // block (bx of n_bx = slice of the points, by = shape, bz = mixture component)
@@ -452,7 +460,7 @@ __device__ __forceinline__ void combine_block(const float* __restrict__ x, const
                                               int n_bx) {
   x += bz * ks.x;
   ga += bz * ks.pts;
-  gb += bz * ks.pts;
+  if (gb) gb += bz * ks.pts;
   g_in += bz * ks.pts;
   mom_rep += bz * ks.mom;
   part += bz * (ks.gmom / 2);
@@ -495,9 +503,10 @@ __device__ __forceinline__ void combine_block(const float* __restrict__ x, const
   for (int n = bx * blockDim.x + threadIdx.x; n < N; n += n_bx * blockDim.x) {
     const size_t o0 = ((size_t)b * 3 + 0) * N + n, o1 = o0 + N, o2 = o1 + N;
     const float x0 = x[o0], x1 = x[o1], x2 = x[o2];
-    g_in[o0] = ga[o0] + gb[o0] + gm[0] + q00 * x0 + q01 * x1 + q02 * x2;
-    g_in[o1] = ga[o1] + gb[o1] + gm[1] + q01 * x0 + q11 * x1 + q12 * x2;
-    g_in[o2] = ga[o2] + gb[o2] + gm[2] + q02 * x0 + q12 * x1 + q22 * x2;
+    const float a0 = gb ? ga[o0] + gb[o0] : ga[o0], a1 = gb ? ga[o1] + gb[o1] : ga[o1], a2 = gb ? ga[o2] + gb[o2] : ga[o2];
+    g_in[o0] = a0 + gm[0] + q00 * x0 + q01 * x1 + q02 * x2;
+    g_in[o1] = a1 + gm[1] + q01 * x0 + q11 * x1 + q12 * x2;
+    g_in[o2] = a2 + gm[2] + q02 * x0 + q12 * x1 + q22 * x2;
   }
 }
 
@@ -565,8 +574,8 @@ extern "C" int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, in
 //     GWTF_PHASE_FWD_A   fold0 (K workgroups) + statistics pass (K x tiles)          -> all-reduce ystats[c]       (K x 64*2*FP*2)
 //     GWTF_PHASE_FWD_B   fold1 (B x K) + apply pass (K x tiles, moments of the output) -> all-reduce moments[step+1] (K x 64*16)
 //   backward, per depth level in reverse:
-//     GWTF_PHASE_BWD_A   coupling-path backward + fold1 backward                     -> all-reduce g_stats[c]      (K x 2*2*FP)
-//     GWTF_PHASE_BWD_B   statistics-path backward + fold0 backward                   -> all-reduce g_mom[c]        (K x 48 doubles)
+//     GWTF_PHASE_BWD_A   light pass (FiLM-record / bias sums of the coupling path) + fold1 backward -> all-reduce g_stats[c] (K x 2*2*FP)
+//     GWTF_PHASE_BWD_B   merged backward (coupling + statistics path) + fold0 backward  -> all-reduce g_mom[c]     (K x 48 doubles)
 //     GWTF_PHASE_BWD_C   combine (moments path) + dW1 reduction
 //
 // i.e. TWO small collectives per depth level and direction for all K x 2 branches (66 per forward of the 33-coupling
@@ -596,8 +605,8 @@ Dims dims_of(const GwtfTrainCtx* t) {
   d.FS = gwtf_film_out_size(d.FP);
   return d;
 }
-size_t dw1_region(const GwtfTrainCtx* t) {   // one component's dW1 workspace: two passes of partials + reduction scratch
-  return 2 * gwtf_dw1_workspace_floats(t->f, t->B, t->N) + gwtf_dw1_reduce_scratch_floats(t->f);
+size_t dw1_region(const GwtfTrainCtx* t) {   // one component's dW1 workspace: the merged pass's partials + reduction scratch
+  return gwtf_dw1_workspace_floats(t->f, t->B, t->N) + gwtf_dw1_reduce_scratch_floats(t->f);
 }
 GwtfKS strides_of(const GwtfTrainCtx* t, const Dims& d, bool first_level) {
   GwtfKS ks = {};
@@ -636,7 +645,7 @@ bool ctx_ok(const GwtfTrainCtx* t, bool backward) {
 }  // namespace
 
 extern "C" size_t gwtf_mtrain_dw1_floats(int f, int B, int N) {
-  return 2 * gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f);
+  return gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f);
 }
 
 extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
@@ -692,22 +701,22 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   const float* pw_c = t->packed_w + (size_t)c * d.PW;
   const float* pb_c = t->packed_b + (size_t)c * d.PB;
   float* g_raw_c = t->g_raw + (size_t)c * d.RC;
+  const float* g_ps_c = t->g_ps ? t->g_ps + (size_t)c * d.XS : nullptr;
+  const float* g_lvs_c = t->g_lvs ? t->g_lvs + (size_t)c * d.XS : nullptr;
   if (phase == GWTF_PHASE_BWD_A) {
-    int rc = gwtf_internal_coupling_backward_k(x_in, cur, t->g_ld, pw_c, pb_c, t->film_rec, t->g_xa, t->dw1_ws, t->g_film, g_sd0,
-                                               g_bias, c, K, B, N, f, t->pattern0, t->eps, t->mode, ks,
-                                               t->g_ps ? t->g_ps + (size_t)c * d.XS : nullptr,
-                                               t->g_lvs ? t->g_lvs + (size_t)c * d.XS : nullptr, t->stream);
+    int rc = gwtf_internal_light_backward_k(x_in, cur, t->g_ld, pw_c, t->film_rec, t->g_film, g_bias, c, K, B, N, f, t->pattern0,
+                                            t->eps, t->mode, ks, g_ps_c, g_lvs_c, t->stream);
     if (rc) return rc;
     hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, K), dim3(kF1Slices * 16), 0, st, t->raw + (size_t)c * d.RC, ys,
                        t->n_total, t->film_raw, t->g_film, g_bias, t->g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks);
     return (int)hipGetLastError();
   }
   if (phase == GWTF_PHASE_BWD_B) {
-    int rc = gwtf_internal_stats_backward_k(x_in, g_stats, pw_c, pb_c, t->g_xb, t->dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0,
-                                            K, B, N, f, pat, ks, t->stream);
+    int rc = gwtf_internal_merged_backward_k(x_in, cur, t->g_ld, pw_c, pb_c, t->film_rec, g_stats, t->g_xa, t->dw1_ws, g_sd0, c, K, B,
+                                             N, f, t->pattern0, t->eps, t->mode, ks, g_ps_c, g_lvs_c, t->stream);
     if (rc) return rc;
-    // sd0 fold + stage 1 of the dW1 reduction (both passes' partials are complete now) in one launch
-    const int rec = 2 * f * f, n_partials = 2 * gwtf_dw1_partials(B, N);
+    // sd0 fold + stage 1 of the dW1 reduction in one launch
+    const int rec = 2 * f * f, n_partials = gwtf_dw1_partials(B, N);
     float* mid = t->dw1_ws + (size_t)n_partials * rec;
     const unsigned blocks = 2u * (FP / 16) * K + (unsigned)((rec + 255) / 256) * gwtf_dw1::kStage * K;
     hipLaunchKernelGGL(bwd_tail1_kernel, dim3(blocks), dim3(256), 0, st, t->raw + (size_t)c * d.RC, mom, t->n_total, pat, g_sd0, g_raw_c,
@@ -717,10 +726,10 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   // GWTF_PHASE_BWD_C: gradient combine + stage 2 of the dW1 reduction in one launch
   const int bxn = (N + 255) / 256, n_bx = bxn < 64 ? bxn : 64;
   const GwtfRaw R(f, G);
-  const int rec = 2 * f * f, n_partials = 2 * gwtf_dw1_partials(B, N);
+  const int rec = 2 * f * f, n_partials = gwtf_dw1_partials(B, N);
   const float* mid = t->dw1_ws + (size_t)n_partials * rec;
   const unsigned blocks = (unsigned)n_bx * B * K + (unsigned)((2 * f * f + 63) / 64) * K;
-  hipLaunchKernelGGL(bwd_tail2_kernel, dim3(blocks), dim3(256), 0, st, x_in, t->g_xa, t->g_xb, mom,
+  hipLaunchKernelGGL(bwd_tail2_kernel, dim3(blocks), dim3(256), 0, st, x_in, t->g_xa, static_cast<const float*>(nullptr), mom,
                      reinterpret_cast<const double*>(g_mom), 2 * (FP / 16), t->n_total, pat, nxt, B, N, ks, K, n_bx, mid,
                      g_raw_c + R.sd1_w(), f, R.branch_size());
   return (int)hipGetLastError();
@@ -851,20 +860,23 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
   const double n_total = (double)B * N;
   hipStream_t st = (hipStream_t)stream;
   const GwtfKS ks = single_ks(C);
-  int rc = gwtf_coupling_backward(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_xa, dw1_ws, g_film, g_sd0,
-                                  g_bias, c, B, N, C, f, pattern0, eps, mode, stream);
+  if (B <= 0 || N <= 0 || C <= 0 || c < 0 || c >= C || f <= 0 || f > GWTF_MAX_FP_TRAIN || pattern0 < 0 || pattern0 > 5 ||
+      (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE))
+    return GWTF_E_BADARG;
+  int rc = gwtf_internal_light_backward_k(x_in, g_out, g_ld, packed_w_c, film_rec, g_film, g_bias, c, 1, B, N, f, pattern0, eps,
+                                          mode, ks, nullptr, nullptr, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, 1), dim3(kF1Slices * 16), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
                      g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks);
-  rc = gwtf_stats_backward(x_in, g_stats, packed_w_c, packed_b_c, g_xb, dw1_ws + gwtf_dw1_workspace_floats(f, B, N), g_sd0, B, N,
-                           f, pat, stream);
+  rc = gwtf_internal_merged_backward_k(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_stats, g_xa, dw1_ws, g_sd0, c, 1, B,
+                                       N, f, pattern0, eps, mode, ks, nullptr, nullptr, stream);
   if (rc) return rc;
   double* part = reinterpret_cast<double*>(g_mom);          // [2][FP/16][5] doubles of scratch (<= 80 floats)
   hipLaunchKernelGGL(fold0_bwd_kernel, dim3(2, FP / 16, 1), dim3(kF1Slices * 16), 0, st, raw_c, moments_c, n_total, pat, g_sd0,
                      g_raw_c, part, f, G, FP, ks);
   const int bx = (N + 255) / 256;
-  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B, 1), dim3(256), 0, st, x_in, g_xa, g_xb, moments_c, part,
-                     2 * (FP / 16), n_total, pat, g_in, B, N, ks);
+  hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B, 1), dim3(256), 0, st, x_in, g_xa, static_cast<const float*>(nullptr),
+                     moments_c, part, 2 * (FP / 16), n_total, pat, g_in, B, N, ks);
   const GwtfRaw R(f, G);
-  return gwtf_dw1_reduce(dw1_ws, 2, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, stream);
+  return gwtf_dw1_reduce(dw1_ws, 1, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, stream);
 }
