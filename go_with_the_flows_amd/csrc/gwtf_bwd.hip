@@ -22,6 +22,7 @@
 // reduction), and writes it to a per-workgroup partial that gwtf_dw1_reduce sums in a fixed order: nothing of size
 // O(B N f) is written to HBM any more (it was 100-150 MB per coupling).
 #include "gwtf_device.h"
+#include <cstdlib>
 #include "gwtf_dw1.h"
 
 namespace {
@@ -53,7 +54,7 @@ struct BCfg {
 // waves per SIMD the register allocation is held to: the LDS footprint admits three workgroups per CU up to FP = 48
 enum { BW_DIRECT = 0, BW_STATS = 1, BW_LIGHT = 2, BW_MERGED = 3 };
 template <int MB, int NB, int VAR>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MB <= 3 ? 3 : 1))) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2 : (MB <= 3 ? 3 : 1)))) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
                                                   float* __restrict__ g_in, float* __restrict__ dw1_ws,
@@ -563,6 +564,14 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
                const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
+  if constexpr (VAR == BW_LIGHT && MB <= 3) {   // forward-sized pass: the forward kernel's tile (256 points per workgroup) where it fills the GPU
+    static const bool small_tile = getenv("GWTF_LIGHT_SMALL_TILE") != nullptr;      // diagnostic hook (tools/diag/light_tile_check.py)
+    if (nb == 2 && (long)B * N * K >= 256L * 1024 && !small_tile) {
+      const dim3 grid4((unsigned)(B * ((N + 255) / 256)), (unsigned)K);
+      hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+      return (int)hipGetLastError();
+    }
+  }
 #define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, VAR>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B

@@ -413,6 +413,45 @@ def test_mixture_partitioned_sampling_path(counts):
         off += cnt
 
 
+def test_train_backward_light_pass_tile_shapes_agree():
+    """The train backward's light pass (FiLM-record sums, csrc/gwtf_bwd.hip BW_LIGHT) takes 256 points per workgroup from B*N*K =
+    256 Ki points up and 128 below: K = 2 components in one pipeline pass (large tile) give the gradients of the two K = 1
+    passes (small tile).  Two evaluations at this size are not equal to rounding: of the ~10^7 ReLU pre-activations a few lie
+    within the run-to-run rounding of the batch statistics of their kink and flip (with either tile,
+    tools/diag/light_tile_check.py).  A flip changes its point's cloud gradient by O(1), the latent gradients by ~1/N and
+    a few parameter tensors by up to ~1e-3 (less with the positive loss weights used here: no cancellation in the sums), so the
+    bars are: the typical tensor / point / shape agrees to rounding, and only a handful are off at all.  A wrong tile would be off
+    everywhere."""
+    L, f, G, B, N = 1, 8, 16, 64, 2048
+    decs = [decoder_and_state(L, f, G, 640 + k)[0].to(DEV).train() for k in range(2)]
+    p, g = synth_inputs(B, N, G, 641)
+    gen = torch.Generator().manual_seed(642)
+    wz, wl = torch.randn(2, B, 3, N, generator=gen).abs().to(DEV), torch.randn(2, B, 3, N, generator=gen).abs().to(DEV)
+
+    def run(stack_decs, ks):
+        for d in decs:
+            d.zero_grad(set_to_none=True)
+        pd, gd = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+        z, ld = gw.MixtureStack(stack_decs).forward_all(pd, gd, 'inverse')
+        ((z * wz[ks]).sum() + (ld * wl[ks]).sum()).backward()
+        return pd.grad.clone(), gd.grad.clone(), [[q.grad.clone() for q in d.parameters()] for d in stack_decs]
+
+    state = [{k: v.clone() for k, v in d.state_dict().items()} for d in decs]
+    dp2, dg2, gr2 = run(decs, slice(0, 2))
+    dp1, dg1 = torch.zeros_like(dp2), torch.zeros_like(dg2)
+    for k in range(2):
+        decs[k].load_state_dict(state[k])
+        a, b, (gr1,) = run([decs[k]], slice(k, k + 1))
+        dp1 += a
+        dg1 += b
+        rel = sorted(float((x - y).abs().max() / (x.abs().max() + 1e-12)) for x, y in zip(gr1, gr2[k]))
+        assert rel[len(rel) // 2] < 1e-5 and rel[-1] < 5e-3, (k, rel[len(rel) // 2], rel[-1])
+    per_point = (dp1 - dp2).abs().amax(1) / dp1.abs().mean()
+    assert int((per_point > 1e-4).sum()) <= 16, int((per_point > 1e-4).sum())
+    # latents: the FiLM heads' BatchNorm runs over the shapes, so one flip reaches every shape's gradient (1e-5 .. 2e-4 observed)
+    assert float((dg1 - dg2).norm()) < 1e-3 * float(dg1.norm())
+
+
 # ---- train mode: batch-statistic BatchNorm -------------------------------------------------------------------
 @pytest.mark.parametrize('mode', ['direct', 'inverse'])
 def test_g1_train_mode_single_couplings(mode):
