@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/profile_train.sh <tag>  -- kernel-trace stats + PMC passes of the train step (one 33-coupling
 # airplane component, 64 x 2048 points: tools/diag/trainstep_kernels.py), per kernel.  Summary -> gpurun_out/prof_<tag>_train/summary.txt
-TAG=${1:-r07}
+TAG=${1:-r09}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_${TAG}_train; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ts -o ts -- python3 tools/diag/trainstep_kernels.py > $OUT/ts.log 2>&1
@@ -33,7 +33,7 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for fn in glob.glob(f"{out}/{d}/*counter_collection.csv"):
         for r in csv.DictReader(open(fn)):
             k = r["Kernel_Name"]
-            key = next((n for n in ("bwd_kernel<3, 2, false>", "bwd_kernel<3, 2, true>", "stats_kernel", "stack_kernel", "dw1_fold_kernel", "fold1_bwd_kernel", "fold0_bwd_kernel", "combine_kernel") if n in k), None)
+            key = next((n for n in ("bwd_kernel<3, 2, 3>", "bwd_kernel<3, 2, 2>", "bwd_kernel<3, 4, 2>", "stats_kernel", "stack_kernel", "bwd_tail1_kernel", "bwd_tail2_kernel", "fold1_bwd_kernel") if n in k), None)
             if key is None: continue
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[key] = {m: r[m] for m in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
