@@ -29,6 +29,8 @@ _SIGNATURES = {
     'gwtf_pack_weights_k': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 6 + [_c_fp]),
     'gwtf_film_forward': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_film_bn_swish_forward': (ctypes.c_int, [_c_fp] * 3 + [ctypes.c_long] * 3 + [ctypes.c_int] * 3 + [_c_fp] * 5),
+    'gwtf_film_bn_swish_backward': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_long] * 3 + [ctypes.c_int] * 3 + [_c_fp] * 6),
     'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_stack_forward_multi': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
                                  [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_fp]),

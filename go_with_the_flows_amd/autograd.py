@@ -353,15 +353,51 @@ class ApplyFn(torch.autograd.Function):
                 None, None, None, None, None, None)
 
 
+class _BNSwishRows(torch.autograd.Function):
+    """hraw (B,C,2,2,f), BatchNorm weight / bias (C,2,2,f) (strided views of the raw arena) -> swish(BatchNorm over the B rows with
+    batch statistics), batch mean, biased batch variance: one HIP kernel per direction (csrc/gwtf_film.hip)."""
+
+    @staticmethod
+    def forward(ctx, hraw, hg, hb):
+        L = _lib.lib()
+        hraw = hraw.contiguous()
+        B, C, f = hraw.shape[0], hraw.shape[1], hraw.shape[-1]
+        M = hraw[0].numel()
+        if hg.stride() != hb.stride() or hg.stride(3) != 1 or hg.dtype != torch.float32:
+            hg, hb = hg.contiguous(), hb.contiguous()
+        y = torch.empty_like(hraw)
+        stats = torch.empty(3, M, device=hraw.device, dtype=torch.float32)
+        with torch.cuda.device(hraw.device):
+            _lib.check(L.gwtf_film_bn_swish_forward(hraw.data_ptr(), hg.data_ptr(), hb.data_ptr(), hg.stride(0), hg.stride(1),
+                                                    hg.stride(2), f, B, M, y.data_ptr(), stats[0].data_ptr(), stats[1].data_ptr(),
+                                                    stats[2].data_ptr(), _lib._stream(hraw)))
+        ctx.save_for_backward(hraw, hg, hb, stats)
+        mean, var = stats[0].view(hraw.shape[1:]), stats[1].view(hraw.shape[1:])
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        hraw, hg, hb, stats = ctx.saved_tensors
+        L = _lib.lib()
+        B, f = hraw.shape[0], hraw.shape[-1]
+        M = hraw[0].numel()
+        gy = gy.contiguous()
+        gx = torch.empty_like(hraw)
+        gp = torch.empty(2, M, device=hraw.device, dtype=torch.float32)
+        with torch.cuda.device(hraw.device):
+            _lib.check(L.gwtf_film_bn_swish_backward(hraw.data_ptr(), gy.data_ptr(), hg.data_ptr(), hb.data_ptr(), hg.stride(0),
+                                                     hg.stride(1), hg.stride(2), f, B, M, stats[0].data_ptr(), stats[2].data_ptr(),
+                                                     gx.data_ptr(), gp[0].data_ptr(), gp[1].data_ptr(), _lib._stream(hraw)))
+        return gx, gp[0].view(hraw.shape[1:]), gp[1].view(hraw.shape[1:])
+
+
 def _film_train(P, g, eps):
     """FiLM heads with batch statistics over the B latent rows -> a, bsh (B,C,2,f) and batch {mean, unbiased var}."""
     hg, hb, _, _ = P['hbn']
     hraw = torch.einsum('bg,cxhfg->bcxhf', g, P['L0'])
     Bn = hraw.shape[0]
-    mean = hraw.mean(0)
-    var = hraw.var(0, unbiased=False)
-    hbn = (hraw - mean) / torch.sqrt(var + BN_EPS) * hg + hb
-    hn = hbn * torch.sigmoid(hbn)
+    hn, mean, var = _BNSwishRows.apply(hraw, hg, hb)
     o = torch.einsum('bcxhi,cxhji->bcxhj', hn, P['L1']) + P['b1']
     # + poison: a non-finite parameter anywhere in the branch makes the FiLM scale NaN, hence u = W2 a s1 and every output
     # (the kernels' v_max ReLU alone would turn e.g. a NaN sd0 weight into a zero activation)

@@ -347,3 +347,113 @@ extern "C" int gwtf_film_forward(const float* g, const float* packed_film, float
   }
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Differentiable train-mode FiLM heads (autograd.py _film_train): between the two batched products of a head sits BatchNorm over
+// the B latent ROWS (batch statistics, reference flows.py:33-38 / 68-73 nn.BatchNorm1d in train()) and a swish.  One kernel forward
+// and one backward instead of ~30 elementwise / reduction launches:
+//   x [B][M] (M = heads * f columns, contiguous)   gamma / beta: element (head = (c, x, h), j) at base + c*sc + x*sx + h*sh + j
+//   forward : mean[M], var[M] (biased), rstd[M], y = swish(gamma (x - mean) rstd + beta)
+//   backward: dx [B][M], dgamma[M], dbeta[M]
+// Block = 64 columns x 4 row slices; the column sums go through LDS.  Two-pass variance (torch's var).
+namespace {
+constexpr int kBsCols = 64, kBsSlices = 4;
+
+__device__ __forceinline__ size_t bs_param_offset(int col, int f, long sc, long sx, long sh) {
+  const int j = col % f, head = col / f;
+  return (size_t)(head >> 2) * sc + (size_t)((head >> 1) & 1) * sx + (size_t)(head & 1) * sh + j;
+}
+
+__device__ __forceinline__ float bs_col_sum(float v, float (*red)[kBsCols], int sl, int tc) {
+  red[sl][tc] = v;
+  __syncthreads();
+  const float s = (red[0][tc] + red[1][tc]) + (red[2][tc] + red[3][tc]);
+  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(kBsCols * kBsSlices) void bn_swish_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                            const float* __restrict__ beta, long sc, long sx, long sh,
+                                                                            int f, int B, int M, float* __restrict__ y,
+                                                                            float* __restrict__ mean, float* __restrict__ var,
+                                                                            float* __restrict__ rstd) {
+  __shared__ float red[kBsSlices][kBsCols];
+  const int tc = threadIdx.x % kBsCols, sl = threadIdx.x / kBsCols;
+  const int col = blockIdx.x * kBsCols + tc;
+  const bool on = col < M;
+  float s = 0.f;
+  if (on)
+    for (int r = sl; r < B; r += kBsSlices) s += x[(size_t)r * M + col];
+  const float mu = bs_col_sum(s, red, sl, tc) / (float)B;
+  float q = 0.f;
+  if (on)
+    for (int r = sl; r < B; r += kBsSlices) { const float d = x[(size_t)r * M + col] - mu; q = fmaf(d, d, q); }
+  const float v = bs_col_sum(q, red, sl, tc) / (float)B;
+  if (!on) return;
+  const float rs = 1.0f / sqrtf(v + GWTF_BN_EPS);
+  const size_t po = bs_param_offset(col, f, sc, sx, sh);
+  const float ga = gamma[po], be = beta[po];
+  for (int r = sl; r < B; r += kBsSlices) {
+    const float h = fmaf((x[(size_t)r * M + col] - mu) * rs, ga, be);
+    y[(size_t)r * M + col] = h / (1.0f + expf(-h));
+  }
+  if (sl == 0) { mean[col] = mu; var[col] = v; rstd[col] = rs; }
+}
+
+__global__ __launch_bounds__(kBsCols * kBsSlices) void bn_swish_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                            long sc, long sx, long sh, int f, int B, int M,
+                                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                                            float* __restrict__ gx, float* __restrict__ ggamma,
+                                                                            float* __restrict__ gbeta) {
+  __shared__ float red[kBsSlices][kBsCols];
+  const int tc = threadIdx.x % kBsCols, sl = threadIdx.x / kBsCols;
+  const int col = blockIdx.x * kBsCols + tc;
+  const bool on = col < M;
+  const size_t po = on ? bs_param_offset(col, f, sc, sx, sh) : 0;
+  const float ga = on ? gamma[po] : 0.f, be = on ? beta[po] : 0.f, mu = on ? mean[col] : 0.f, rs = on ? rstd[col] : 0.f;
+  auto dh_of = [&](int r, float& xh) {   // d loss / d h of row r (h = the BatchNorm output), and the normalised input
+    xh = (x[(size_t)r * M + col] - mu) * rs;
+    const float h = fmaf(xh, ga, be);
+    const float sg = 1.0f / (1.0f + expf(-h));
+    return gy[(size_t)r * M + col] * (sg * (1.0f + h * (1.0f - sg)));
+  };
+  float sb = 0.f, sg_ = 0.f;
+  if (on)
+    for (int r = sl; r < B; r += kBsSlices) {
+      float xh;
+      const float dh = dh_of(r, xh);
+      sb += dh;
+      sg_ = fmaf(dh, xh, sg_);
+    }
+  const float dbeta = bs_col_sum(sb, red, sl, tc);
+  const float dgamma = bs_col_sum(sg_, red, sl, tc);
+  if (!on) return;
+  const float k = ga * rs, mb = dbeta / (float)B, mg = dgamma / (float)B;
+  for (int r = sl; r < B; r += kBsSlices) {
+    float xh;
+    const float dh = dh_of(r, xh);
+    gx[(size_t)r * M + col] = k * (dh - mb - xh * mg);
+  }
+  if (sl == 0) { ggamma[col] = dgamma; gbeta[col] = dbeta; }
+}
+}  // namespace
+
+extern "C" int gwtf_film_bn_swish_forward(const float* x, const float* gamma, const float* beta, long stride_c, long stride_x,
+                                          long stride_h, int f, int B, int M, float* y, float* mean, float* var, float* rstd,
+                                          void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !var || !rstd || f <= 0 || B <= 0 || M <= 0 || M % (4 * f) != 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(bn_swish_fwd_kernel, dim3((M + kBsCols - 1) / kBsCols), dim3(kBsCols * kBsSlices), 0, (hipStream_t)stream, x,
+                     gamma, beta, stride_c, stride_x, stride_h, f, B, M, y, mean, var, rstd);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_film_bn_swish_backward(const float* x, const float* gy, const float* gamma, const float* beta, long stride_c,
+                                           long stride_x, long stride_h, int f, int B, int M, const float* mean, const float* rstd,
+                                           float* gx, float* ggamma, float* gbeta, void* stream) {
+  if (!x || !gy || !gamma || !beta || !mean || !rstd || !gx || !ggamma || !gbeta || f <= 0 || B <= 0 || M <= 0 || M % (4 * f) != 0)
+    return GWTF_E_BADARG;
+  hipLaunchKernelGGL(bn_swish_bwd_kernel, dim3((M + kBsCols - 1) / kBsCols), dim3(kBsCols * kBsSlices), 0, (hipStream_t)stream, x,
+                     gy, gamma, beta, stride_c, stride_x, stride_h, f, B, M, mean, rstd, gx, ggamma, gbeta);
+  return (int)hipGetLastError();
+}

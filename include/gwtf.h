@@ -68,6 +68,20 @@ int gwtf_pack_weights_k(const float* raw, float* packed_w, float* packed_film,
 int gwtf_film_forward(const float* g, const float* packed_film, float* film_out, float* bn_stats_out,
                       int B, int G, int C, int f, float eps, int training, void* stream);
 
+/* Differentiable train-mode FiLM heads: the BatchNorm over the B latent rows (batch statistics) + swish that sits between a
+ * head's two Linear layers -- T_{mu,logvar}_0_cond_{w,b} = Linear, BatchNorm1d, Swish, Linear (lib/networks/flows.py:33-45,68-80)
+ * in train() -- as one kernel per direction; the two Linear layers stay batched library products (autograd.py _film_train).
+ *   x      [B][M]   first Linear's outputs of all heads, M = (couplings * 2 branches * 2 heads) * f columns
+ *   gamma, beta     BatchNorm weight / bias of head (c, branch x, head h), feature j at base + c*stride_c + x*stride_x + h*stride_h + j
+ *                   (views of the raw arena, include/gwtf.h RAW ARENA)
+ *   forward : y [B][M] = swish(BN(x)), mean / var (biased) / rstd [M]
+ *   backward: gx [B][M], ggamma / gbeta [M] from gy [B][M] */
+int gwtf_film_bn_swish_forward(const float* x, const float* gamma, const float* beta, long stride_c, long stride_x, long stride_h,
+                               int f, int B, int M, float* y, float* mean, float* var, float* rstd, void* stream);
+int gwtf_film_bn_swish_backward(const float* x, const float* gy, const float* gamma, const float* beta, long stride_c, long stride_x,
+                                long stride_h, int f, int B, int M, const float* mean, const float* rstd, float* gx, float* ggamma,
+                                float* gbeta, void* stream);
+
 /* Fused coupling stack: all C elementary couplings applied to every point, with the log-det
  * accumulation.  Replaces LocalCondRNVPDecoder.forward (lib/networks/decoders.py:61-79) ->
  * CondRealNVPFlow3DTriple.forward (flows.py:150-160) -> CondRealNVPFlow3D.forward (flows.py:95-117)
