@@ -167,10 +167,11 @@ int gwtf_coupling_backward_lists(const float* x_in, const float* g_out, const fl
 
 /* Backward records of the train pipeline: W1T sections from the un-scaled sd1 weights (sd0 sections: gwtf_train_fold0). */
 int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, int G, void* stream);
-/* Backward of ONE coupling of the single-rank train pipeline (coupling path + fold1 + statistics path + fold0 + moments
- * path + dW1 reduction; csrc/gwtf_train.hip).  dw1_ws: 2 * gwtf_dw1_workspace_floats(f, B, N) +
- * gwtf_dw1_reduce_scratch_floats(f) floats.  Workspace contract at
- * the definition. */
+/* Backward of ONE coupling of the single-rank train pipeline: light pass (the FiLM-record / bias sums of the coupling path) +
+ * fold1 + merged pass (coupling path and statistics path together: everything after dL/dy is linear in it) + fold0 + moments
+ * path + dW1 reduction; csrc/gwtf_train.hip, csrc/gwtf_bwd.hip BW_LIGHT / BW_MERGED.  dw1_ws: at least
+ * gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f) floats.  g_xb is no longer written (one merged pass
+ * leaves one gradient buffer, g_xa); the argument stays for ABI stability.  Workspace contract at the definition. */
 int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const float* g_ld, const float* raw_c,
                                  const float* packed_w_c, const float* packed_b_c, const float* film_rec,
                                  const float* film_raw, const float* moments_c, const float* ystats_c, float* g_in,
@@ -196,7 +197,7 @@ int gwtf_train_backward(const float* p, const float* ps, const float* g_out, con
  * A rank that owns the whole batch calls gwtf_mtrain_forward / gwtf_mtrain_backward; a sharded run calls
  * gwtf_mtrain_phase level by level and all-reduces (sum) the named slab between the phases:
  *     FWD_INIT -> moments[0] (64*16 floats) | per step: FWD_A -> ystats[c] (K*64*2*FP*2) | FWD_B -> moments[step+1] (K*64*16)
- *     per backward step: BWD_A -> g_stats[c] (K*2*2*FP) | BWD_B -> g_mom[c] (K*48 DOUBLES) | BWD_C
+ *     per backward step: BWD_A (light pass, fold1) -> g_stats[c] (K*2*2*FP) | BWD_B (merged pass, fold0) -> g_mom[c] (K*48 DOUBLES) | BWD_C
  * with c = step (DIRECT) or C-1-step (INVERSE) going forward, and c = step (INVERSE) or C-1-step (DIRECT) going backward.
  * Every buffer is caller-owned; "zero" = must be zero on entry.  FP = gwtf_padded_width(f), R = 64 statistic replicas. */
 #define GWTF_PHASE_FWD_INIT 0
@@ -227,7 +228,7 @@ typedef struct GwtfTrainCtx {
   const float* g_ps;         /* [K][C][B][3][N] or NULL: dL/d ps[c], gradients entering through the per-coupling list slots */
   const float* g_lvs;        /* [K][C][B][3][N] or NULL: dL/d logvars[c] */
   float* g_bufs;             /* [2][K][B][3][N]  dL/dp per component ends in half gwtf_mtrain_final_backward_half(C, mode) */
-  float* g_xa; float* g_xb;  /* [K][B][3][N] scratch */
+  float* g_xa; float* g_xb;  /* [K][B][3][N] scratch (g_xb: unused since the merged backward pass, kept for layout stability) */
   float* dw1_ws;             /* [K][gwtf_mtrain_dw1_floats(f, B, N)] scratch */
   float* g_film;             /* [B][K*C][2][3][FP]   zero */
   float* g_sd0;              /* [C][K][R*2*3*FP]     zero */
