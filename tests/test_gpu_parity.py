@@ -413,6 +413,31 @@ def test_mixture_partitioned_sampling_path(counts):
         off += cnt
 
 
+@pytest.mark.parametrize('B,C,f', [(7, 3, 5), (64, 33, 37), (2, 1, 64)])
+def test_film_head_batchnorm_swish_kernel_matches_torch(B, C, f):
+    """gwtf_film_bn_swish_{forward,backward} (the BatchNorm over the latent rows + swish between a FiLM head's two Linear layers,
+    reference flows.py:33-45 in train()) against the same expression under torch autograd in float64; weight / bias are strided
+    views of a larger record, as in the raw arena."""
+    from go_with_the_flows_amd.autograd import _BNSwishRows
+    gen = torch.Generator().manual_seed(900 + f)
+    x = (torch.randn(B, C, 2, 2, f, generator=gen) * 1.7 + 0.3).to(DEV).requires_grad_(True)
+    rec = torch.randn(C, 2, 2, 4, f + 3, generator=gen).to(DEV).requires_grad_(True)       # heads' records: 4 vectors, padded rows
+    up = torch.randn(B, C, 2, 2, f, generator=gen).to(DEV)
+    hg, hb = rec[:, :, :, 0, :f], rec[:, :, :, 1, :f]
+    y, mean, var = _BNSwishRows.apply(x, hg, hb)
+    (y * up).sum().backward()
+    gx, grec = x.grad.clone(), rec.grad.clone()
+    xd, rd = x.detach().double().requires_grad_(True), rec.detach().double().requires_grad_(True)
+    m, v = xd.mean(0), xd.var(0, unbiased=False)
+    h = (xd - m) / torch.sqrt(v + 1e-5) * rd[:, :, :, 0, :f] + rd[:, :, :, 1, :f]
+    yr = h * torch.sigmoid(h)
+    (yr * up.double()).sum().backward()
+    assert maxabs(host(y), host(yr)) < 2e-5 * max(1.0, float(yr.detach().abs().max()))
+    assert maxabs(host(mean), host(m)) < 1e-5 and maxabs(host(var), host(v)) < 1e-5 * max(1.0, float(v.max()))
+    assert maxabs(host(gx), host(xd.grad)) < 5e-5 * max(1.0, float(xd.grad.abs().max()))
+    assert maxabs(host(grec), host(rd.grad)) < 5e-5 * max(1.0, float(rd.grad.abs().max()))
+
+
 def test_train_backward_light_pass_tile_shapes_agree():
     """The train backward's light pass (FiLM-record sums, csrc/gwtf_bwd.hip BW_LIGHT) takes 256 points per workgroup from B*N*K =
     256 Ki points up and 128 below: K = 2 components in one pipeline pass (large tile) give the gradients of the two K = 1
