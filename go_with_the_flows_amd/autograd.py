@@ -642,7 +642,7 @@ class TrainMixtureFn(torch.autograd.Function):
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
         t.eps, t.n_total = eps, n_total
         scratch = new(K, B, 3, N)
-        bufs = dict(g_bufs=new(2, K, B, 3, N), g_xa=new(K, B, 3, N), g_xb=new(K, B, 3, N),
+        bufs = dict(g_bufs=new(2, K, B, 3, N), g_xa=new(K, B, 3, N),
                     dw1_ws=new(K * L.gwtf_mtrain_dw1_floats(f, B, N)), g_film=zeros(B, K * C, 2, 3, FP),
                     g_sd0=zeros(C, K, R * 2 * 3 * FP), g_bias=zeros(C, K, R * 4), g_stats=new(C, K, 2 * 2 * FP),
                     g_mom=torch.zeros(C, K, 48, device=dev, dtype=torch.float64), g_film_raw=torch.zeros_like(film_raw),
@@ -658,6 +658,7 @@ class TrainMixtureFn(torch.autograd.Function):
         t.g_lvs = g_lvs.data_ptr() if g_lvs is not None else None
         for name, buf in bufs.items():
             setattr(t, name, buf.data_ptr())
+        t.g_xb = t.g_xa                    # not written since the merged backward pass (one gradient buffer per level)
         t.stream = _lib._stream(p)
         with torch.cuda.device(dev):
             if not sharded:
