@@ -20,6 +20,7 @@ _c_fp = ctypes.c_void_p
 _SIGNATURES = {
     'gwtf_abi_version': (ctypes.c_int, []),
     'gwtf_error_string': (ctypes.c_char_p, [ctypes.c_int]),
+    'gwtf_diag_stamp': (ctypes.c_int, [_c_fp, _c_fp]),
     'gwtf_padded_width': (ctypes.c_int, [ctypes.c_int]),
     'gwtf_raw_coupling_floats': (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int]),
     'gwtf_packed_w_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),

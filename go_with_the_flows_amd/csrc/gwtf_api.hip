@@ -17,3 +17,14 @@ extern "C" size_t gwtf_raw_coupling_floats(int f, int G) { return GwtfRaw(f, G).
 extern "C" size_t gwtf_packed_w_coupling_floats(int f) { return GwtfPackW(gwtf_padded_width(f)).coupling_size(); }
 extern "C" size_t gwtf_packed_film_coupling_floats(int f, int G) { return GwtfPackF(gwtf_padded_width(f), G).coupling_size(); }
 extern "C" size_t gwtf_film_out_floats(int f) { return gwtf_film_out_size(gwtf_padded_width(f)); }
+
+// Diagnostic: one wall-clock stamp (100 MHz constant counter) written by a one-thread kernel on `stream` -- placed between the
+// nodes of a captured hipGraph it shows where parallel branches really run (tools/diag/graph_stamps.py).
+namespace {
+__global__ void stamp_kernel(unsigned long long* slot) { *slot = wall_clock64(); }
+}  // namespace
+extern "C" int gwtf_diag_stamp(unsigned long long* slot, void* stream) {
+  if (!slot) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, slot);
+  return (int)hipGetLastError();
+}

@@ -30,6 +30,8 @@ extern "C" {
 int gwtf_abi_version(void);
 /* Human-readable text for a non-zero return value (static storage). */
 const char* gwtf_error_string(int code);
+/* Diagnostic: a one-thread kernel on `stream` writes wall_clock64() (100 MHz) to *slot -- a time stamp inside a captured hipGraph. */
+int gwtf_diag_stamp(unsigned long long* slot, void* stream);
 
 /* Sizes (in floats) of the buffers the caller must provide. FP = f rounded up to 16. */
 int    gwtf_padded_width(int f);
