@@ -702,8 +702,8 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
         g_all = g
     if rows_total < 2:
         raise ValueError('train-mode BatchNorm needs more than 1 shape per (global) batch (torch raises the same)')
-    Ps = [_gather(e) for e in engines]
-    raw = Ps[0]['raw'].unsqueeze(0) if K == 1 else torch.stack([P['raw'] for P in Ps])
+    from .flows import stacked_raw_arena
+    raw = stacked_raw_arena(engines)                          # (K, R): one gather launch, one autograd node
     # the FiLM heads of all K stacks in ONE set of batched products: views of the stacked arena, K*C couplings
     film_a, film_b, film_mean, film_var = _film_train(_gather_film(raw, K * C, f, G), g_all, eps)
     a, bsh = film_a[row0:row0 + B], film_b[row0:row0 + B]                # (B, K*C, 2, f)
@@ -712,9 +712,8 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
         # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
         # the FiLM heads' part, summed by autograd): hand it to the data-parallel reducer the moment it exists, so that its
         # all-reduce overlaps the rest of the backward pass
-        for e, P in zip(engines, Ps):
-            if P['raw'].requires_grad:
-                P['raw'].register_hook(lambda grad, e=e: sink.on_flat_gradient(grad, e))
+        if raw.requires_grad:
+            raw.register_hook(lambda grad: [sink.on_flat_gradient(grad[k], e) for k, e in enumerate(engines)] and None)
     out, logdet, ps, mus, lvs, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
                                                                float(rows_total) * N, distributed, want_lists)
     lists = (ps, mus, lvs) if want_lists else None           # (K,C,B,3,N) each; ps / lvs differentiable

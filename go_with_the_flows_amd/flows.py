@@ -196,6 +196,71 @@ class _ArenaCat(torch.autograd.Function):
         return (None, *grads)
 
 
+class _ArenaCatMulti(torch.autograd.Function):
+    """The raw arenas of K engines of one shape as ONE (K, R) tensor built by ONE pointer-table launch (a mixture's K decoders:
+    instead of K gathers and a torch.stack); backward hands every parameter its slice, like _ArenaCat."""
+
+    @staticmethod
+    def forward(ctx, engines, *tensors):
+        ctx.engines = engines
+        return _gather_stacked(engines)
+
+    @staticmethod
+    def backward(ctx, g_raw):
+        grads = []
+        for k, eng in enumerate(ctx.engines):
+            pieces = g_raw[k].split_with_sizes(eng._sizes)
+            for (t, op), piece in zip(eng._srcs, pieces):
+                if t is not None:
+                    grads.append(piece.view(t.shape) if t.requires_grad else None)
+        return (None, *grads)
+
+
+_STACK_TABLES = {}
+
+
+def _gather_stacked(engines):
+    """(K, R) stacked raw arena from the engines' cached detached views; the combined device table is cached per engine tuple and
+    rebuilt when a source pointer changed (not inside a hipGraph capture: per-engine gathers + torch.stack stand in there)."""
+    for e in engines:
+        e._refresh_flat()
+    flat0 = engines[0]._flat
+    R = sum(engines[0]._sizes)
+    if not flat0[0].is_cuda:
+        return torch.stack([torch.cat(e._flat) for e in engines])
+    key = tuple(id(e) for e in engines)
+    tab = _STACK_TABLES.get(key)
+    flats = [e._flat for e in engines]
+    if tab is None or len(tab[0]) != len(flats) or any(x is not y for x, y in zip(tab[0], flats)):   # a flat list is rebuilt with its tensors
+        rows = []
+        for k, e in enumerate(engines):
+            off = k * R
+            for t, n in zip(e._flat, e._sizes):
+                rows.append((t.data_ptr(), off, n))
+                off += n
+        if tab is not None and tab[1] == rows:
+            tab = _STACK_TABLES[key] = (flats, rows, tab[2])
+        elif torch.cuda.is_current_stream_capturing():
+            return torch.stack([e._cat_detached() for e in engines])
+        else:
+            tab = _STACK_TABLES[key] = (flats, rows, torch.tensor(rows, dtype=torch.int64).to(flat0[0].device))
+    out = torch.empty(len(engines), R, device=flat0[0].device, dtype=torch.float32)
+    with torch.cuda.device(out.device):
+        _lib.check(_lib.lib().gwtf_gather_table(tab[2].data_ptr(), out.data_ptr(), len(tab[1]), _lib._stream(out)))
+    return out
+
+
+def stacked_raw_arena(engines):
+    """(K, R): the raw arenas of K same-shaped engines, differentiable w.r.t. every parameter (one autograd node)."""
+    engines = list(engines)
+    for e in engines:
+        e._refresh_flat()
+    srcs = [t for e in engines for t, _ in e._srcs if t is not None]
+    if torch.is_grad_enabled() and any(t.requires_grad for t in srcs):
+        return _ArenaCatMulti.apply(engines, *srcs)
+    return _gather_stacked(engines)
+
+
 class StackEngine:
     """Host-side driver of the HIP path for a run of consecutive couplings (direct order).
 
@@ -231,6 +296,13 @@ class StackEngine:
         """Parameters + BatchNorm buffers of all couplings as one flat tensor (autograd-aware torch.cat).  The list
         of sources is cached (module traversal costs more than the copy); it is rebuilt when .to()/.cuda()/
         load_state_dict() re-create tensors (stamp change)."""
+        self._refresh_flat()
+        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t, _ in self._srcs):
+            return _ArenaCat.apply(self, *[t for t, _ in self._srcs if t is not None])
+        return self._cat_detached()
+
+    def _refresh_flat(self):
+        """(Re)build the cached source list and its detached flat views."""
         stamp = sum(c._stamp for c in self.couplings)
         if stamp != self._src_stamp:
             self._srcs = [so for c in self.couplings for so in c.raw_sources()]
@@ -247,9 +319,6 @@ class StackEngine:
             self._flat = [z[op] if t is None else t.detach().view(-1) for t, op in self._srcs]
             self._sizes = [op if t is None else t.numel() for t, op in self._srcs]
             self._flat_key = True
-        if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t, _ in self._srcs):
-            return _ArenaCat.apply(self, *[t for t, _ in self._srcs if t is not None])
-        return self._cat_detached()
 
     def _cat_detached(self):
         """The flat arena from the cached detached views: one pointer-table kernel (csrc/gwtf_train.hip) on a HIP device --
