@@ -521,11 +521,26 @@ __global__ void pack_folded_kernel(const float* __restrict__ W1p, const float* _
         _Float16 e[2] = {(_Float16)0.f, (_Float16)0.f};
         if (ks < KS && jo < f) {
           const GwtfA16Slot sl = gwtf_a16_slot(f, KS, ks, part, jp);
+          const bool absf = gwtf_abs_form(f);        // gwtf_layout.h: halved entries, columns in the merged image's last slot pair
+          const float* Wrow = W1p + (((size_t)c * 2 + br) * f + jo) * f;
           for (int t = 0; t < 2; ++t) {
             const int ji = 32 * ks + 4 * (2 * sl.jsrc + t) + (lane >> 4);
-            const float w = (ji < f && !sl.zero) ? W1p[(((size_t)c * 2 + br) * f + jo) * f + ji] : 0.f;
+            const float w = (ji < f && !sl.zero) ? (absf ? 0.5f : 1.0f) * Wrow[ji] : 0.f;
             const _Float16 hi = (_Float16)w;
             e[t] = sl.lo ? (_Float16)(w - (float)hi) : hi;
+          }
+          if (absf && sl.zero) {
+            double Ca = 0.0, Cb = 0.0, Cc = 0.0;
+            for (int k = 0; k < f; ++k) {
+              const double w = Wrow[k];
+              Ca += w * (double)W0f[(((size_t)c * 2 + br) * f + k) * 2 + 0];
+              Cb += w * (double)W0f[(((size_t)c * 2 + br) * f + k) * 2 + 1];
+              Cc += w * (double)c0f[((size_t)c * 2 + br) * f + k];
+            }
+            float e0, e1;
+            gwtf_abs_cols(lane >> 4, (float)(0.5 * Ca), (float)(0.5 * Cb), (float)(0.5 * Cc), &e0, &e1);
+            e[0] = (_Float16)e0;
+            e[1] = (_Float16)e1;
           }
         }
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));

@@ -50,6 +50,29 @@ __device__ __forceinline__ void split_pair(f32x2 h, f16x2& hi, f16x2& lo) {
   lo = __builtin_convertvector(r, f16x2);
 }
 
+// split of |h| (abs form, gwtf_layout.h): the absolute value rides on the source modifiers of all three instructions
+__device__ __forceinline__ void split_pair_abs(f32x2 h, f16x2& hi, f16x2& lo) {
+  unsigned hib;
+  asm("v_cvt_pk_f16_f32 %0, |%1|, |%2|" : "=v"(hib) : "v"(h[0]), "v"(h[1]));
+  hi = __builtin_bit_cast(f16x2, hib);
+  float r0, r1;
+  asm("v_fma_mix_f32 %0, %1, -1.0, |%2| op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hib), "v"(h[0]));
+  asm("v_fma_mix_f32 %0, %1, -1.0, |%2| op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hib), "v"(h[1]));
+  const f32x2 r = {r0, r1};
+  lo = __builtin_convertvector(r, f16x2);
+}
+
+// The abs form's B entries for the column slot pair (k positions 6, 7 of the merged k-step) of this lane's quarter q:
+// q0 (xa_hi, xa_lo) | q1 (xa_hi, xb_hi) | q2 (xb_lo, xb_hi) | q3 (1, 1)   -- two f16 in one register
+__device__ __forceinline__ unsigned abs_form_x_slots(float xa, float xb, int q) {
+  const f32x2 xx = {xa, xb};
+  f16x2 xh, xl;
+  split_pair(xx, xh, xl);
+  const unsigned sel = q == 0 ? 0x01000504u : (q == 1 ? 0x07060504u : 0x07060302u);
+  const unsigned v = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, xh), __builtin_bit_cast(unsigned, xl), sel);
+  return q == 3 ? 0x3C003C00u : v;
+}
+
 // Sum over the 16 lanes of a DPP row (= one quarter of the wavefront = the 16 points of a column group); every lane ends
 // with the total.  Four v_add_f32 with DPP operand modifiers -- no LDS traffic (a __shfl_xor goes through ds_bpermute).
 // MEASURED AND REJECTED (round 2): a transpose-reduce of twelve values at a time (bank-masked v_add_f32_dpp for the mirror
@@ -103,19 +126,19 @@ __device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br
         // a last k-step with at most 2 valid k-slots per lane (f = 33..40): its three products in ONE MFMA, the lane's 8
         // k-slots holding B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0] (the hi image of
         // this k-step as gwtf_pack.hip writes it for these widths)
+        // ABS FORM (gwtf_layout.h): B holds |pre|, the last slot pair the split kept coordinates against the packed columns
         const f32x4* sp = reinterpret_cast<const f32x4*>(sd0 + ks * 96);
         const f32x2 wa2 = {sp[0][0], sp[0][1]}, wb2 = {KEEP2 ? sp[2][0] : 0.f, KEEP2 ? sp[2][1] : 0.f}, cc2 = {sp[4][0], sp[4][1]};
         f16x8 bm[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
-          f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
-                            : __builtin_elementwise_fma(wa2, xa2, cc2);
-          pre[0] = fmaxf(pre[0], 0.f);
-          pre[1] = fmaxf(pre[1], 0.f);
+          const f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
+                                  : __builtin_elementwise_fma(wa2, xa2, cc2);
           f16x2 hi, lo;
-          split_pair(pre, hi, lo);
-          bm[nb] = f16x8{hi[0], hi[1], lo[0], lo[1], hi[0], hi[1], (_Float16)0.f, (_Float16)0.f};
+          split_pair_abs(pre, hi, lo);
+          const f16x2 xs = __builtin_bit_cast(f16x2, abs_form_x_slots(xa[nb], KEEP2 ? xb[nb] : 0.f, q));
+          bm[nb] = f16x8{hi[0], hi[1], lo[0], lo[1], hi[0], hi[1], xs[0], xs[1]};
         }
 #pragma unroll
         for (int m = 0; m < MB; ++m) {
@@ -144,10 +167,14 @@ __device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br
             const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
             f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
                               : __builtin_elementwise_fma(wa2, xa2, cc2);
-            pre[0] = fmaxf(pre[0], 0.f);
-            pre[1] = fmaxf(pre[1], 0.f);
             f16x2 hi, lo;
-            split_pair(pre, hi, lo);
+            if (KS == 2 && nj_last <= 2) {       // abs form (wave-uniform): |pre| here, the linear half in the merged k-step
+              split_pair_abs(pre, hi, lo);
+            } else {
+              pre[0] = fmaxf(pre[0], 0.f);
+              pre[1] = fmaxf(pre[1], 0.f);
+              split_pair(pre, hi, lo);
+            }
             bhi[nb][2 * jp] = hi[0]; bhi[nb][2 * jp + 1] = hi[1];
             blo[nb][2 * jp] = lo[0]; blo[nb][2 * jp + 1] = lo[1];
           }

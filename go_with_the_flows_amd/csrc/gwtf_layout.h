@@ -63,7 +63,25 @@ struct GwtfRaw {  // offsets inside one branch record
 // Exception (f = 33..40: the second k-step has at most two valid k positions per lane): that k-step is contracted by ONE
 // MFMA against B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0], and its hi image holds A' = [W_hi (2) | W_hi (2) | W_lo (2) | 0 0]
 // -- slot pair 0 as above, pairs 1-2 in place of the zeros that pad a short k-step; the lo image is unchanged.
+// ABS FORM of these widths (f = 33..40, every packer, every consumer).  relu(x) = (x + |x|)/2 and the pre-activation is linear in
+// the kept coordinates, pre_k = wa_k xa + wb_k xb + c0_k, so
+//     W relu(pre) = 1/2 W |pre|  +  xa (1/2 W wa) + xb (1/2 W wb) + (1/2 W c0):
+// the B operand carries |pre| (the absolute value is a source modifier of v_cvt_pk_f16_f32 / v_fma_mix_f32: no v_max), every A entry
+// is stored HALVED, and the three columns Ca = 1/2 W wa, Cb = 1/2 W wb, Cc = 1/2 W c0 with their split-f16 products take the LAST
+// slot pair (k positions 6, 7) of the merged image, which the eight k positions of the four quarters q = lane >> 4 fill exactly:
+//     q = 0: A = (Ca_hi, Ca_hi)  against  B = (xa_hi, xa_lo)        q = 2: A = (Cb_hi, Cb_lo)  against  B = (xb_lo, xb_hi)
+//     q = 1: A = (Ca_lo, Cb_hi)  against  B = (xa_hi, xb_hi)        q = 3: A = (Cc_hi, Cc_lo)  against  B = (1, 1)
+// No extra MFMA; 80 v_max per coupling and wavefront become ~40 VALU that split and place xa / xb.
 // The record is padded to a whole number of 1-KiB LDS-DMA pieces.
+GWTF_HD bool gwtf_abs_form(int f) { return f >= 33 && f <= 40; }
+// the two fp32 values (each exactly representable in f16 after rounding to nearest) of quarter q's column slot pair
+GWTF_HD void gwtf_abs_cols(int q, float Ca, float Cb, float Cc, float* e0, float* e1) {
+  const float ah = (float)(_Float16)Ca, bh = (float)(_Float16)Cb, ch = (float)(_Float16)Cc;
+  if (q == 0) { *e0 = ah; *e1 = ah; }
+  else if (q == 1) { *e0 = Ca - ah; *e1 = bh; }
+  else if (q == 2) { *e0 = bh; *e1 = Cb - bh; }
+  else { *e0 = ch; *e1 = Cc - ch; }
+}
 struct GwtfA16Slot { int jsrc; bool lo, zero; };
 // float slot jp (= k positions 2jp, 2jp+1) of image `part` of k-step ks: which pair of k positions, and which f16 part, it holds
 GWTF_HD GwtfA16Slot gwtf_a16_slot(int f, int KS, int ks, int part, int jp) {
@@ -71,7 +89,7 @@ GWTF_HD GwtfA16Slot gwtf_a16_slot(int f, int KS, int ks, int part, int jp) {
   GwtfA16Slot s;
   s.jsrc = merged ? 0 : jp;
   s.lo = merged ? jp == 2 : part == 1;
-  s.zero = merged && jp == 3;
+  s.zero = merged && jp == 3;          // abs form: the column slot pair (gwtf_abs_cols), written separately
   return s;
 }
 struct GwtfPackW {

@@ -18,6 +18,22 @@ __device__ __forceinline__ int floor_log2(float x) {   // x > 0, finite
   return e - 1;
 }
 
+// un-halved abs-form columns of output row jo (gwtf_layout.h): sum_k W1'[jo][k] {wa_k, wb_k, c0_k}, W1' = sd1.weight * sc (the range
+// exponents CS cancel between the image and the sd0 record), the folded sd0 as the sd0 section stores it
+__device__ inline void abs_columns(const float* rb, const GwtfRaw& R, int f, int jo, int kept, float sc, double* Ca, double* Cb,
+                                   double* Cc) {
+  const float* bn = rb + R.bn0();
+  double a = 0.0, b = 0.0, c = 0.0;
+  for (int k = 0; k < f; ++k) {
+    const float s = bn[k] * inv_std(bn[3 * f + k]);
+    const double w = (double)(rb[R.sd1_w() + (size_t)jo * f + k] * sc);
+    a += w * (double)(rb[R.sd0_w(k, 0, kept)] * s);
+    if (kept > 1) b += w * (double)(rb[R.sd0_w(k, 1, kept)] * s);
+    c += w * (double)(bn[f + k] - bn[2 * f + k] * s);
+  }
+  *Ca = a; *Cb = b; *Cc = c;
+}
+
 // Range scaling exponents + poison of every (coupling, branch) -> packed_film's RS / CS / POISON slots (gwtf_layout.h).
 // One workgroup per branch record; runs before the two gather kernels below, which read the exponents.
 __global__ __launch_bounds__(256) void pack_scales_kernel(const float* __restrict__ raw, float* __restrict__ pf, int C, int f,
@@ -53,6 +69,11 @@ __global__ __launch_bounds__(256) void pack_scales_kernel(const float* __restric
       const float sc = inv_std(rb[R.bn1() + f + t]);
       float m = 0.f;
       for (int j = 0; j < f; ++j) m = fmaxf(m, fabsf(ldexpf(rb[R.sd1_w() + (size_t)t * f + j] * sc, s_cs[j])));
+      if (gwtf_abs_form(f)) {     // the row also holds the three abs-form columns (gwtf_layout.h): they share its scale
+        double Ca, Cb, Cc;
+        abs_columns(rb, R, f, t, gwtf_pattern_kept((pattern0 + c % Cper) % 6), sc, &Ca, &Cb, &Cc);
+        m = fmaxf(m, fmaxf(fabsf((float)Ca), fmaxf(fabsf((float)Cb), fabsf((float)Cc))));
+      }
       if (m > 0.f && !nonfinite(m)) rs = min(50, max(-50, floor_log2(m) - 12));
     }
     w[P.rs() + t] = (float)rs;
@@ -93,13 +114,19 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, const float* __rest
         const int rs = (int)ex[PF.rs() + jo];
         const float sc = training ? 1.0f : inv_std(rb[R.bn1() + f + jo]);   // train: sd1_bn is applied via fold1
         const GwtfA16Slot sl = gwtf_a16_slot(f, KS, ks, part, jp);   // f = 33..40: merged image of the short k-step
+        const bool absf = gwtf_abs_form(f);                          // ... in abs form: every entry halved, columns in the last pair
         float e[2];
         for (int t = 0; t < 2; ++t) {
           const int ji = 32 * ks + 4 * (2 * sl.jsrc + t) + (lane >> 4);  // input feature
           float w = 0.f;
-          if (ji < f && !sl.zero) w = ldexpf(rb[R.sd1_w() + (size_t)jo * f + ji] * sc, (int)ex[PF.cs() + ji] - rs);
+          if (ji < f && !sl.zero) w = ldexpf(rb[R.sd1_w() + (size_t)jo * f + ji] * sc, (int)ex[PF.cs() + ji] - rs - (absf ? 1 : 0));
           const float hi = __half2float(__float2half_rn(w));
           e[t] = sl.lo ? (w - hi) : hi;
+        }
+        if (absf && sl.zero && !training) {    // train packing: gwtf_train_fold0 writes the columns per level (batch statistics)
+          double Ca, Cb, Cc;
+          abs_columns(rb, R, f, jo, gwtf_pattern_kept((pattern0 + c % Cper) % 6), sc, &Ca, &Cb, &Cc);
+          gwtf_abs_cols(lane >> 4, (float)ldexp(Ca, -rs - 1), (float)ldexp(Cb, -rs - 1), (float)ldexp(Cc, -rs - 1), &e[0], &e[1]);
         }
         pk = __floats2half2_rn(e[0], e[1]);
       }

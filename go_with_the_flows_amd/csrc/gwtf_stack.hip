@@ -162,6 +162,14 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
         for (int e = MERGE ? 6 : 2 * PAIRS_LAST; e < 8; ++e) bhi[br][KS - 1][nb][e] = blo[br][KS - 1][nb][e] = (_Float16)0.f;
   }
 
+  if (MERGE) {   // abs form: the column slot pair of the merged k-step carries the split kept coordinates (same for both branches)
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      const f16x2 xs = __builtin_bit_cast(f16x2, abs_form_x_slots(xa[nb], xb[nb], q));
+      bhi[0][KS - 1][nb][6] = xs[0]; bhi[0][KS - 1][nb][7] = xs[1];
+      bhi[1][KS - 1][nb][6] = xs[0]; bhi[1][KS - 1][nb][7] = xs[1];
+    }
+  }
   auto unit = [&](int br, int u) {        // u-th (pair, point block) item of branch br
     const int per_ks = 4 * NB;
     const int ks = u / per_ks < KS - 1 ? u / per_ks : KS - 1;
@@ -184,10 +192,14 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     }
     f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
                       : __builtin_elementwise_fma(wa2, xa2, cc2);
-    pre[0] = fmaxf(pre[0], 0.f);
-    pre[1] = fmaxf(pre[1], 0.f);
     f16x2 hi, lo;
-    split_pair(pre, hi, lo);
+    if (MERGE) {                           // abs form (gwtf_layout.h): |pre| on the source modifiers, no v_max
+      split_pair_abs(pre, hi, lo);
+    } else {
+      pre[0] = fmaxf(pre[0], 0.f);
+      pre[1] = fmaxf(pre[1], 0.f);
+      split_pair(pre, hi, lo);
+    }
     if (PACK5) {
       f16x8& b1 = bhi[br][0][nb];
       f16x8& b2 = blo[br][0][nb];

@@ -61,11 +61,13 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
     mom[t] = sacc;
   }
   __syncthreads();
-  if (t >= 2 * f) return;
-  const int br = t / f, j = t % f;
+  __shared__ float s_sd0[2][3][GWTF_MAX_FP];     // folded sd0 of both branches: the abs-form columns below need every feature's
+  const bool on = t < 2 * f;
+  const int br = on ? t / f : 0, j = on ? t % f : 0;
   const GwtfRaw R(f, G);
   const GwtfPackW P(FP);
   const float* rb = raw_c + (size_t)br * R.branch_size();
+  if (on) {
   int k0, k1, w0, w1;
   gwtf_pattern_dims(pat, &k0, &k1, &w0, &w1);
   // moments in double: Cov = E[xx] - E[x]E[x] cancels
@@ -94,6 +96,35 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
   float* bb = bn_batch + ((size_t)br * 4 + 0) * 2 * f;
   bb[j] = (float)mean;
   bb[f + j] = (float)(var * (n_total / (n_total > 1.0 ? n_total - 1.0 : 1.0)));
+  s_sd0[br][0][j] = sd0[0]; s_sd0[br][1][j] = sd0[8]; s_sd0[br][2][j] = sd0[16];
+  }
+  if (!gwtf_abs_form(f)) return;
+  // ABS FORM (gwtf_layout.h): this level's columns 1/2 W1 {wa, wb, c0} into the last slot pair of the merged k-step's image (the
+  // train packer left it empty and stored the sd1 weights halved); thread = (branch, output row)
+  __syncthreads();
+  if (!on) return;
+  const int jo = j, MB = FP / 16;
+  double Ca = 0.0, Cb = 0.0, Cc = 0.0;
+  {
+    const float* wr = rb + R.sd1_w() + (size_t)jo * f;
+    double a2 = 0.0, b2 = 0.0, c2 = 0.0;                   // two independent chains per sum
+    int k = 0;
+    for (; k + 1 < f; k += 2) {
+      const double w0_ = wr[k], w1_ = wr[k + 1];
+      Ca += w0_ * (double)s_sd0[br][0][k]; a2 += w1_ * (double)s_sd0[br][0][k + 1];
+      Cb += w0_ * (double)s_sd0[br][1][k]; b2 += w1_ * (double)s_sd0[br][1][k + 1];
+      Cc += w0_ * (double)s_sd0[br][2][k]; c2 += w1_ * (double)s_sd0[br][2][k + 1];
+    }
+    if (k < f) { const double w0_ = wr[k]; Ca += w0_ * (double)s_sd0[br][0][k]; Cb += w0_ * (double)s_sd0[br][1][k]; Cc += w0_ * (double)s_sd0[br][2][k]; }
+    Ca += a2; Cb += b2; Cc += c2;
+  }
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  for (int q = 0; q < 4; ++q) {
+    float e0, e1;
+    gwtf_abs_cols(q, (float)(0.5 * Ca), (float)(0.5 * Cb), (float)(0.5 * Cc), &e0, &e1);
+    const h2 pk = {(_Float16)e0, (_Float16)e1};
+    pw_c[P.a16(br) + ((size_t)(1 * MB + jo / 16) * 2 + 0) * 256 + (size_t)(q * 16 + jo % 16) * 4 + 3] = __builtin_bit_cast(float, pk);
+  }
 }
 
 // grid = B workgroups, thread = (branch, feature).  Workgroup 0 also emits the running-stat update of sd1_bn.
