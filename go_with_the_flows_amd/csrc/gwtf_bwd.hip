@@ -53,7 +53,7 @@ struct BCfg {
 //              linear in dy): per level one full pass and one forward-sized pass instead of two full ones, and one set of dW1 partials.
 // waves per SIMD the register allocation is held to: the LDS footprint admits three workgroups per CU up to FP = 48
 enum { BW_DIRECT = 0, BW_STATS = 1, BW_LIGHT = 2, BW_MERGED = 3 };
-template <int MB, int NB, int VAR>
+template <int MB, int NB, int VAR, int MG = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2 : (MB <= 3 ? 3 : 1)))) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
     f32x4 cinit[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) cinit[m] = STATS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(fe + 16 * m);
-    if (keep2) sd1_contract<MB, NB, true>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
-    else sd1_contract<MB, NB, false>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
+    if (keep2) sd1_contract<MB, NB, true, MG>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
+    else sd1_contract<MB, NB, false, MG>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
     if (STATS) continue;
     float o0[NB], o1[NB];
 #pragma unroll
@@ -579,6 +579,20 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
                const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
+  if constexpr (MB == 3 && (VAR == BW_LIGHT || VAR == BW_MERGED)) {
+    // the train pipeline's two passes at the abs-form widths (f = 33..40): the forward recompute as one basic block (MG = 1)
+    if (gwtf_abs_form(f)) {
+      if (VAR == BW_LIGHT && nb == 2 && (long)B * N * K >= 256L * 1024 && getenv("GWTF_LIGHT_SMALL_TILE") == nullptr) {
+        const dim3 grid4((unsigned)(B * ((N + 255) / 256)), (unsigned)K);
+        hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+      } else if (nb == 1) {
+        hipLaunchKernelGGL((bwd_kernel<MB, 1, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+      } else {
+        hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+      }
+      return (int)hipGetLastError();
+    }
+  }
   if constexpr (VAR == BW_LIGHT && MB <= 3) {   // forward-sized pass: the forward kernel's tile (256 points per workgroup) where it fills the GPU
     static const bool small_tile = getenv("GWTF_LIGHT_SMALL_TILE") != nullptr;      // diagnostic hook (tools/diag/light_tile_check.py)
     if (nb == 2 && (long)B * N * K >= 256L * 1024 && !small_tile) {

@@ -111,18 +111,22 @@ __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
 
 // sd0 (+ folded sd0_bn) + ReLU + f16 split in the lane that owns each MFMA k-slot, then the f x f contraction
 // acc[m][nb] = cinit[m] + W1'[16m.., :] . h0[:, points of block nb] on v_mfma_f32_16x16x32_f16 (3 products).
-template <int MB, int NB, bool KEEP2>
+// MG: 1 = the caller knows at compile time that the last k-step is the merged abs-form one (f = 33..40: the whole contraction is
+// then one basic block), 0 = that it is not, -1 = decided at run time from kk_steps (wave-uniform branches).
+template <int MB, int NB, bool KEEP2, int MG = -1>
 __device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br, int kk_steps, int lane, int q,
                                              const float (&xa)[NB], const float (&xb)[NB], const f32x4 (&cinit)[MB],
                                              f32x4 (&acc)[MB][NB]) {
   using K = Cfg<MB>;
   constexpr int KS = K::KS;
-  const int nj_last = kk_steps - 8 * (KS - 1);   // valid k positions per lane in the last k-step (1..8)
+  static_assert(MG != 1 || KS == 2, "the merged k-step exists only with two k-steps");
+  const int nj_last = MG == 1 ? 2 : kk_steps - 8 * (KS - 1);   // valid k positions per lane in the last k-step (1..8; merged: 1..2, unused)
+  const bool merged = MG < 0 ? (KS == 2 && nj_last <= 2) : MG == 1;
     const float* aimg = L + br * K::A16 + lane * 4;
     const float* sd0 = L + 2 * K::A16 + br * K::SD0 + q * 24;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      if (KS == 2 && ks == 1 && nj_last <= 2) {
+      if (KS == 2 && ks == 1 && merged) {
         // a last k-step with at most 2 valid k-slots per lane (f = 33..40): its three products in ONE MFMA, the lane's 8
         // k-slots holding B' = [h_hi (2) | h_lo (2) | h_hi (2) | 0 0] against A' = [W_hi | W_hi | W_lo | 0 0] (the hi image of
         // this k-step as gwtf_pack.hip writes it for these widths)
@@ -168,7 +172,7 @@ __device__ __forceinline__ void sd1_contract(const float* __restrict__ L, int br
             f32x2 pre = KEEP2 ? __builtin_elementwise_fma(wa2, xa2, __builtin_elementwise_fma(wb2, xb2, cc2))
                               : __builtin_elementwise_fma(wa2, xa2, cc2);
             f16x2 hi, lo;
-            if (KS == 2 && nj_last <= 2) {       // abs form (wave-uniform): |pre| here, the linear half in the merged k-step
+            if (merged) {                        // abs form (wave-uniform): |pre| here, the linear half in the merged k-step
               split_pair_abs(pre, hi, lo);
             } else {
               pre[0] = fmaxf(pre[0], 0.f);

@@ -363,7 +363,7 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
 // Same tile decomposition and contraction as the forward kernel; the accumulators are reduced over the wave's
 // points (in-lane over the NB blocks, shuffles over the 16 lanes of a quarter) and added to ystats with one
 // atomic per feature and workgroup.   ystats: [GWTF_STAT_REPLICAS][2 branches][FP][2] = {sum y, sum y^2}
-template <int MB, int NB>
+template <int MB, int NB, int MG = -1>
 __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p, const float* __restrict__ pw_c,
                                                     float* __restrict__ ystats, int B, int N, int pat, int kk_steps,
                                                     size_t p_sk, size_t pw_sk, size_t ys_sk) {
@@ -406,8 +406,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
     f32x4 acc[MB][NB], cinit[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) cinit[m] = zero4;
-    if (pat < 3) sd1_contract<MB, NB, true>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
-    else sd1_contract<MB, NB, false>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
+    if (pat < 3) sd1_contract<MB, NB, true, MG>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
+    else sd1_contract<MB, NB, false, MG>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -810,6 +810,16 @@ int launch_stats(int nb, const float* p, const float* pw_c, float* ystats, int B
                  size_t p_sk, size_t pw_sk, size_t ys_sk, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
+  if constexpr (MB == 3) {          // abs-form widths (f = 33..40): the contraction as one basic block
+    if (kk_steps - 8 <= 2) {
+      switch (nb) {
+        case 1: hipLaunchKernelGGL((stats_kernel<MB, 1, 1>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;
+        case 2: hipLaunchKernelGGL((stats_kernel<MB, 2, 1>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;
+        default: hipLaunchKernelGGL((stats_kernel<MB, 4, 1>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;
+      }
+      return (int)hipGetLastError();
+    }
+  }
   switch (nb) {
     case 1: hipLaunchKernelGGL((stats_kernel<MB, 1>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;
     case 2: hipLaunchKernelGGL((stats_kernel<MB, 2>), grid, block, 0, st, p, pw_c, ystats, B, N, pat, kk_steps, p_sk, pw_sk, ys_sk); break;

@@ -100,24 +100,31 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
   }
   if (!gwtf_abs_form(f)) return;
   // ABS FORM (gwtf_layout.h): this level's columns 1/2 W1 {wa, wb, c0} into the last slot pair of the merged k-step's image (the
-  // train packer left it empty and stored the sd1 weights halved); thread = (branch, output row)
+  // train packer left it empty and stored the sd1 weights halved).  Thread = (k third, branch, output row): 3 x 2 f <= 240 threads
+  // share a row's three sums (the kernel is one block on the level's dependency chain: latency is what counts).
+  __shared__ double s_col[3][2][3][48];
+  __syncthreads();
+  {
+    const int part = t / (2 * f), tt = t % (2 * f), pbr = tt / f, pjo = tt % f;
+    if (part < 3) {
+      const float* wr = raw_c + (size_t)pbr * R.branch_size() + R.sd1_w() + (size_t)pjo * f;
+      const int k0_ = part * ((f + 2) / 3), k1_ = min(f, k0_ + (f + 2) / 3);
+      double a = 0.0, b = 0.0, c = 0.0;
+      for (int k = k0_; k < k1_; ++k) {
+        const double w = wr[k];
+        a += w * (double)s_sd0[pbr][0][k];
+        b += w * (double)s_sd0[pbr][1][k];
+        c += w * (double)s_sd0[pbr][2][k];
+      }
+      s_col[part][pbr][0][pjo] = a; s_col[part][pbr][1][pjo] = b; s_col[part][pbr][2][pjo] = c;
+    }
+  }
   __syncthreads();
   if (!on) return;
   const int jo = j, MB = FP / 16;
-  double Ca = 0.0, Cb = 0.0, Cc = 0.0;
-  {
-    const float* wr = rb + R.sd1_w() + (size_t)jo * f;
-    double a2 = 0.0, b2 = 0.0, c2 = 0.0;                   // two independent chains per sum
-    int k = 0;
-    for (; k + 1 < f; k += 2) {
-      const double w0_ = wr[k], w1_ = wr[k + 1];
-      Ca += w0_ * (double)s_sd0[br][0][k]; a2 += w1_ * (double)s_sd0[br][0][k + 1];
-      Cb += w0_ * (double)s_sd0[br][1][k]; b2 += w1_ * (double)s_sd0[br][1][k + 1];
-      Cc += w0_ * (double)s_sd0[br][2][k]; c2 += w1_ * (double)s_sd0[br][2][k + 1];
-    }
-    if (k < f) { const double w0_ = wr[k]; Ca += w0_ * (double)s_sd0[br][0][k]; Cb += w0_ * (double)s_sd0[br][1][k]; Cc += w0_ * (double)s_sd0[br][2][k]; }
-    Ca += a2; Cb += b2; Cc += c2;
-  }
+  const double Ca = s_col[0][br][0][jo] + s_col[1][br][0][jo] + s_col[2][br][0][jo];
+  const double Cb = s_col[0][br][1][jo] + s_col[1][br][1][jo] + s_col[2][br][1][jo];
+  const double Cc = s_col[0][br][2][jo] + s_col[1][br][2][jo] + s_col[2][br][2][jo];
   typedef _Float16 h2 __attribute__((ext_vector_type(2)));
   for (int q = 0; q < 4; ++q) {
     float e0, e1;
