@@ -713,6 +713,36 @@ def test_train_mode_gradients_vs_torch_cpu_autograd(cfg):
             assert maxabs(host(sd[k]), v.detach().numpy()) < 1e-4, k
 
 
+def test_train_mode_gradients_at_full_tile_sizes_f37_vs_torch_cpu_autograd():
+    """The same comparison at the sizes the training step runs at -- 128 x 2048 points, f = 37: the statistics pass and the light
+    backward pass on their 256-point tiles, the merged pass on its 128-point tile, the abs-form contraction with its compile-time
+    merged flag (csrc/gwtf_device.h sd1_contract MG = 1) -- against CPU autograd of the oracle.  Loss weights are positive (a few of
+    the 2.9e7 ReLU pre-activations sit within rounding of their kink and differ between ANY two evaluations, DESIGN.md 4.11: with
+    random-sign weights the sums cancel and one flipped point shows at 1e-3 of a tensor's gradient)."""
+    from oracle import torch_port as tp
+    L, f, G, B, N = 1, 37, 16, 128, 2048
+    m, st = decoder_and_state(L, f, G, 458)
+    m = m.to(DEV).train()
+    p, g = synth_inputs(B, N, G, 459)
+    rng = np.random.default_rng(460)
+    wz, wl = np.abs(rng.normal(size=(B, 3, N))).astype(np.float32), np.abs(rng.normal(size=(B, 3, N))).astype(np.float32)
+    tst = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and not k.endswith(('running_mean', 'running_var', 'eps')))
+           for k, v in st.items()}
+    pc, gc = torch.from_numpy(p).requires_grad_(True), torch.from_numpy(g).requires_grad_(True)
+    zc, ldc = tp.decoder_fused(pc, gc, tst, L, 'inverse', grad=True, training=True)
+    ((zc * torch.from_numpy(wz)).sum() + (ldc * torch.from_numpy(wl)).sum()).backward()
+    pt, gt = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+    z, ld = m.forward_fused(pt, gt, 'inverse')
+    ((z * dev(wz)).sum() + (ld * dev(wl)).sum()).backward()
+    assert maxabs(host(z), zc.detach().numpy()) < 1e-4 and maxabs(host(ld), ldc.detach().numpy()) < 1e-4
+    # clouds: all but a handful of points (a flipped ReLU changes its own point's gradient by O(1))
+    per_point = np.abs(host(pt.grad) - pc.grad.numpy()).max(axis=1) / np.abs(pc.grad.numpy()).mean()
+    assert int((per_point > 1e-3).sum()) <= 32, int((per_point > 1e-3).sum())
+    assert _rel(host(gt.grad), gc.grad.numpy()) < 2e-3
+    rels = sorted((_rel(host(prm.grad), tst[k].grad.numpy()), k) for k, prm in m.named_parameters())
+    assert rels[len(rels) // 2][0] < 2e-4 and rels[-1][0] < 5e-3, (rels[len(rels) // 2], rels[-1])
+
+
 def test_three_sgd_steps_match_cpu_training():
     """End-to-end training semantics: forward (train-mode BN) -> NLL-like loss -> backward -> SGD, three steps, against
     the same loop run through the PyTorch-CPU port; parameters and running statistics must track each other."""
