@@ -713,14 +713,15 @@ def test_train_mode_gradients_vs_torch_cpu_autograd(cfg):
             assert maxabs(host(sd[k]), v.detach().numpy()) < 1e-4, k
 
 
-def test_train_mode_gradients_at_full_tile_sizes_f37_vs_torch_cpu_autograd():
+@pytest.mark.parametrize('B', [16, 128])
+def test_train_mode_gradients_at_full_tile_sizes_f37_vs_torch_cpu_autograd(B):
     """The same comparison at the sizes the training step runs at -- 128 x 2048 points, f = 37: the statistics pass and the light
     backward pass on their 256-point tiles, the merged pass on its 128-point tile, the abs-form contraction with its compile-time
     merged flag (csrc/gwtf_device.h sd1_contract MG = 1) -- against CPU autograd of the oracle.  Loss weights are positive (a few of
     the 2.9e7 ReLU pre-activations sit within rounding of their kink and differ between ANY two evaluations, DESIGN.md 4.11: with
     random-sign weights the sums cancel and one flipped point shows at 1e-3 of a tensor's gradient)."""
     from oracle import torch_port as tp
-    L, f, G, B, N = 1, 37, 16, 128, 2048
+    L, f, G, N = 1, 37, 16, 2048          # B = 16: the 64-point tiles (512 workgroups: still two per compute unit); 128: the large ones
     m, st = decoder_and_state(L, f, G, 458)
     m = m.to(DEV).train()
     p, g = synth_inputs(B, N, G, 459)
@@ -1019,6 +1020,19 @@ def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B,
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
         else:
             assert torch.equal(a, b)
+    if B * N >= 32 * 2048:
+        # every tile shape at a grid that puts two workgroups on a compute unit (the inline-asm splits have shown a hazard that
+        # only such grids expose): 16 / 32 / 64 points per wave forced, pipelined against the generic reference above
+        ref = outs[1]
+        try:
+            for ppw in (16, 32, 64):
+                _lib.lib().gwtf_debug_set_points_per_wave(ppw)
+                with torch.no_grad():
+                    z, ld = m.forward_fused(pd, gd, mode)
+                for a, b in ((z, ref[0]), (ld, ref[1])):
+                    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), ppw
+        finally:
+            _lib.lib().gwtf_debug_set_points_per_wave(0)
 
 
 @pytest.mark.parametrize('training', [False, True])
