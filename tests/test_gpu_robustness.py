@@ -119,8 +119,8 @@ def test_adversarial_ranges_gradients():
     record_parity('gpu:adversarial_gradients:f37', worst_rel=worst)
 
 
-def _small():
-    L, f, G, B, N = 2, 19, 16, 3, 130
+def _small(f=19):
+    L, G, B, N = 2, 16, 3, 130
     m, st = decoder_and_state(L, f, G, 4400)
     p, g = synth_inputs(B, N, G, 4401)
     return L, f, G, B, N, m, st, p, g
@@ -128,8 +128,9 @@ def _small():
 
 @pytest.mark.parametrize('mode', ['direct', 'inverse'])
 @pytest.mark.parametrize('bad', [np.nan, np.inf, -np.inf, 1e5])
-def test_nonfinite_or_out_of_range_points_reach_out_and_logdet(mode, bad):
-    L, f, G, B, N, m, st, p, g = _small()
+@pytest.mark.parametrize('f', [19, 37])          # 37: the abs-form widths (|.| source modifiers instead of v_max)
+def test_nonfinite_or_out_of_range_points_reach_out_and_logdet(mode, bad, f):
+    L, f, G, B, N, m, st, p, g = _small(f)
     m = m.to(DEV).eval()
     p = p.copy()
     hits = [(0, 0, 5), (1, 2, 77), (2, 1, 129)]
@@ -156,8 +157,9 @@ def test_nonfinite_or_out_of_range_points_reach_out_and_logdet(mode, bad):
 
 
 @pytest.mark.parametrize('bad', [np.nan, np.inf])
-def test_nonfinite_latent_reaches_every_point_of_its_shape(bad):
-    L, f, G, B, N, m, st, p, g = _small()
+@pytest.mark.parametrize('f', [19, 37])          # 37: the abs-form widths (|.| source modifiers instead of v_max)
+def test_nonfinite_latent_reaches_every_point_of_its_shape(bad, f):
+    L, f, G, B, N, m, st, p, g = _small(f)
     m = m.to(DEV).eval()
     g = g.copy()
     g[1, 3] = bad
@@ -171,10 +173,11 @@ def test_nonfinite_latent_reaches_every_point_of_its_shape(bad):
 @pytest.mark.parametrize('key', ['flows.0.nvp2.T_mu_0.mu_sd0.weight', 'flows.1.nvp1.T_logvar_0.logvar_sd1.weight',
                                  'flows.0.nvp3.T_mu_0_cond_b.mu_sd1_film_b1.bias', 'flows.1.nvp3.T_logvar_0.logvar_sd0_bn.running_var',
                                  'flows.0.nvp1.T_logvar_0_cond_w.logvar_sd1_film_w0.weight', 'flows.1.nvp2.T_mu_1.mu_sd2.weight'])
-def test_nonfinite_weight_reaches_every_output(key):
+@pytest.mark.parametrize('f', [19, 37])          # 37: the abs-form widths (|.| source modifiers instead of v_max)
+def test_nonfinite_weight_reaches_every_output(key, f):
     """A single NaN anywhere in a coupling's parameters / buffers (diverged training): every point's result is NaN -- also
     for the weights whose NaN the v_max ReLU alone would turn into zeros (sd0, sd1, the FiLM shift head)."""
-    L, f, G, B, N, m, st, p, g = _small()
+    L, f, G, B, N, m, st, p, g = _small(f)
     st = {k: v.copy() for k, v in st.items()}
     st[key].reshape(-1)[1] = np.nan
     m = load(m, st).to(DEV).eval()
@@ -190,8 +193,9 @@ def test_nonfinite_weight_reaches_every_output(key):
     assert not np.isfinite(float((out ** 2).sum() + ld.sum()))
 
 
-def test_nonfinite_point_in_train_mode_reaches_the_loss():
-    L, f, G, B, N, m, st, p, g = _small()
+@pytest.mark.parametrize('f', [19, 37])          # 37: the abs-form widths (|.| source modifiers instead of v_max)
+def test_nonfinite_point_in_train_mode_reaches_the_loss(f):
+    L, f, G, B, N, m, st, p, g = _small(f)
     m = m.to(DEV).train()
     p = p.copy()
     p[1, 0, 3] = np.nan
