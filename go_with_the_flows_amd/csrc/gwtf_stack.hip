@@ -35,6 +35,9 @@ using namespace gwtf_dev;
 // noise of fp32 evaluation order, far inside the stated tolerance (2e-5); airplane kernel 0.522 -> 0.498 ms.
 __device__ __forceinline__ float tail_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 __device__ __forceinline__ float tail_scale(float eps, float logvar) { return __builtin_amdgcn_sqrtf(eps + __expf(logvar)); }
+// INVERSE mode divides by the scale: 1 / sqrt(eps + exp(logvar)) is ONE hardware op (v_rsq_f32) instead of a square root and a
+// reciprocal in a row -- one transcendental less on the coupling boundary's dependent chain, and none per coordinate
+__device__ __forceinline__ float tail_rscale(float eps, float logvar) { return __builtin_amdgcn_rsqf(eps + __expf(logvar)); }
 
 // One elementary coupling on the wave's tile.  KEEP2 = two kept coordinates / one warped (patterns 0-2),
 // otherwise one kept / two warped (patterns 3-5).  Every VALU instruction here costs the SIMD 4 cycles that
@@ -89,24 +92,25 @@ __device__ __forceinline__ void coupling_body(const float* __restrict__ L, int k
   const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
 
   // transcendental tail on this lane's own point
+  const float r_keep = __builtin_amdgcn_rcpf(s_keep);
   float lv_w[2] = {0.f, 0.f}, mu_w[2] = {0.f, 0.f}, sc_w[2] = {s_keep, s_keep};
 #pragma unroll
   for (int s = 0; s < (KEEP2 ? 1 : 2); ++s) {
     const float t = res[0][s] + bias[s];
     lv_w[s] = tail_div(t, 1.0f + fabsf(t));          // softsign (flows.py:99)
     mu_w[s] = res[1][s] + bias[2 + s];
-    sc_w[s] = tail_scale(eps, lv_w[s]);              // flows.py:113,115
+    sc_w[s] = MODE == GWTF_MODE_DIRECT ? tail_scale(eps, lv_w[s]) : tail_rscale(eps, lv_w[s]);   // flows.py:113,115 (INVERSE: its reciprocal)
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const bool is0 = d == w0, is1 = !KEEP2 && d == w1;
     lv_d[d] = is0 ? lv_w[0] : (is1 ? lv_w[1] : 0.f);
     mu_d[d] = is0 ? mu_w[0] : (is1 ? mu_w[1] : 0.f);
-    const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : s_keep);
+    const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : (MODE == GWTF_MODE_DIRECT ? s_keep : r_keep));
     if (MODE == GWTF_MODE_DIRECT)
       xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
     else
-      xo[d] = tail_div(__fsub_rn(xo[d], mu_d[d]), sc);
+      xo[d] = __fmul_rn(__fsub_rn(xo[d], mu_d[d]), sc);
   }
 }
 
@@ -335,24 +339,25 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     if (!KEEP2) res[br][1] = quarter_reduce<NB>(o1[br], q);
   }
   const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
+  const float r_keep = __builtin_amdgcn_rcpf(s_keep);
   float lv_w[2] = {0.f, 0.f}, mu_w[2] = {0.f, 0.f}, sc_w[2] = {s_keep, s_keep};
 #pragma unroll
   for (int s = 0; s < (KEEP2 ? 1 : 2); ++s) {
     const float t = res[0][s] + bias[s];
     lv_w[s] = tail_div(t, 1.0f + fabsf(t));
     mu_w[s] = res[1][s] + bias[2 + s];
-    sc_w[s] = tail_scale(eps, lv_w[s]);
+    sc_w[s] = MODE == GWTF_MODE_DIRECT ? tail_scale(eps, lv_w[s]) : tail_rscale(eps, lv_w[s]);
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     const bool is0 = d == w0, is1 = !KEEP2 && d == w1;
     lv_d[d] = is0 ? lv_w[0] : (is1 ? lv_w[1] : 0.f);
     mu_d[d] = is0 ? mu_w[0] : (is1 ? mu_w[1] : 0.f);
-    const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : s_keep);
+    const float sc = is0 ? sc_w[0] : (is1 ? sc_w[1] : (MODE == GWTF_MODE_DIRECT ? s_keep : r_keep));
     if (MODE == GWTF_MODE_DIRECT)
       xo[d] = __fadd_rn(__fmul_rn(sc, xo[d]), mu_d[d]);
     else
-      xo[d] = tail_div(__fsub_rn(xo[d], mu_d[d]), sc);
+      xo[d] = __fmul_rn(__fsub_rn(xo[d], mu_d[d]), sc);
   }
 }
 
