@@ -93,11 +93,20 @@ __device__ __forceinline__ float row_sum16(float v) {
 template <int NB>
 __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
   if constexpr (NB == 4) {
-    const bool hi = q >= 2, odd = q & 1;
-    const float s0 = hi ? o[0] : o[2], s1 = hi ? o[1] : o[3];
-    const float t0 = (hi ? o[2] : o[0]) + __shfl_xor(s0, 32);
-    const float t1 = (hi ? o[3] : o[1]) + __shfl_xor(s1, 32);
-    return (odd ? t1 : t0) + __shfl_xor(odd ? t0 : t1, 16);
+    // A 4 x 4 transpose-reduce over the quarters on gfx950's lane-swap instructions: v_permlane32_swap exchanges the upper half of
+    // its first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of
+    // the second (tools/diag/swap_probe.hip) -- three register-file moves where the shuffle version (below, NB < 4) makes two
+    // DEPENDENT ds_bpermute round trips through the LDS crossbar and six selects, on the coupling boundary's critical chain.  Same
+    // pairs added in the same order: bit-identical (tools/diag/qr_probe.hip).  Inline asm, because hipcc 7.2 miscompiles the
+    // two-result builtin when both results feed arithmetic (reads the second result from the first register); the two v_nop are the
+    // wait states a VALU write of an operand needs before the swap reads it (cdna_hip_programming.md T21) -- the hazard recogniser
+    // does not look inside asm.
+    float a0 = o[0], a2 = o[2], a1 = o[1], a3 = o[3];
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(a2));
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(a3));
+    float s02 = a0 + a2, s13 = a1 + a3;      // rows: block 0 (Q0+Q2), block 0 (Q1+Q3), block 2 (..), block 2 (..) | blocks 1, 3
+    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(s02), "+v"(s13));
+    return s02 + s13;                        // row q: block q, (Q0+Q2) + (Q1+Q3)
   } else if constexpr (NB == 2) {
     const bool odd = q & 1;
     const float t0 = o[0] + __shfl_xor(o[0], 32);

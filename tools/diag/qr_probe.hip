@@ -16,12 +16,20 @@ __device__ float qr_new(const float (&o)[4], int q) {
   const auto c = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s02), __builtin_bit_cast(unsigned, s13), false, false);
   return __builtin_bit_cast(float, c[0]) + __builtin_bit_cast(float, c[1]);
 }
+__device__ float qr_asm(const float (&o)[4], int q) {
+  float a0 = o[0], a2 = o[2], a1 = o[1], a3 = o[3];
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(a2));
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(a3));
+  float s02 = a0 + a2, s13 = a1 + a3;
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(s02), "+v"(s13));
+  return s02 + s13;
+}
 __global__ void k(const float* x, float* y) {
   const int lane = threadIdx.x, q = lane >> 4;
   float o[4];
   for (int i = 0; i < 4; ++i) o[i] = x[i * 64 + lane];
   y[lane] = qr_old(o, q);
-  y[64 + lane] = qr_new(o, q);
+  y[64 + lane] = qr_asm(o, q);
 }
 int main() {
   float h[256], r[128]; for (int i = 0; i < 256; ++i) h[i] = (float)((i * 37) % 101) * 0.25f;
