@@ -92,29 +92,33 @@ __device__ __forceinline__ float row_sum16(float v) {
 // with the total of point block (q & (NB-1)).
 template <int NB>
 __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
+  // A transpose-reduce over the quarters on gfx950's lane-swap instructions: v_permlane16_swap exchanges the odd 16-lane rows of its
+  // first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half of the second
+  // (tools/diag/swap_probe.hip) -- register-file moves where shuffles make two DEPENDENT ds_bpermute round trips through the LDS
+  // crossbar plus selects, on the coupling boundary's critical chain (reduce -> tail -> broadcast -> next fragments).  Every tile
+  // shape adds the same pairs in the same order, (Q0 + Q1) + (Q2 + Q3): a shape's result does not depend on the tile it ran with
+  // (test_full_size_properties).  Inline asm, because hipcc 7.2 miscompiles the two-result builtins when both results feed arithmetic
+  // (reads the second result from the first register, tools/diag/qr_probe.hip); the two v_nop are the wait states a VALU write of an
+  // operand needs before the swap reads it (cdna_hip_programming.md T21) -- the hazard recogniser does not look inside asm.
   if constexpr (NB == 4) {
-    // A 4 x 4 transpose-reduce over the quarters on gfx950's lane-swap instructions: v_permlane32_swap exchanges the upper half of
-    // its first operand with the lower half of its second, v_permlane16_swap the odd 16-lane rows of the first with the even rows of
-    // the second (tools/diag/swap_probe.hip) -- three register-file moves where the shuffle version (below, NB < 4) makes two
-    // DEPENDENT ds_bpermute round trips through the LDS crossbar and six selects, on the coupling boundary's critical chain.  Same
-    // pairs added in the same order: bit-identical (tools/diag/qr_probe.hip).  Inline asm, because hipcc 7.2 miscompiles the
-    // two-result builtin when both results feed arithmetic (reads the second result from the first register); the two v_nop are the
-    // wait states a VALU write of an operand needs before the swap reads it (cdna_hip_programming.md T21) -- the hazard recogniser
-    // does not look inside asm.
-    float a0 = o[0], a2 = o[2], a1 = o[1], a3 = o[3];
-    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(a2));
-    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(a3));
-    float s02 = a0 + a2, s13 = a1 + a3;      // rows: block 0 (Q0+Q2), block 0 (Q1+Q3), block 2 (..), block 2 (..) | blocks 1, 3
-    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(s02), "+v"(s13));
-    return s02 + s13;                        // row q: block q, (Q0+Q2) + (Q1+Q3)
+    float a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3];
+    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));
+    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2), "+v"(a3));
+    float s01 = a0 + a1, s23 = a2 + a3;       // rows: b0 (Q0+Q1), b1 (Q0+Q1), b0 (Q2+Q3), b1 (Q2+Q3) | the same for blocks 2, 3
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s01), "+v"(s23));
+    return s01 + s23;                         // row q: block q
   } else if constexpr (NB == 2) {
-    const bool odd = q & 1;
-    const float t0 = o[0] + __shfl_xor(o[0], 32);
-    const float t1 = o[1] + __shfl_xor(o[1], 32);
-    return (odd ? t1 : t0) + __shfl_xor(odd ? t0 : t1, 16);
+    float a0 = o[0], a1 = o[1];
+    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));
+    float s = a0 + a1, t = s;                 // rows: b0 (Q0+Q1), b1 (Q0+Q1), b0 (Q2+Q3), b1 (Q2+Q3)
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s), "+v"(t));
+    return s + t;                             // row q: block q & 1
   } else {
-    float t = o[0] + __shfl_xor(o[0], 32);
-    return t + __shfl_xor(t, 16);
+    float s = o[0], t = s;
+    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(s), "+v"(t));   // s: rows 0 0 2 2, t: rows 1 1 3 3
+    float u = s + t, v = u;                   // rows: (Q0+Q1) x 2, (Q2+Q3) x 2
+    asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(v));
+    return u + v;
   }
 }
 
