@@ -241,10 +241,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
     float bsum[4] = {own_valid ? dt[0][0] : 0.f, own_valid ? dt[0][1] : 0.f, own_valid ? dt[1][0] : 0.f,
                      own_valid ? dt[1][1] : 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) bsum[i] += __shfl_down(bsum[i], off);
-    }
+    for (int i = 0; i < 4; ++i) bsum[i] = wave_sum(bsum[i]);
     if (lane == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) atomicAdd(&s_bias[i], bsum[i]);
@@ -325,8 +322,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
       for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) amax = fmaxf(amax, fabsf(acc[br][m][nb][r]));
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    amax = wave_max(amax);
     if (lane == 0) s_amax[br][wave] = amax;
     if (br == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of branch 1's W1T have landed
     __syncthreads();   // also: every wave is past its forward recompute (branch 0) / past reading the previous X image (branch 1)

@@ -122,6 +122,24 @@ __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
   }
 }
 
+// Whole-wavefront sum / maximum, every lane ends with the result: DPP inside the 16-lane rows, lane swaps across them -- six
+// register-file steps where a shuffle ladder makes six DEPENDENT ds_bpermute round trips.
+__device__ __forceinline__ float wave_sum(float v) {
+  const float r[1] = {row_sum16(v)};
+  return quarter_reduce<1>(r, 0);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false)));
+  v = fmaxf(v, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false)));
+  float t = v;
+  asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(t));
+  float u = fmaxf(v, t), w = u;
+  asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(u), "+v"(w));
+  return fmaxf(u, w);
+}
+
 // sd0 (+ folded sd0_bn) + ReLU + f16 split in the lane that owns each MFMA k-slot, then the f x f contraction
 // acc[m][nb] = cinit[m] + W1'[16m.., :] . h0[:, points of block nb] on v_mfma_f32_16x16x32_f16 (3 products).
 // MG: 1 = the caller knows at compile time that the last k-step is the merged abs-form one (f = 33..40: the whole contraction is

@@ -639,8 +639,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     mv[6] = mv[1] * mv[1]; mv[7] = mv[1] * mv[2]; mv[8] = mv[2] * mv[2];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) mv[i] += __shfl_down(mv[i], off);
+      mv[i] = wave_sum(mv[i]);
     }
     __shared__ float s_mom[4][9];
     if (lane == 0) {
