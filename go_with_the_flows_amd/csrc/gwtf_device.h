@@ -102,8 +102,8 @@ __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
   // operand needs before the swap reads it (cdna_hip_programming.md T21) -- the hazard recogniser does not look inside asm.
   if constexpr (NB == 4) {
     float a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3];
-    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a0), "+v"(a1));
-    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a2), "+v"(a3));
+    asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"      // one pair of wait states covers both
+        : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
     float s01 = a0 + a1, s23 = a2 + a3;       // rows: b0 (Q0+Q1), b1 (Q0+Q1), b0 (Q2+Q3), b1 (Q2+Q3) | the same for blocks 2, 3
     asm("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(s01), "+v"(s23));
     return s01 + s23;                         // row q: block q
