@@ -578,7 +578,8 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
   if constexpr (MB == 3 && (VAR == BW_LIGHT || VAR == BW_MERGED)) {
     // the train pipeline's two passes at the abs-form widths (f = 33..40): the forward recompute as one basic block (MG = 1)
     if (gwtf_abs_form(f)) {
-      if (VAR == BW_LIGHT && nb == 2 && (long)B * N * K >= 256L * 1024 && getenv("GWTF_LIGHT_SMALL_TILE") == nullptr) {
+      static const bool small_tile_mg = getenv("GWTF_LIGHT_SMALL_TILE") != nullptr;   // diagnostic hook (tools/diag/light_tile_check.py)
+      if (VAR == BW_LIGHT && nb == 2 && (long)B * N * K >= 256L * 1024 && !small_tile_mg) {
         const dim3 grid4((unsigned)(B * ((N + 255) / 256)), (unsigned)K);
         hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
       } else if (nb == 1) {
