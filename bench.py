@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 import go_with_the_flows_amd as gw                      # noqa: E402
 from go_with_the_flows_amd import _lib                  # noqa: E402
 from go_with_the_flows_amd.synth import load_synth_, synth_inputs  # noqa: E402
+from go_with_the_flows_amd.dist import graph_capture      # noqa: E402
 
 # Resolved dimensions of BASELINE.json's configs: K components, L triples, f, G, per-GPU B, N
 WORKLOADS = {
@@ -108,23 +109,86 @@ def cpu_baseline(cfg, budget_s=15.0):
                       f'(min / max = slowest / fastest rep)'}
 
 
-def train_step_record():
-    """The airplane config's whole training step (encoder + posterior + prior flow + 4 decoders with batch-statistic BatchNorm +
-    mixture NLL + backward in one hipGraph, fused AMSGrad), timed by tools/bench_train.py in a child process after the headline
-    measurement.  Secondary figure: never part of `value`."""
+def _run_bench_train(extra_args, env, timeout=300, graph=True):
+    """One run of tools/bench_train.py in a child process -> {label: ms per step} parsed from its report, or {'error': ...}."""
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     try:
-        r = subprocess.run([sys.executable, os.path.join(here, 'tools', 'bench_train.py'), '--graph', '--steps', '20', '--api', 'both'],
-                           cwd=here, capture_output=True, text=True, timeout=420)
-        ms = {l.split(':')[0].strip(): float(l.split(':')[1].split('ms/step')[0]) for l in r.stdout.splitlines() if 'ms/step' in l}
-        if 'hipGraph' not in ms:
-            return {'error': (r.stderr or r.stdout)[-300:]}
-        return {'ms_per_step': ms['hipGraph'], 'eager_ms_per_step': ms.get('eager'), 'steps': 20,
-                'list_api_ms_per_step': ms.get('hipGraph list API'),        # the reference's own call: model(g, p) -> lists -> loss
-                'workload': 'airplane config, whole model: forward + backward (one hipGraph) + fused AMSGrad, B=64 x N=2048, K=4'}
+        r = subprocess.run([sys.executable, os.path.join(here, 'tools', 'bench_train.py'), '--steps', '20'] + (['--graph'] if graph else []) + extra_args,
+                           cwd=here, env=env, capture_output=True, text=True, timeout=timeout)
     except Exception as e:      # a secondary figure must never cost the headline line
         return {'error': repr(e)[:300]}
+    ms = {l.split(':')[0].strip(): float(l.split(':')[1].split('ms/step')[0]) for l in r.stdout.splitlines() if 'ms/step' in l}
+    for l in r.stdout.splitlines():
+        if l.startswith('statistic all-reduces captured in the graph:'):
+            ms['collectives'] = int(l.split(':')[1])
+    if r.returncode != 0:
+        return {'error': (r.stderr or r.stdout)[-300:]}
+    ms['rc'] = 0
+    return ms
+
+
+def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backend='nccl', share_device=False):
+    """The airplane config's whole training step (encoder + posterior + prior flow + 4 decoders with batch-statistic BatchNorm +
+    mixture NLL + backward in one hipGraph, fused AMSGrad), timed by tools/bench_train.py in child processes after the headline
+    measurement.  Secondary figures: never part of `value`.
+      one rank  : the plain step, the reference's own list-API call, and the DATA-PARALLEL code path on a 1-rank RCCL group
+                  (GWTF_FORCE_SHARDED=1: phase-split pipeline, 132 statistic all-reduces + row gathers + gradient exchange captured
+                  in the graph) -- what that path costs before any link latency;
+      N > 1     : every rank starts one child (same GPU), the children form their own RCCL group and run the sharded step:
+                  `global_batch_64` = the reference's run (train_ae.py:77-78 divides the batch of 64 over the ranks) and
+                  `per_rank_batch_64` (weak scaling).  ms per step = the slowest rank's."""
+    base_env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    for k in list(base_env):
+        # the launcher's agent settings must not reach the children: with TORCHELASTIC_USE_AGENT_STORE=True a child rank 0 would
+        # expect the AGENT to host the rendezvous store on its (new) port and never start one -- every child then waits forever
+        if k.startswith('TORCHELASTIC_') or k in ('GROUP_RANK', 'ROLE_RANK', 'ROLE_NAME', 'ROLE_WORLD_SIZE', 'GROUP_WORLD_SIZE',
+                                                  'LOCAL_WORLD_SIZE', 'TORCH_NCCL_ASYNC_ERROR_HANDLING'):
+            base_env.pop(k)
+    wl = 'airplane config, whole model: forward + backward (one hipGraph) + fused AMSGrad, K=4, N=2048'
+    if world == 1:
+        for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'GWTF_FORCE_SHARDED'):
+            base_env.pop(k, None)
+        ms = _run_bench_train(['--api', 'both'], base_env)
+        if 'hipGraph' not in ms:
+            return ms if 'error' in ms else {'error': 'no hipGraph line'}
+        rec = {'ms_per_step': ms['hipGraph'], 'eager_ms_per_step': ms.get('eager'), 'steps': 20,
+               'list_api_ms_per_step': ms.get('hipGraph list API'),        # the reference's own call: model(g, p) -> lists -> loss
+               'workload': wl + ', B=64'}
+        sh = _run_bench_train([], dict(base_env, GWTF_FORCE_SHARDED='1'))
+        rec['data_parallel_path_1rank'] = ({'ms_per_step': sh.get('hipGraph'), 'statistic_all_reduces_in_graph': sh.get('collectives'),
+                                            'note': 'SyncBatchNorm model, phase-split pipeline, every collective captured in the hipGraph, '
+                                                    'RCCL 1-rank group'} if 'hipGraph' in sh else sh)
+        return rec
+    # N > 1: a fresh rendezvous port for the children, agreed on through the parents' group
+    import socket
+    ports = [0, 0]
+    if rank == 0:
+        with socket.socket() as s1, socket.socket() as s2:
+            s1.bind(('127.0.0.1', 0))
+            s2.bind(('127.0.0.1', 0))
+            ports = [s1.getsockname()[1], s2.getsockname()[1]]
+    dist.broadcast_object_list(ports, src=0)
+    env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1')
+    env.pop('GWTF_FORCE_SHARDED', None)
+    rec = {'workload': wl + f', {world} ranks, SyncBatchNorm + overlapped gradient all-reduce, all collectives inside the graph',
+           'steps': 20}
+    for label, per_rank, port in (('global_batch_64', max(2, 64 // world), ports[0]), ('per_rank_batch_64', 64, ports[1])):
+        # rehearsal on one GPU (--backend gloo --share-device): gloo's collectives are host-side, so no graph -- the eager step only
+        graph = backend == 'nccl'
+        key = 'hipGraph' if graph else 'eager'
+        ms = _run_bench_train(['--batch', str(per_rank), '--backend', backend] + (['--share-device'] if share_device else []),
+                              dict(env, MASTER_PORT=str(port)), graph=graph)
+        ok = torch.tensor([1.0 if ms.get('rc') == 0 and (rank != 0 or key in ms) else 0.0], device=dev if graph else 'cpu')
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # also keeps the parents in step between the two runs
+        if float(ok) == 0.0:
+            rec[label] = {'error': ms.get('error', 'a rank failed')}
+            break
+        if rank == 0:
+            rec[label] = {'ms_per_step': ms[key], 'eager_ms_per_step': ms.get('eager'), 'per_rank_batch': per_rank,
+                          'statistic_all_reduces_in_graph': ms.get('collectives'), 'graphed': graph,
+                          'shapes_per_s': round(per_rank * world / ms[key] * 1e3, 1)}
+    return rec
 
 
 def spawn_ranks(args, argv):
@@ -206,7 +270,7 @@ def run_workload(name, args, dev, rank, world, sync_all, reduce_max):
                 launch_step()
             torch.cuda.current_stream(dev).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            with graph_capture(graph):
                 graph_out = launch_step()
 
         def step(timers=None):                      # noqa: F811
@@ -285,6 +349,9 @@ def main():
     ap.add_argument('--workload', default='airplane', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the secondary M1 (north-star shape) measurement')
+    ap.add_argument('--no-train-step', action='store_true', help='skip the secondary whole-model training-step measurement')
+    ap.add_argument('--also-select', default='m1,ae,svr,k16,k16_b1,train_step',
+                    help='comma list of the secondary measurements to run beside the airplane headline')
     ap.add_argument('--eager', action='store_true', help='launch through the eager module path instead of one hipGraph per step')
     ap.add_argument('--points-per-wave', type=int, default=0, help='tuning hook: 16/32/64, 0 = library default')
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
@@ -335,14 +402,17 @@ def main():
         # the metric's own shape (B=32 x N=2048, the north-star module) and the other BASELINE configs' shapes, timed by the
         # same protocol in the same run (a few seconds each)
         also = {}
-        for name in ('m1', 'ae', 'svr', 'k16', 'k16_b1'):
+        selected = [n for n in args.also_select.split(',') if n]
+        for name in [n for n in ('m1', 'ae', 'svr', 'k16', 'k16_b1') if n in selected]:
             a = run_workload(name, args, dev, rank, world, sync_all, reduce_max)
             also[name] = {'value': round(a['value'], 3), 'unit': 'Mpoints/s',
                           'ms_per_step': round(a['elapsed'] / args.steps * 1e3, 4), 'steps': args.steps, 'warmup': args.warmup,
                           'workload': a['cfg']['name'], 'roofline': roofline_record(name, a)}
 
-        if world == 1 and rank == 0:
-            also['train_step'] = train_step_record()
+        if not args.no_train_step and 'train_step' in selected:
+            ts = train_step_record(world, rank, local_rank, dist, dev, args.backend, args.share_device)      # N > 1: every rank takes part (one child per GPU)
+            if rank == 0:
+                also['train_step'] = ts
 
     if rank == 0:
         cfg = m['cfg']

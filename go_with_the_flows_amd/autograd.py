@@ -425,38 +425,6 @@ class _AllReduceSum(torch.autograd.Function):
         return g
 
 
-def gather_rows(g, sizes):
-    """all_gather of (B_r, G) blocks whose B_r differ (collectives need equal shapes: pad to the largest, then trim)."""
-    import torch.distributed as dist
-    bmax = max(sizes)
-    mine = g.contiguous() if g.shape[0] == bmax else torch.cat([g, g.new_zeros(bmax - g.shape[0], g.shape[1])])
-    parts = [torch.empty(bmax, g.shape[1], device=g.device, dtype=g.dtype) for _ in sizes]
-    dist.all_gather(parts, mine)
-    return torch.cat([q[:n] for q, n in zip(parts, sizes)])
-
-
-class _AllGatherRows(torch.autograd.Function):
-    """Concatenate per-rank (B_r, G) latents (B_r may differ by one, train_ae.py:77-78); backward returns the summed
-    gradient of this rank's rows."""
-
-    @staticmethod
-    def forward(ctx, g):
-        import torch.distributed as dist
-        world, rank = dist.get_world_size(), dist.get_rank()
-        sizes = [torch.zeros(1, dtype=torch.int64, device=g.device) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([g.shape[0]], dtype=torch.int64, device=g.device))
-        sizes = [int(x.item()) for x in sizes]
-        ctx.row0, ctx.rows = sum(sizes[:rank]), sizes[rank]
-        return gather_rows(g, sizes)
-
-    @staticmethod
-    def backward(ctx, g_all):
-        import torch.distributed as dist
-        g_all = g_all.clone().contiguous()
-        dist.all_reduce(g_all, op=dist.ReduceOp.SUM)
-        return g_all[ctx.row0:ctx.row0 + ctx.rows]
-
-
 def train_density_forward(engine, p, g, distributed=False, mode='inverse'):
     """Differentiable train-mode density pass.  Returns out, logdet, per-coupling lists (ps, mus, lvs in direct
     order; ps/lvs differentiable) and bn_batch (C,2,4,2,f) for the running-statistic update.
@@ -469,12 +437,9 @@ def train_density_forward(engine, p, g, distributed=False, mode='inverse'):
     n = float(B * N)
     g = g.float()
     if distributed:
-        g_all = _AllGatherRows.apply(g)
-        import torch.distributed as dist
-        sizes = [torch.zeros(1, dtype=torch.int64, device=g.device) for _ in range(dist.get_world_size())]
-        dist.all_gather(sizes, torch.tensor([B], dtype=torch.int64, device=g.device))
-        row0 = sum(int(x.item()) for x in sizes[:dist.get_rank()])
-        n = float(sum(int(x.item()) for x in sizes) * N)
+        from .dist import gather_rows
+        g_all, lay = gather_rows(g)
+        row0, n = lay.row0, float(lay.total * N)
         if g_all.shape[0] < 2:
             raise ValueError('train-mode BatchNorm needs more than 1 shape per (global) batch')
         a, bsh, fmean, fvar = _film_train(P, g_all, eps)
@@ -677,16 +642,6 @@ class TrainMixtureFn(torch.autograd.Function):
         return (dp, bufs["g_raw"], gfr[:, :, :, 0, :f], gfr[:, :, :, 1, :f]) + (None,) * 10
 
 
-def _rank_rows(g):
-    """Data-parallel bookkeeping for the per-shape FiLM BatchNorm: the latents of all ranks (differentiable all-gather,
-    uneven per-rank batches allowed: train_ae.py:77-78), this rank's first row and the global number of shapes."""
-    import torch.distributed as dist
-    sizes = [torch.zeros(1, dtype=torch.int64, device=g.device) for _ in range(dist.get_world_size())]
-    dist.all_gather(sizes, torch.tensor([g.shape[0]], dtype=torch.int64, device=g.device))
-    sizes = [int(x.item()) for x in sizes]
-    return _AllGatherRows.apply(g), sum(sizes[:dist.get_rank()]), sum(sizes)
-
-
 def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False, want_lists=True):
     """Train-mode density pass of K stacks (the components of a mixture, or one decoder) through the fused pipeline.
     -> out, logdet (K,B,3,N), lists = (ps, mus, lvs) each (K,C,B,3,N) with ps / lvs differentiable, bn_batch (K,C,2,4,2,f)
@@ -697,7 +652,11 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
     g = g.float()
     row0, rows_total = 0, B
     if distributed:
-        g_all, row0, rows_total = _rank_rows(g)
+        # the latents of all ranks (differentiable all-gather; uneven per-rank batches allowed, train_ae.py:77-78): the per-shape
+        # FiLM BatchNorm normalises with the global batch.  The per-rank row counts are cached (dist.row_layout): no host sync.
+        from .dist import gather_rows
+        g_all, lay = gather_rows(g)
+        row0, rows_total = lay.row0, lay.total
     else:
         g_all = g
     if rows_total < 2:
@@ -707,13 +666,16 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
     # the FiLM heads of all K stacks in ONE set of batched products: views of the stacked arena, K*C couplings
     film_a, film_b, film_mean, film_var = _film_train(_gather_film(raw, K * C, f, G), g_all, eps)
     a, bsh = film_a[row0:row0 + B], film_b[row0:row0 + B]                # (B, K*C, 2, f)
-    sink = GRAD_SINK['reducer']
-    if sink is not None:
+    if raw.requires_grad:
         # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
-        # the FiLM heads' part, summed by autograd): hand it to the data-parallel reducer the moment it exists, so that its
-        # all-reduce overlaps the rest of the backward pass
-        if raw.requires_grad:
-            raw.register_hook(lambda grad: [sink.on_flat_gradient(grad[k], e) for k, e in enumerate(engines)] and None)
+        # the FiLM heads' part, summed by autograd): hand it to the data-parallel reducer (dist.OverlappedGradients, looked up
+        # when the backward pass runs) the moment it exists, so that its all-reduce overlaps the rest of the backward pass
+        def _to_reducer(grad, engines=tuple(engines)):
+            sink = GRAD_SINK['reducer']
+            if sink is not None:
+                for k, e in enumerate(engines):
+                    sink.on_flat_gradient(grad[k], e)
+        raw.register_hook(_to_reducer)
     out, logdet, ps, mus, lvs, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
                                                                float(rows_total) * N, distributed, want_lists)
     lists = (ps, mus, lvs) if want_lists else None           # (K,C,B,3,N) each; ps / lvs differentiable

@@ -39,10 +39,143 @@ def max_over_ranks(value, device='cpu'):
     return float(t.item())
 
 
+def capture_mode():
+    """capture_error_mode for torch.cuda.graph(...).  With a process group alive, ProcessGroupNCCL's watchdog THREAD polls the
+    events of earlier collectives (hipEventQuery); under the default 'global' mode that call is illegal while this thread
+    captures and takes the process down ("operation not permitted when stream is capturing").  'thread_local' restricts the
+    check to the capturing thread."""
+    return 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
+
+
+def quiesce_for_capture(device=None):
+    """Call right before a hipGraph capture in a process with an RCCL process group.  ProcessGroupNCCL's watchdog thread polls the
+    completion events of earlier (eager) collectives every ~100 ms; while its internal stream is part of a capture HIP refuses
+    such a query (hipErrorCapturedEvent / hipErrorStreamCaptureUnsupported) and the watchdog takes the process down.  This
+    torch build does not wait for the watchdog's list to drain by itself, so: finish all device work, then give the watchdog
+    three polling periods to retire what is left."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and torch.cuda.is_available():
+        import time
+        torch.cuda.synchronize(device)
+        time.sleep(0.35)
+
+
+def graph_capture(graph, device=None, **kwargs):
+    """torch.cuda.graph(graph) made safe beside a live process group: quiesce_for_capture + capture_mode()."""
+    quiesce_for_capture(device)
+    return torch.cuda.graph(graph, capture_error_mode=capture_mode(), **kwargs)
+
+
 def sum_over_ranks(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
+
+
+def sharded():
+    """True when batch statistics must be summed over the ranks of torch.distributed's default group: more than one rank, or
+    GWTF_FORCE_SHARDED=1 (takes the multi-rank code path on a 1-rank group -- the only way to run the collectives over RCCL,
+    and to capture them in a hipGraph, on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('GWTF_FORCE_SHARDED') == '1'
+
+
+def syncs_statistics(bn_modules):
+    """True when these BatchNorm modules must see the statistics of ALL ranks: the reference converts every BatchNorm to
+    SyncBatchNorm before wrapping the model in DistributedDataParallel (train_ae.py:152), and the run is sharded()."""
+    return sharded() and any(isinstance(m, torch.nn.SyncBatchNorm) for m in bn_modules)
+
+
+# ---- the rows (shapes) each rank holds -------------------------------------------------------------------------------------
+# Per-shape work (the FiLM heads of the decoders, the prior flow on the latent, the Gaussian heads) is a few MFLOP on B rows:
+# every rank runs it on the rows of ALL ranks (one all-gather of the B x G latents) instead of synchronising the statistics of
+# each of its BatchNorm layers -- same numbers as SyncBatchNorm, two collectives per module instead of two per layer.  That
+# needs every rank's row count.  The reference's loader gives a rank the same batch on every step (DistributedSampler +
+# drop_last, train_ae.py:77-78,97-109), so the counts are exchanged ONCE per distinct local batch size and cached: no
+# device-to-host synchronisation in the step, which is what lets the whole step be captured in a hipGraph.
+class RowLayout:
+    __slots__ = ('sizes', 'row0', 'total', 'even')
+
+    def __init__(self, sizes, rank):
+        self.sizes = [int(s) for s in sizes]
+        self.row0, self.total = sum(self.sizes[:rank]), sum(self.sizes)
+        self.even = len(set(self.sizes)) == 1
+
+    def __repr__(self):
+        return f'RowLayout(sizes={self.sizes}, row0={self.row0})'
+
+
+_ROW_LAYOUTS = {}
+
+
+def reset_row_layouts():
+    """Forget the cached per-rank batch sizes (call on every rank when the per-rank batch size changes on SOME rank only)."""
+    _ROW_LAYOUTS.clear()
+
+
+def row_layout(rows, device):
+    """The number of rows every rank of the default group holds, given that this rank holds `rows`.  Collective on first
+    use of a value of `rows` (every rank must call it then), cached afterwards."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return RowLayout([rows], 0)
+    world, rank = dist.get_world_size(), dist.get_rank()
+    key = (world, rank, int(rows))
+    lay = _ROW_LAYOUTS.get(key)
+    if lay is None:
+        if world == 1:
+            lay = RowLayout([rows], 0)
+        else:
+            if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the per-rank batch sizes are exchanged on the first step with a given batch size: run one '
+                                   'step outside the hipGraph capture first (GraphedTrainStep does)')
+            on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
+            sizes = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
+            dist.all_gather(sizes, torch.tensor([int(rows)], dtype=torch.int64, device=on))
+            lay = RowLayout([int(x.item()) for x in sizes], rank)
+        _ROW_LAYOUTS[key] = lay
+    return lay
+
+
+def _gather_padded(t, lay):
+    """all_gather of (B_r, ...) blocks whose B_r may differ (collectives need equal shapes: pad to the largest, then trim)."""
+    bmax = max(lay.sizes)
+    mine = t.contiguous()
+    if mine.shape[0] < bmax:
+        mine = torch.cat([mine, mine.new_zeros((bmax - mine.shape[0],) + tuple(mine.shape[1:]))])
+    out = mine.new_empty((len(lay.sizes) * bmax,) + tuple(mine.shape[1:]))
+    if dist.get_backend() == 'nccl':
+        dist.all_gather_into_tensor(out, mine)
+    else:
+        dist.all_gather(list(out.chunk(len(lay.sizes))), mine)
+    if lay.even:
+        return out
+    return torch.cat([blk[:n] for blk, n in zip(out.chunk(len(lay.sizes)), lay.sizes)])
+
+
+class GatherRows(torch.autograd.Function):
+    """rows of all ranks, concatenated in rank order: (B_r, ...) -> (sum_r B_r, ...).  The backward sums the gradient every
+    rank holds for every row and returns this rank's rows: each rank's loss depends on each rank's rows through the batch
+    statistics (SyncBatchNorm semantics, reference train_ae.py:152).  No host synchronisation: capturable."""
+
+    @staticmethod
+    def forward(ctx, t, lay):
+        ctx.lay = lay
+        return _gather_padded(t, lay)
+
+    @staticmethod
+    def backward(ctx, g_all):
+        lay = ctx.lay
+        g_all = g_all.contiguous().clone()
+        dist.all_reduce(g_all, op=dist.ReduceOp.SUM)
+        return g_all[lay.row0:lay.row0 + lay.sizes[dist.get_rank()]], None
+
+
+def gather_rows(t):
+    """-> (rows of all ranks (differentiable), RowLayout).  Identity without a process group."""
+    lay = row_layout(t.shape[0], t.device)
+    if len(lay.sizes) == 1 and not sharded():
+        return t, lay
+    return GatherRows.apply(t, lay), lay
 
 
 def all_reduce_direct(flat, group=None):
@@ -116,18 +249,26 @@ def all_reduce_gradients(module, average=True, force=False, algorithm='ring'):
     return flat.numel()
 
 
+_REDUCE_STREAMS = {}        # per device: the stream the overlapped gradient all-reduces are ordered on
+
+
 class OverlappedGradients:
     """Data-parallel gradient exchange overlapped with the backward pass (the job DistributedDataParallel's buckets do in
     the reference, train_ae.py:153).  The decoders hold ~3/4 of the model's parameters (3.7 M of 4.8 M for the airplane
     config) and are the LAST modules of the forward pass, so their gradients are complete FIRST in the backward pass -- one
     flat tensor per decoder (the gradient of its raw parameter arena).  Their all-reduces are launched asynchronously
-    right there (RCCL runs it on its own stream over xGMI) while the encoder / prior-flow backward continues on the compute
-    stream; ``finish()`` reduces what is left as one more flat buffer and waits.
+    right there (on a side stream: RCCL runs over xGMI) while the encoder / prior-flow backward continues on the compute
+    stream; ``finish()`` reduces what is left as one more flat buffer and waits.  Capturable in a hipGraph.
 
         reducer = OverlappedGradients(model)          # once
-        with reducer:                                  # per step
+        with reducer:                                  # per step; the forward pass may be inside or outside
             loss.backward()
         optimizer.step()
+
+    Contract: a decoder's parameters receive gradient only through its raw arena (true for every path of this package), so the
+    reduced flat gradient REPLACES the .grad this backward pass created.  Gradient accumulation: run the earlier micro-batches
+    outside the reducer (DistributedDataParallel.no_sync semantics) and the last one inside -- decoders whose parameters already
+    hold a .grad are then reduced with the remainder, as accumulated totals (tests/dist_gpu_worker.py).
     """
 
     def __init__(self, module, average=True):
@@ -138,7 +279,7 @@ class OverlappedGradients:
     def __enter__(self):
         from . import autograd
         self.pending = []
-        autograd.GRAD_SINK['reducer'] = self if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+        autograd.GRAD_SINK['reducer'] = self if sharded() else None
         return self
 
     def __exit__(self, exc_type, exc, tb):
@@ -149,30 +290,51 @@ class OverlappedGradients:
         return False
 
     def on_flat_gradient(self, grad, engine):
-        grad = grad.contiguous()
-        work = dist.all_reduce(grad, op=dist.ReduceOp.SUM, async_op=True)     # in place, on the collective stream
-        self.pending.append((work, grad, engine))
+        """Called from the backward pass with one decoder's flat gradient (the gradient of its raw arena; the parameters' .grad
+        are about to be made from slices of it).  The all-reduce runs on a PRIVATE copy: the compute stream goes on reading
+        `grad` (AccumulateGrad) while RCCL works, so reducing it in place would be a data race.
+        Gradient accumulation: when a covered parameter already holds a .grad (earlier micro-batches, run OUTSIDE the reducer
+        like DistributedDataParallel.no_sync), what must be reduced is the accumulated total, which exists only after this
+        backward pass -- such a decoder is left to finish()'s flat buffer."""
+        if any(t is not None and t.grad is not None for t, _op in engine._srcs):
+            return
+        buf = grad.contiguous().clone()
+        if not buf.is_cuda:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            self.pending.append((buf, engine, None))
+        else:
+            # a stream-ordered all-reduce on a SIDE stream (not async_op=True: a Work object created inside a hipGraph capture
+            # ends up in ProcessGroupNCCL's watchdog list and its captured events cannot be queried): the collective and the
+            # rest of the backward pass are parallel branches -- of the stream DAG when eager, of the graph when captured
+            cur = torch.cuda.current_stream(buf.device)
+            side = _REDUCE_STREAMS.get(buf.device)
+            if side is None:
+                side = _REDUCE_STREAMS[buf.device] = torch.cuda.Stream(device=buf.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            buf.record_stream(side)
+            self.pending.append((buf, engine, side))
         self.launched += 1
-        return grad
 
     def finish(self):
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         covered, dsts, srcs = set(), [], []
-        for work, grad, e in self.pending:
-            work.wait()
+        for buf, e, side in self.pending:
+            if side is not None:
+                torch.cuda.current_stream(buf.device).wait_stream(side)
             if self.average:
-                grad.div_(world)
-            for (t, _op), v in zip(e._srcs, grad.split_with_sizes(e._sizes)):
+                buf.div_(world)
+            for (t, _op), v in zip(e._srcs, buf.split_with_sizes(e._sizes)):
                 if t is None or not t.requires_grad or t.grad is None:
                     continue
-                covered.add(id(t))
-                if t.grad.data_ptr() != v.data_ptr():      # autograd cloned instead of keeping the view: copy the reduced values
-                    dsts.append(t.grad)
-                    srcs.append(v.view_as(t.grad))
+                covered.add(id(t))                # .grad was created by this backward pass: it IS the local gradient -> replace it
+                dsts.append(t.grad)
+                srcs.append(v.view_as(t.grad))
         if dsts:
             torch._foreach_copy_(dsts, srcs)
         self.pending = []
-        if world == 1:
+        if world == 1 and not sharded():
             return
         rest = [p.grad for p in self.module.parameters() if p.grad is not None and id(p) not in covered]
         if rest:
@@ -181,4 +343,3 @@ class OverlappedGradients:
             if self.average:
                 flat.div_(world)
             torch._foreach_copy_(rest, [v.view_as(g) for v, g in zip(flat.split_with_sizes([g.numel() for g in rest]), rest)])
-

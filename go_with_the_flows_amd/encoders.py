@@ -25,9 +25,8 @@ from .layers import SharedDot, Swish
 def _bn_sync(bn):
     """True when this BatchNorm sums its batch statistics over the ranks (SyncBatchNorm after train_ae.py:152, more than
     one rank in the default group)."""
-    import torch.distributed as dist
-    return (isinstance(bn, nn.SyncBatchNorm) and dist.is_available() and dist.is_initialized()
-            and dist.get_world_size() > 1)
+    from .dist import sharded
+    return isinstance(bn, nn.SyncBatchNorm) and sharded()
 
 
 class _EncoderTrainFn(torch.autograd.Function):
@@ -48,8 +47,10 @@ class _EncoderTrainFn(torch.autograd.Function):
         Ws = [w.detach().reshape(C[l + 1], C[l]).contiguous() for l, w in enumerate(params[0::3])]
         gam = [g.detach().contiguous() for g in params[1::3]]
         bet = [b.detach().contiguous() for b in params[2::3]]
-        world = dist.get_world_size() if sync else 1
-        n_total = float(B * N * world)
+        # points the statistics cover: every rank's shapes (the per-rank batch may differ by one, train_ae.py:77-78; the counts
+        # are exchanged once and cached, dist.row_layout)
+        from .dist import row_layout
+        n_total = float((row_layout(B, dev).total if sync else B) * N)
         f32 = dict(device=dev, dtype=torch.float32)
         P = lambda t: 0 if t is None else _ptr(t, 'encoder buffer')
         rm = [bn.running_mean if bn.track_running_stats else None for bn in bns]
@@ -352,8 +353,60 @@ class FeatureEncoder(nn.Module):
                     self.logvars[-1].weight.normal_(std=logvar_weight_std)
                     self.logvars[-1].bias.fill_(logvar_bias)
 
-    def forward(self, input):
-        h = self.features(input) if self.n_layers > 0 else input
+    def _bn_modules(self):
+        return [m for m in self.features if isinstance(m, nn.modules.batchnorm._BatchNorm)] if self.n_layers > 0 else []
+
+    def _features_functional(self, h, bn_updates):
+        """self.features(h) layer by layer with torch.nn.functional calls -- for the two cases the module call cannot serve:
+        SyncBatchNorm modules whose input already holds the rows of all ranks (their own forward would synchronise again), and
+        `bn_updates` > 1 = the running statistics advanced as if this batch had been seen that many times (the reference
+        evaluates p_prior once per mixture component on the same latents, models.py:169-193 inside flow_mixture.py:163-166)."""
+        for mod in self.features:
+            if isinstance(mod, nn.Linear):
+                h = nn.functional.linear(h, mod.weight, mod.bias)
+            elif isinstance(mod, nn.modules.batchnorm._BatchNorm):
+                batch_stats = mod.training or not mod.track_running_stats
+                x = h
+                h = nn.functional.batch_norm(x, mod.running_mean if mod.track_running_stats else None,
+                                             mod.running_var if mod.track_running_stats else None, mod.weight, mod.bias,
+                                             batch_stats, 0.0 if mod.momentum is None else mod.momentum, mod.eps)
+                if mod.training and mod.track_running_stats:
+                    if mod.momentum is None:
+                        raise NotImplementedError('BatchNorm momentum=None (cumulative average) is not supported here; the '
+                                                  'reference never sets it (encoders.py:49)')
+                    with torch.no_grad():
+                        if bn_updates > 1:
+                            xd = x.detach()
+                            keep = (1.0 - mod.momentum) ** (bn_updates - 1)
+                            # .data: the batch-norm node saved these buffers for its backward (it only reads them in eval mode); the
+                            # replayed updates must not trip autograd's version check -- K real passes update them in place too
+                            mod.running_mean.data.mul_(keep).add_(xd.mean(0), alpha=1.0 - keep)
+                            mod.running_var.data.mul_(keep).add_(xd.var(0, unbiased=True), alpha=1.0 - keep)
+                        if mod.num_batches_tracked is not None:
+                            mod.num_batches_tracked.data.add_(bn_updates)
+            else:
+                h = mod(h)
+        return h
+
+    def _hidden(self, input, bn_updates=1):
+        """The shared trunk: Linear -> BatchNorm -> Swish per layer.  In a synchronised data-parallel run (SyncBatchNorm modules,
+        train_ae.py:152) every rank evaluates the trunk on the rows of ALL ranks and keeps its own (dist.gather_rows): one
+        all-gather forward and one all-reduce backward per module instead of two collectives per BatchNorm layer."""
+        if self.n_layers == 0:
+            return input
+        bns = self._bn_modules()
+        from .dist import gather_rows, syncs_statistics
+        sync = self.training and bool(bns) and syncs_statistics(bns)
+        if not sync and bn_updates == 1:
+            return self.features(input)
+        rows = input.shape[0]
+        if sync:
+            input, lay = gather_rows(input)
+        h = self._features_functional(input, bn_updates)
+        return h[lay.row0:lay.row0 + rows] if sync else h
+
+    def forward(self, input, bn_updates=1):
+        h = self._hidden(input, bn_updates)
         if self.deterministic:
             return self.mus(h)
         return self.mus(h), self.logvars(h)
@@ -362,5 +415,5 @@ class FeatureEncoder(nn.Module):
 class WeightsEncoder(FeatureEncoder):
     """Mixture-weight head: log-softmax of the deterministic output (reference encoders.py:87-91)."""
 
-    def forward(self, input):
-        return nn.functional.log_softmax(super().forward(input), dim=1)
+    def forward(self, input, bn_updates=1):
+        return nn.functional.log_softmax(super().forward(input, bn_updates), dim=1)

@@ -24,14 +24,14 @@ WARP_PATTERNS = ((0,), (1,), (2,), (0, 1), (0, 2), (1, 2))
 
 
 def _sharded():
-    """True when BatchNorm statistics must be summed over the ranks of torch.distributed's default group (more than one
-    rank; GWTF_FORCE_SHARDED=1 takes the phase-split path on a 1-rank group too -- the only way to run the statistic
-    collectives over RCCL on a one-GPU box, tests/rccl_single_rank_worker.py)."""
-    import os
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return False
-    return dist.get_world_size() > 1 or os.environ.get('GWTF_FORCE_SHARDED') == '1'
+    """dist.sharded(): BatchNorm statistics are summed over the ranks of torch.distributed's default group."""
+    from .dist import sharded
+    return sharded()
+
+
+def _graph_capture(graph):
+    from .dist import graph_capture
+    return graph_capture(graph)
 
 
 def _film_head(X, which, f, G):
@@ -216,9 +216,6 @@ class _ArenaCatMulti(torch.autograd.Function):
         return (None, *grads)
 
 
-_STACK_TABLES = {}
-
-
 def _gather_stacked(engines):
     """(K, R) stacked raw arena from the engines' cached detached views; the combined device table is cached per engine tuple and
     rebuilt when a source pointer changed (not inside a hipGraph capture: per-engine gathers + torch.stack stand in there)."""
@@ -228,8 +225,11 @@ def _gather_stacked(engines):
     R = sum(engines[0]._sizes)
     if not flat0[0].is_cuda:
         return torch.stack([torch.cat(e._flat) for e in engines])
+    # the combined table lives on the first engine (it dies with the model: a module-level cache keyed on id() would keep the
+    # detached parameter views and the device table of every model ever built alive)
     key = tuple(id(e) for e in engines)
-    tab = _STACK_TABLES.get(key)
+    tables = engines[0].__dict__.setdefault('_stack_tables', {})
+    tab = tables.get(key)
     flats = [e._flat for e in engines]
     if tab is None or len(tab[0]) != len(flats) or any(x is not y for x, y in zip(tab[0], flats)):   # a flat list is rebuilt with its tensors
         rows = []
@@ -239,11 +239,11 @@ def _gather_stacked(engines):
                 rows.append((t.data_ptr(), off, n))
                 off += n
         if tab is not None and tab[1] == rows:
-            tab = _STACK_TABLES[key] = (flats, rows, tab[2])
+            tab = tables[key] = (flats, rows, tab[2])
         elif torch.cuda.is_current_stream_capturing():
             return torch.stack([e._cat_detached() for e in engines])
         else:
-            tab = _STACK_TABLES[key] = (flats, rows, torch.tensor(rows, dtype=torch.int64).to(flat0[0].device))
+            tab = tables[key] = (flats, rows, torch.tensor(rows, dtype=torch.int64).to(flat0[0].device))
     out = torch.empty(len(engines), R, device=flat0[0].device, dtype=torch.float32)
     with torch.cuda.device(out.device):
         _lib.check(_lib.lib().gwtf_gather_table(tab[2].data_ptr(), out.data_ptr(), len(tab[1]), _lib._stream(out)))
@@ -447,7 +447,8 @@ class StackEngine:
     def _update_running_stats(self, bn_batch):
         """running = (1-m)*running + m*batch with the unbiased batch variance (torch.nn.BatchNorm1d semantics)."""
         stamp = sum(c._stamp for c in self.couplings)
-        if self._bn_cache is None or self._bn_cache[0] != stamp:
+        capturing = bn_batch.is_cuda and torch.cuda.is_current_stream_capturing()
+        if self._bn_cache is None or self._bn_cache[0] != stamp or (self._bn_cache[2] is None and not capturing):
             # (re)derive the pointer rows; the device table is rebuilt only when a pointer really changed (load_state_dict copies
             # in place and keeps them), because building it is a host-to-device copy -- not allowed while a hipGraph is captured
             mods = self._bn_modules()
@@ -462,10 +463,12 @@ class StackEngine:
                                  float(m.momentum)))
                     touched += [m.running_mean, m.running_var] + ([nbt] if nbt is not None else [])
             old = self._bn_cache
-            if old is not None and old[3] == rows and old[2][0] is not None and old[2][0].device == bn_batch.device:
+            if old is not None and old[3] == rows and old[2] is not None and old[2][0] is not None and old[2][0].device == bn_batch.device:
                 self._bn_cache = (stamp, len(mods), old[2], rows, touched)
-            elif torch.cuda.is_current_stream_capturing():
-                self._bn_cache = (stamp, len(mods), None, rows, touched)       # this capture takes the _foreach_ route below
+            elif capturing:
+                # no device table can be built inside a capture (host-to-device copy): this capture takes the per-module route
+                # below; the next call outside a capture builds the table (the condition above)
+                self._bn_cache = (stamp, len(mods), None, rows, touched)
             else:
                 dev = bn_batch.device
                 table = torch.tensor([r[1:4] for r in rows], dtype=torch.int64).to(dev) if rows else None
@@ -562,7 +565,7 @@ class GraphedStack:
             body()                                   # warm-up outside capture (lazy module loading etc.)
         torch.cuda.current_stream(p.device).wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with _graph_capture(self.graph), torch.no_grad():
             self.results = body()
         self._keepalive = packs
 

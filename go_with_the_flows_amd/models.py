@@ -122,44 +122,16 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
         raise ValueError(f'unknown p_decoder_base_type {self.p_decoder_base_type!r}')
 
     def _base_gaussian_repeated(self, g_sample, times):
-        """_base_gaussian evaluated ONCE with the buffer side effects of `times` evaluations on the same batch: every tracked
-        BatchNorm of p_prior in train mode gets running = (1-m) running + m batch applied `times - 1` more times (the batch
-        statistics recomputed from the module's input, unbiased variance) and num_batches_tracked += times - 1."""
-        bns = [mod for mod in getattr(self, 'p_prior', nn.Module()).modules()
-               if isinstance(mod, nn.modules.batchnorm._BatchNorm) and mod.training and mod.track_running_stats]
-        if times <= 1 or not bns or self.p_decoder_base_type == 'fixed':
+        """_base_gaussian evaluated ONCE with the buffer side effects of `times` evaluations on the same batch (the reference
+        evaluates p_prior inside its loop over the K components, models.py:169-193 in flow_mixture.py:163-166): every tracked
+        BatchNorm of p_prior in train mode gets running = (1-m) running + m batch applied `times` times and num_batches_tracked
+        += times (FeatureEncoder.forward(bn_updates=times))."""
+        if times <= 1 or self.p_decoder_base_type == 'fixed':
             return self._base_gaussian(g_sample)
-        import torch.distributed as dist
-        if any(isinstance(mod, nn.SyncBatchNorm) for mod in bns) and dist.is_available() and dist.is_initialized() \
-                and dist.get_world_size() > 1:
-            out = self._base_gaussian(g_sample)          # synchronised statistics are not this rank's alone: really run K passes
-            for _ in range(times - 1):
-                self._base_gaussian(g_sample)
-            return out
-        seen, hooks = {}, []
-        for mod in bns:
-            hooks.append(mod.register_forward_pre_hook(lambda md, args: seen.__setitem__(md, args[0].detach())))
-        try:
-            out = self._base_gaussian(g_sample)
-        finally:
-            for h in hooks:
-                h.remove()
-        with torch.no_grad():
-            for mod in bns:
-                x = seen.get(mod)
-                if x is None or mod.momentum is None:
-                    for _ in range(times - 1):           # cumulative-average BatchNorm: no closed form kept here, just re-run
-                        self._base_gaussian(g_sample)
-                    return out
-                dims = [d for d in range(x.dim()) if d != 1]
-                mean, var = x.mean(dims), x.var(dims, unbiased=True)
-                keep = (1.0 - mod.momentum) ** (times - 1)
-                # .data: the batch-norm node saved these buffers for its backward (it only reads them in eval mode); the replayed
-                # updates must not trip autograd's version check -- K real passes update them in place between passes as well
-                mod.running_mean.data.mul_(keep).add_(mean, alpha=1.0 - keep)
-                mod.running_var.data.mul_(keep).add_(var, alpha=1.0 - keep)
-                mod.num_batches_tracked.data.add_(times - 1)
-        return out
+        if self.p_decoder_base_type == 'free':
+            mu0, lv0 = self.p_prior(g_sample, bn_updates=times)
+            return mu0.unsqueeze(2), lv0.unsqueeze(2)
+        return self.p_prior_mus, self.p_prior(g_sample, bn_updates=times).unsqueeze(2)
 
     def one_flow_decode(self, p_input, g_sample, pc_decoder, n_sampled_points):
         """models.py:153-207: lists for ONE component (inverse on p_input when training, direct on a base draw otherwise)."""

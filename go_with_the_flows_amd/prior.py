@@ -139,16 +139,21 @@ class GlobalRNVPDecoder(nn.Module):
                     parts += [t[0].weight, t[1].weight, t[1].bias, t[1].running_mean, t[1].running_var, t[3].weight, t[3].bias]
         return torch.cat([q.reshape(-1) for q in parts])
 
-    def _fused_ok(self, g):
+    def _syncs(self):
+        """Batch statistics over the rows of ALL ranks (the reference converts every BatchNorm to SyncBatchNorm,
+        train_ae.py:152)."""
+        from .dist import syncs_statistics
+        return self.training and syncs_statistics(self._bn_modules())
+
+    def _fused_ok(self, g, rows=None):
+        """The one-launch kernels cover this call (csrc/gwtf_prior.hip make_plan: rows <= 128, G <= 512, F <= 128, fp32 affine
+        BatchNorm with a momentum); otherwise the module-by-module evaluation runs."""
         bns = self._bn_modules()
-        if self.training and any(isinstance(bn, nn.SyncBatchNorm) for bn in bns):
-            import torch.distributed as dist
-            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-                # synchronised statistics (train_ae.py:152) are over ALL ranks' rows: the single-launch kernel sees this rank's
-                # only -- the module path below runs torch's SyncBatchNorm
-                return False
-        return (g.is_cuda and g.dim() == 2 and 2 <= g.shape[1] == self.g_n_features and g.shape[0] <= 128 and
-                2 * self.n_flows <= 64 and all(bn.track_running_stats and bn.momentum is not None for bn in bns))
+        rows = g.shape[0] if rows is None else rows
+        return (g.is_cuda and g.dim() == 2 and 2 <= g.shape[1] == self.g_n_features <= 512 and rows <= 128 and
+                self.n_features <= 128 and 2 * self.n_flows <= 64 and g.dtype == torch.float32 and
+                all(bn.track_running_stats and bn.momentum is not None and bn.affine and bn.weight.dtype == torch.float32
+                    for bn in bns))
 
     def _forward_fused(self, g, mode):
         if mode not in ('direct', 'inverse'):
@@ -157,8 +162,19 @@ class GlobalRNVPDecoder(nn.Module):
         if training and g.shape[0] < 2:
             raise ValueError('Expected more than 1 value per channel when training (BatchNorm over the batch)')
         eps = self.flows[0].nvp1._eps_value
+        row0, rows = 0, g.shape[0]
+        if self._syncs():
+            # data-parallel run: the flow is per SHAPE (a few MFLOP on one compute unit), so every rank evaluates it on the rows
+            # of ALL ranks -- one all-gather forward, one all-reduce of the row gradients backward -- instead of synchronising
+            # the statistics of each of its 4 n_flows BatchNorm layers; its own rows are sliced out below.  Same numbers as
+            # SyncBatchNorm (each rank's loss sees every row through the batch statistics; GatherRows.backward sums that).
+            from .dist import gather_rows
+            g, lay = gather_rows(g.contiguous().float())
+            row0 = lay.row0
         gs, mus, lvs, stats = _PriorFlowFn.apply(g.contiguous().float(), self._raw_arena(), self.n_flows, self.n_features,
                                                  eps, mode, training)
+        if g.shape[0] != rows:
+            gs, mus, lvs = (t[:, row0:row0 + rows] for t in (gs, mus, lvs))
         if training:
             # running = (1 - m) running + m batch, unbiased batch variance, num_batches_tracked += 1 (nn.BatchNorm1d)
             B = g.shape[0]
@@ -185,7 +201,7 @@ class GlobalRNVPDecoder(nn.Module):
         fill the other 255 compute units -- in between: the prior flow then costs no time on the critical path, forward or
         backward (autograd runs a node's backward on the stream of its forward).  Capturable: the fork / join pair becomes a
         branch of the hipGraph.  Falls back to the synchronous evaluation when the fused path does not apply."""
-        if not self._fused_ok(g):
+        if not self._fused_ok(g, self._rows_seen(g)):
             return _PriorResult(self.forward(g, mode), None, None)
         cur = torch.cuda.current_stream(g.device)
         side = _SIDE_STREAMS.get(g.device)              # per device, not per module: a stream is not module state (deepcopy, pickle)
@@ -197,8 +213,15 @@ class GlobalRNVPDecoder(nn.Module):
         g.record_stream(side)
         return _PriorResult(res, side, cur)
 
+    def _rows_seen(self, g):
+        """Rows the BatchNorm statistics cover: this rank's, or every rank's in a synchronised data-parallel run."""
+        if g.is_cuda and self._syncs():
+            from .dist import row_layout
+            return row_layout(g.shape[0], g.device).total
+        return g.shape[0]
+
     def forward(self, g, mode='direct'):
-        if self._fused_ok(g):
+        if self._fused_ok(g, self._rows_seen(g)):
             return self._forward_fused(g, mode)
         gs, mus, logvars = [], [], []
         cur = g

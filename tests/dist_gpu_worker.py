@@ -68,6 +68,30 @@ def main():
     got = torch.cat([q.grad.reshape(-1) for d in decs for q in d.parameters()])
     assert float((got - ref_grads).abs().max() / ref_grads.abs().max()) < 1e-5
     assert abs(float(holder[-1].bias.grad[0]) - sum(r + 1.0 for r in range(world))) < 1e-6     # the non-decoder remainder
+    # gradient accumulation: the first micro-batch outside the reducer (local accumulation, like DDP.no_sync), the
+    # second inside -- the decoders' .grad already exist then, so their accumulated TOTALS are reduced with the remainder:
+    # twice the single-step result, nothing overwritten
+    for q in holder.parameters():
+        q.grad = None
+
+    def micro():
+        zo, ldo = ms.forward_all(ptm, gtm, 'inverse')
+        extra = holder[-1](torch.ones(1, 3, device='cuda')).sum() * (rank + 1.0)
+        ((zo * wk * torch.from_numpy(wz[b0:b1]).cuda()).sum() + (ldo * wk * torch.from_numpy(wl[b0:b1]).cuda()).sum() + extra).backward()
+    micro()
+    launched_before = reducer.launched
+    with reducer:
+        micro()
+    assert reducer.launched == launched_before          # accumulating: no decoder was reduced from inside the backward pass
+    got2 = torch.cat([q.grad.reshape(-1) for d in decs for q in d.parameters()])
+    assert float((got2 - 2.0 * ref_grads).abs().max() / ref_grads.abs().max()) < 2e-5
+    assert abs(float(holder[-1].bias.grad[0]) - 2.0 * sum(r + 1.0 for r in range(world))) < 1e-5
+    for d in decs:                                       # the saved comparison below reads the single-step gradients
+        for q in d.parameters():
+            q.grad = None
+    with reducer:
+        micro()
+    assert reducer.launched == launched_before + 2
     mix = {'zm': zm.detach().cpu().numpy(), 'dpm': dpm, 'dgm': dgm,
            'gm': torch.cat([q.grad.reshape(-1) for d in decs for q in d.parameters()]).cpu().numpy()}
     n_flat = all_reduce_gradients(m, average=False)           # one flat buffer, summed (DDP would also divide by W)

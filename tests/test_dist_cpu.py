@@ -91,3 +91,67 @@ def test_direct_reduce_scatter_all_gather_equals_all_reduce(world):
     """The point-to-point (xGMI-mesh) gradient exchange against the library all-reduce, 2 and 3 gloo ranks."""
     port = 31500 + os.getpid() % 2000 + world
     mp.spawn(_direct_worker, args=(world, port), nprocs=world, join=True)
+
+
+def _rows_worker(rank, world, port):
+    """dist.row_layout / gather_rows (the rows of ALL ranks for the per-shape modules) and the FeatureEncoder head on top of them:
+    ragged per-rank batches, forward == the single-process full batch, backward == its gradients (SyncBatchNorm semantics)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from go_with_the_flows_amd import dist as gd
+    gd.init_from_env('gloo')
+    B, G = 7, 6
+    b0, b1 = gd.shard_bounds(B, rank, world)
+    full = torch.randn(B, G, generator=torch.Generator().manual_seed(5))
+    lay = gd.row_layout(b1 - b0, torch.device('cpu'))
+    assert lay.sizes == [gd.shard_bounds(B, r, world)[1] - gd.shard_bounds(B, r, world)[0] for r in range(world)]
+    assert (lay.row0, lay.total, lay.even) == (b0, B, B % world == 0)
+    assert gd.row_layout(b1 - b0, torch.device('cpu')) is lay                    # cached: no second exchange
+    mine = full[b0:b1].clone().requires_grad_(True)
+    rows, lay2 = gd.gather_rows(mine)
+    assert torch.equal(rows, full) and lay2 is lay
+    w = torch.arange(B * G, dtype=torch.float32).view(B, G) * (rank + 1)          # every rank weighs every row differently
+    (rows * w).sum().backward()
+    want = sum(torch.arange(B * G, dtype=torch.float32).view(B, G) * (r + 1) for r in range(world))[b0:b1]
+    assert torch.allclose(mine.grad, want)
+    # a per-shape head converted to SyncBatchNorm (train_ae.py:152): every rank runs the trunk on all rows and keeps its own
+    from go_with_the_flows_amd.encoders import FeatureEncoder
+    torch.manual_seed(3)
+    head = FeatureEncoder(2, G, 3)
+    ref = FeatureEncoder(2, G, 3)
+    ref.load_state_dict(head.state_dict())
+    head = torch.nn.SyncBatchNorm.convert_sync_batchnorm(head).train()
+    x = full[b0:b1].clone().requires_grad_(True)
+    mu, lv = head(x, bn_updates=2)
+    wr = torch.linspace(0.5, 1.5, B).view(B, 1)
+    ((mu + lv * lv) * wr[b0:b1]).sum().backward()
+    for q in head.parameters():
+        dist.all_reduce(q.grad)
+    xf = full.clone().requires_grad_(True)
+    ref.train()
+    mu1, lv1 = ref(xf, bn_updates=2)
+    ((mu1 + lv1 * lv1) * wr).sum().backward()
+    assert torch.allclose(mu, mu1[b0:b1], atol=1e-6) and torch.allclose(lv, lv1[b0:b1], atol=1e-6)
+    assert torch.allclose(x.grad, xf.grad[b0:b1], atol=1e-5)
+    for q, q1 in zip(head.parameters(), ref.parameters()):
+        assert torch.allclose(q.grad, q1.grad, atol=1e-5)
+    for (k, v), v1 in zip(head.state_dict().items(), ref.state_dict().values()):
+        assert torch.allclose(v.float(), v1.float(), atol=1e-6), k                 # running statistics, num_batches_tracked (+2)
+    # ... and the two-update replay equals two real passes
+    two = FeatureEncoder(2, G, 3)
+    two.load_state_dict({k: v for k, v in zip(two.state_dict(), [t.clone() for t in FeatureEncoder(2, G, 3).state_dict().values()])})
+    one = FeatureEncoder(2, G, 3)
+    one.load_state_dict(two.state_dict())
+    two.train(), one.train()
+    two(full), two(full)
+    one(full, bn_updates=2)
+    for (k, v), v1 in zip(two.state_dict().items(), one.state_dict().values()):
+        assert torch.allclose(v.float(), v1.float(), atol=1e-6), k
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_row_layout_and_gather_rows(world):
+    port = 33500 + os.getpid() % 2000 + world
+    mp.spawn(_rows_worker, args=(world, port), nprocs=world, join=True)

@@ -29,6 +29,9 @@ def test_single_gpu_line_has_roofline_and_m1():
     assert line['also']['m1']['value'] > 0 and 0 < line['also']['m1']['roofline']['frac'] < 1
     ts = line['also']['train_step']                      # the whole training step, timed in a child process
     assert 'error' not in ts and 5 < ts['ms_per_step'] < 60, ts
+    # ... and the data-parallel code path on a 1-rank RCCL group: every collective inside the graph, at most 15 % slower
+    dp = ts['data_parallel_path_1rank']
+    assert 'error' not in dp and dp['statistic_all_reduces_in_graph'] == 132 and dp['ms_per_step'] < 1.15 * ts['ms_per_step'], ts
 
 
 def test_gpus_2_spawns_itself_and_reports_the_aggregate():
@@ -37,3 +40,12 @@ def test_gpus_2_spawns_itself_and_reports_the_aggregate():
     # value = points of BOTH ranks / max-over-ranks time
     pts = 2 * line['config']['per_gpu_batch'] * line['config']['points_per_shape'] * line['config']['components']
     assert abs(line['value'] - pts / (line['ms_per_step'] * 1e-3) / 1e6) / line['value'] < 1e-2
+
+
+def test_gpus_2_training_step_record_rehearsal():
+    """bench.py --gpus 2 also times the data-parallel training step (one child per rank, the children form their own group):
+    rehearsed on the one card over gloo (eager step: gloo's collectives are host-side, nothing to capture)."""
+    line = _run(['--gpus', '2', '--backend', 'gloo', '--share-device', '--also-select', 'train_step'])
+    ts = line['also']['train_step']
+    for label, b in (('global_batch_64', 32), ('per_rank_batch_64', 64)):
+        assert 'error' not in ts[label] and ts[label]['per_rank_batch'] == b and ts[label]['ms_per_step'] > 0, ts

@@ -238,6 +238,16 @@ def test_two_rank_whole_model_training_step_matches_single_process(tmp_path):
     assert r.returncode == 0 and 'MODEL2' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
 
 
+def test_data_parallel_training_step_is_one_hipgraph_with_every_collective_inside():
+    """the multi-rank step (phase-split pipeline + 4C packed statistic all-reduces + row all-gathers + overlapped
+    gradient all-reduce) captured in ONE hipGraph over RCCL (1-rank nccl group, GWTF_FORCE_SHARDED=1) == the plain eager step."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), 'rccl_graph_worker.py')],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'GRAPH1 ok' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
 def test_eval_after_training_steps_sees_every_update():
     """Parameters are written through raw pointers by the fused optimiser and running statistics by the pointer-table kernel: every
     packed-weight cache must notice.  Two training steps, then an eval pass == the eval pass of a FRESH model loaded from the

@@ -4,8 +4,14 @@ decoders resolve to 11 Triples x f=37, G=128, B=64 x N=2048) on one MI355X: enco
 (batch-statistic BatchNorm) + mixture NLL + backward + fused Adam.  GPU box only.
 
     python tools/bench_train.py [--batch 64] [--steps 5] [--graph]
+
+Data parallel: started once per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment (torch.distributed.run, or
+bench.py's own per-rank children) it joins an RCCL process group, converts the model to SyncBatchNorm (train_ae.py:152) and runs
+the sharded step -- statistic all-reduces, row all-gathers and the overlapped gradient exchange all inside the one hipGraph;
+--batch is the PER-RANK batch.  GWTF_FORCE_SHARDED=1 takes that path on a 1-rank group (one-GPU box).
 """
 import argparse
+import os
 import sys
 import time
 
@@ -26,10 +32,24 @@ ap.add_argument('--api', default='fused', choices=['fused', 'list', 'both'],
                      "both: fused, then a second graph of the list call in the same process")
 ap.add_argument('--lib', default=None, help='A/B: load this build of libgwtf_hip.so instead of the in-tree one')
 ap.add_argument('--parts', default='epd', help='debug: which parts run (e=encoder, p=prior flow, d=decoders)')
+ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend of a data-parallel run (nccl = RCCL)')
+ap.add_argument('--share-device', action='store_true', help='rehearsal: every rank uses cuda:0 (needs --backend gloo; no graph)')
 a = ap.parse_args()
 if a.lib:
     from go_with_the_flows_amd import _lib
     _lib.LIB_PATH = a.lib
+WORLD, RANK = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+FORCED = os.environ.get('GWTF_FORCE_SHARDED') == '1'
+torch.cuda.set_device(0 if a.share_device else int(os.environ.get('LOCAL_RANK', '0')))
+if WORLD > 1 or FORCED:
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', str(29900 + os.getpid() % 90))
+    if a.backend == 'nccl':
+        dist.init_process_group('nccl', rank=RANK, world_size=WORLD, device_id=torch.device('cuda', torch.cuda.current_device()))
+    else:
+        dist.init_process_group('gloo', rank=RANK, world_size=WORLD)
+say = print if RANK == 0 else (lambda *x, **k: None)
 
 CFG = dict(train_mode='p_rnvp_mc_g_rnvp_vae', util_mode='training', deterministic=False,
            pc_enc_init_n_channels=3, pc_enc_init_n_features=64, pc_enc_n_features=[128, 256, 512],
@@ -40,13 +60,18 @@ CFG = dict(train_mode='p_rnvp_mc_g_rnvp_vae', util_mode='training', deterministi
            pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0)
 torch.manual_seed(0)
 model = models.Flow_Mixture_Model(**CFG).cuda().train()
+if WORLD > 1 or FORCED:
+    model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)          # train_ae.py:152
 crit = models.Flow_Mixture_Loss(**CFG)
 opt = optim.Adam(model.parameters(), lr=2.56e-4, betas=(0.9, 0.999), weight_decay=1e-5, amsgrad=True)
 n_params = sum(p.numel() for p in model.parameters())
-print(f'decoders: {len(model.pc_decoder)} x ({model.pc_decoder[0].n_flows} Triples, f={model.pc_decoder[0].f_n_features}); '
+say(f'decoders: {len(model.pc_decoder)} x ({model.pc_decoder[0].n_flows} Triples, f={model.pc_decoder[0].f_n_features}); '
       f'{n_params / 1e6:.2f} M parameters')
-g_in = torch.from_numpy(synth_inputs(a.batch, a.points, 4, 1)[0]).cuda()
-p_in = torch.from_numpy(synth_inputs(a.batch, a.points, 4, 2)[0]).cuda()
+g_in = torch.from_numpy(synth_inputs(a.batch, a.points, 4, 1 + 10 * RANK)[0]).cuda()          # every rank its own shapes
+p_in = torch.from_numpy(synth_inputs(a.batch, a.points, 4, 2 + 10 * RANK)[0]).cuda()
+from go_with_the_flows_amd import autograd as gwa
+from go_with_the_flows_amd.dist import OverlappedGradients, graph_capture, sharded
+reducer = OverlappedGradients(model) if sharded() else None
 
 
 g_fix = torch.randn(a.batch, CFG['g_latent_space_size'], device='cuda')
@@ -80,7 +105,11 @@ def fwd_bwd():
             mu0 = torch.zeros(4, a.batch, 3, device='cuda'); lv0 = torch.zeros(4, a.batch, 3, device='cuda')
             from go_with_the_flows_amd.mixture import flow_mixture_nll
             loss = loss + flow_mixture_nll(z, ld, mu0, lv0, model.get_weights(g_fix))[0]
-    loss.backward()
+    if reducer is not None:
+        with reducer:              # the gradient exchange: one asynchronous all-reduce per decoder from inside the backward + a remainder
+            loss.backward()
+    else:
+        loss.backward()
     return loss
 
 
@@ -92,20 +121,27 @@ def step():
 
 def timed(fn, n):
     torch.cuda.synchronize()
+    if WORLD > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n * 1e3
+    dt = torch.tensor([(time.perf_counter() - t0) / n * 1e3], dtype=torch.float64, device='cuda' if a.backend == 'nccl' else 'cpu')
+    if WORLD > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)          # the slowest rank's time
+    return float(dt)
 
 
 for _ in range(2):
     l = step()
-print('loss after warm-up', float(l.detach()))
+say('loss after warm-up', float(l.detach()))
 del l                       # keep no reference to an autograd graph across iterations (hipGraph capture needs that)
 ms = timed(step, a.steps)
-pts = a.batch * a.points
-print(f'eager   : {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s (each point through all {CFG["n_components"]} components)')
+pts = a.batch * a.points * WORLD
+say(f'ranks: {WORLD}  per-rank batch: {a.batch}  sharded path: {sharded()}')
+say(f'eager   : {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s (each point through all {CFG["n_components"]} components)')
 if a.graph:
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -115,14 +151,16 @@ if a.graph:
     torch.cuda.current_stream().wait_stream(s)
     graph = torch.cuda.CUDAGraph()
     opt.zero_grad(set_to_none=True)
-    with torch.cuda.graph(graph):
+    gwa.COLLECTIVES['n'] = 0
+    with graph_capture(graph):
         fwd_bwd()          # the optimiser stays outside: its bias corrections depend on the host-side step count
+    say(f'statistic all-reduces captured in the graph: {gwa.COLLECTIVES["n"]}')
 
     def replay_step():
         graph.replay()
         opt.step()
     ms = timed(replay_step, a.steps)
-    print(f'hipGraph: {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s')
+    say(f'hipGraph: {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s')
     if a.api == 'both':
         API[0] = 'list'
         with torch.cuda.stream(s):
@@ -131,11 +169,14 @@ if a.graph:
         torch.cuda.current_stream().wait_stream(s)
         graph_list = torch.cuda.CUDAGraph()
         opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph_list):
+        with graph_capture(graph_list):
             fwd_bwd()
 
         def replay_list():
             graph_list.replay()
             opt.step()
         ms = timed(replay_list, a.steps)
-        print(f'hipGraph list API: {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s')
+        say(f'hipGraph list API: {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s')
+if WORLD > 1 or FORCED:
+    dist.barrier()
+    dist.destroy_process_group()
