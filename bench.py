@@ -381,7 +381,7 @@ def main():
             dist.init_process_group('nccl', device_id=dev)   # RCCL; used only for the barrier + max-over-ranks
         else:
             dist.init_process_group('gloo')
-    _lib.lib().gwtf_debug_set_points_per_wave(args.points_per_wave)
+    _lib.set_tuning(args.points_per_wave)
 
     def sync_all():
         torch.cuda.synchronize(dev)

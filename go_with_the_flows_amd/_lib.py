@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgwtf_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 MODE_DIRECT, MODE_INVERSE = 0, 1
 STAT_REPLICAS = 64   # GWTF_STAT_REPLICAS in csrc/gwtf_layout.h
@@ -32,15 +32,16 @@ _SIGNATURES = {
                                          ctypes.c_int, ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_film_bn_swish_forward': (ctypes.c_int, [_c_fp] * 3 + [ctypes.c_long] * 3 + [ctypes.c_int] * 3 + [_c_fp] * 5),
     'gwtf_film_bn_swish_backward': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_long] * 3 + [ctypes.c_int] * 3 + [_c_fp] * 6),
-    'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_stack_forward_multi': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
-                                 [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_fp]),
+                                 [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, _c_fp]),
+    'gwtf_stack_plan': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]),
     'gwtf_train_moments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_train_fold0': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_train_stats': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_stats': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
     'gwtf_train_fold1': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, _c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
-    'gwtf_train_apply': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
-    'gwtf_train_forward': (ctypes.c_int, [_c_fp] * 14 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_train_apply': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_train_forward': (ctypes.c_int, [_c_fp] * 14 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_pack_w1t': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_train_coupling_backward': (ctypes.c_int, [_c_fp] * 21 + [ctypes.c_int] * 7 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_packed_b_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
@@ -70,7 +71,6 @@ _SIGNATURES = {
     'gwtf_encoder_packed_floats': (ctypes.c_size_t, [_c_fp, ctypes.c_int]),
     'gwtf_encoder_pack': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_encoder_forward': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int, ctypes.c_int, _c_fp, ctypes.c_int, _c_fp]),
-    'gwtf_debug_set_points_per_wave': (None, [ctypes.c_int]),
     'gwtf_enc_train_supported': (ctypes.c_int, [_c_fp, ctypes.c_int]),
     'gwtf_enc_train_units_floats': (ctypes.c_size_t, [ctypes.c_int]),
     'gwtf_enc_train_pack': (ctypes.c_int, [_c_fp] * 3 + [ctypes.c_int, _c_fp]),
@@ -108,13 +108,45 @@ PHASE_FWD_INIT, PHASE_FWD_A, PHASE_FWD_B, PHASE_BWD_A, PHASE_BWD_B, PHASE_BWD_C 
 
 class TrainCtx(ctypes.Structure):
     """GwtfTrainCtx of include/gwtf.h (K-batched, phase-split train pipeline): same field order."""
-    _fields_ = ([(n, ctypes.c_int) for n in ('K', 'B', 'N', 'C', 'f', 'G', 'pattern0', 'mode')] +
+    _fields_ = ([(n, ctypes.c_int) for n in ('K', 'B', 'N', 'C', 'f', 'G', 'pattern0', 'mode', 'tune')] +
                 [('eps', ctypes.c_float), ('n_total', ctypes.c_double)] +
                 [(n, ctypes.c_void_p) for n in (
                     'p', 'raw', 'packed_w', 'packed_b', 'film_raw', 'film_rec', 'moments', 'ystats', 'bn_batch', 'xbuf',
                     'logdet', 'ps', 'mus', 'logvars', 'g_out', 'g_ld', 'g_ps', 'g_lvs', 'g_bufs', 'g_xa', 'g_xb', 'dw1_ws', 'g_film', 'g_sd0',
                     'g_bias', 'g_stats', 'g_mom', 'g_film_raw', 'g_raw', 'stream')])
 EXPORTS = tuple(_SIGNATURES)
+
+# ---- per-call tuning word (include/gwtf.h GWTF_TUNE_*) ------------------------------------------------------------------------
+# The library keeps no tuning state: every dispatching entry point takes the word as an argument.  The HOST side keeps the value
+# the wrappers pass -- 0 unless a test / calibration tool changes it inside `with tuning(...)` (restored on exit, also on an
+# exception).
+TUNE_GENERIC_BODY, TUNE_SMALL_LIGHT_TILE, TUNE_SINGLE_TILE = 1 << 30, 1 << 29, 1 << 28
+_TUNE = [0]
+
+
+def tune_word():
+    return _TUNE[0]
+
+
+def set_tuning(word=0):
+    """Set the tuning word the wrappers pass from now on (tests: an autouse fixture resets it); prefer `with tuning(...)`."""
+    _TUNE[0] = int(word)
+
+
+class tuning:
+    """with tuning(points_per_wave=64, generic_body=True): ...   -- tile size / coupling body forced for the calls inside."""
+
+    def __init__(self, points_per_wave=0, generic_body=False, small_light_tile=False, word=None):
+        self.word = (int(points_per_wave) & 0xffff) | (TUNE_GENERIC_BODY if generic_body else 0) | \
+            (TUNE_SMALL_LIGHT_TILE if small_light_tile else 0) if word is None else int(word)
+
+    def __enter__(self):
+        self.saved, _TUNE[0] = _TUNE[0], self.word
+        return self
+
+    def __exit__(self, *exc):
+        _TUNE[0] = self.saved
+        return False
 
 _lib = None
 
@@ -209,7 +241,7 @@ def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists):
     with torch.cuda.device(p.device):
         check(L.gwtf_stack_forward(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
                                    _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], B, N, C, f, pattern0, float(eps),
-                                   _MODES[mode], _stream(p)))
+                                   _MODES[mode], _TUNE[0], _stream(p)))
     return out, logdet, lists
 
 
@@ -240,7 +272,7 @@ def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segment
     with torch.cuda.device(p.device):
         check(L.gwtf_stack_forward_multi(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
                                          _ptr(logdet, 'logdet'), None, None, None, seg, K, B, N, C, f, pattern0,
-                                         float(eps), _MODES[mode], 0, stride, _stream(p)))
+                                         float(eps), _MODES[mode], 0, stride, _TUNE[0], _stream(p)))
     return out, logdet
 
 
@@ -304,9 +336,20 @@ def train_forward(p, g, raw, C, f, G, pattern0, eps, mode, want_lists):
         check(L.gwtf_train_forward(_ptr(p, 'p'), _ptr(raw, 'raw'), pw.data_ptr(), None, film_raw.data_ptr(), mom.data_ptr(),
                                    ystats.data_ptr(), bn_batch.data_ptr(), film_rec.data_ptr(), xbuf.data_ptr(),
                                    logdet.data_ptr(), lp[0], lp[1], lp[2], B, N, C, f, G, pattern0, float(eps),
-                                   _MODES[mode], st))
+                                   _MODES[mode], _TUNE[0], st))
         out = xbuf[(C - 1) & 1]
         # per-shape FiLM BatchNorms: biased batch var -> unbiased
         bn_batch[:, :, 2:4, 0, :] = fstats[:, :, :, 0, :]
         bn_batch[:, :, 2:4, 1, :] = fstats[:, :, :, 1, :] * (B / (B - 1.0))
     return out, logdet, lists, bn_batch
+
+
+def stack_plan(K, B, N, f, segments=None, word=None):
+    """The tile plan gwtf_stack_forward* would use (no launch): (points per wave, workgroups) -- host-only, works without a GPU."""
+    seg = None
+    if segments is not None:
+        flat = [int(v) for be in segments for v in be]
+        seg = (ctypes.c_int * len(flat))(*flat)
+    out = (ctypes.c_int * 4)()
+    check(lib().gwtf_stack_plan(seg, K, B, N, f, _TUNE[0] if word is None else int(word), out))
+    return out[0], out[1]

@@ -285,7 +285,7 @@ class StatsFn(torch.autograd.Function):
         FP = L.gwtf_padded_width(f)
         ys = torch.zeros(_lib.STAT_REPLICAS, 2, FP, 2, device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
-            _lib.check(L.gwtf_train_stats(x.data_ptr(), pw.data_ptr(), ys.data_ptr(), B, N, f, pat, _lib._stream(x)))
+            _lib.check(L.gwtf_train_stats(x.data_ptr(), pw.data_ptr(), ys.data_ptr(), B, N, f, pat, _lib.tune_word(), _lib._stream(x)))
         ctx.save_for_backward(x, pw, pb)
         ctx.meta = (pat, f, FP)
         return ys.sum(0)[:, :f, :]
@@ -549,7 +549,7 @@ class TrainMixtureFn(torch.autograd.Function):
             _lib.check(L.gwtf_pack_w1t(raw.data_ptr(), pb.data_ptr(), K * C, f, G, _lib._stream(p)))
         t = _lib.TrainCtx()
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
-        t.eps, t.n_total = float(eps), float(n_total)
+        t.eps, t.n_total, t.tune = float(eps), float(n_total), _lib.tune_word()
         bufs = dict(moments=zeros(C + 1, K, R * 16), ystats=zeros(C, K, R * 2 * FP * 2), bn_batch=zeros(K, C, 2, 4, 2, f),
                     film_rec=new(B, K * C, FS), xbuf=new(2, K, B, 3, N), logdet=new(K, B, 3, N),
                     # the per-coupling inputs (ps) are what the backward recomputes from; mus / logvars only when the caller
@@ -605,7 +605,7 @@ class TrainMixtureFn(torch.autograd.Function):
         g_ld = (g_logdet if g_logdet is not None else zeros(K, B, 3, N)).contiguous().float()
         t = _lib.TrainCtx()
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
-        t.eps, t.n_total = eps, n_total
+        t.eps, t.n_total, t.tune = eps, n_total, _lib.tune_word()
         scratch = new(K, B, 3, N)
         bufs = dict(g_bufs=new(2, K, B, 3, N), g_xa=new(K, B, 3, N),
                     dw1_ws=new(K * L.gwtf_mtrain_dw1_floats(f, B, N)), g_film=zeros(B, K * C, 2, 3, FP),

@@ -7,7 +7,7 @@ extern "C" int gwtf_abi_version(void) { return GWTF_ABI_VERSION; }
 
 extern "C" const char* gwtf_error_string(int code) {
   if (code == 0) return "success";
-  if (code == GWTF_E_BADARG) return "gwtf: bad argument (null pointer, non-positive size, f > 64, bad mode/pattern, or B too large for train-mode FiLM)";
+  if (code == GWTF_E_BADARG) return "gwtf: bad argument (null pointer, non-positive size, width beyond what the kernels reach -- eval forward f <= 128, train / backward f <= 96 --, bad mode / pattern, or B too large for train-mode FiLM)";
   if (code == GWTF_E_UNSUPPORTED) return "gwtf: no kernel instantiation was built for this layer-width list";
   return hipGetErrorString((hipError_t)code);
 }

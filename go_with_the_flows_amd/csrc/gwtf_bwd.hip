@@ -22,7 +22,6 @@
 // reduction), and writes it to a per-workgroup partial that gwtf_dw1_reduce sums in a fixed order: nothing of size
 // O(B N f) is written to HBM any more (it was 100-150 MB per coupling).
 #include "gwtf_device.h"
-#include <cstdlib>
 #include "gwtf_dw1.h"
 
 namespace {
@@ -578,7 +577,7 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
   if constexpr (MB == 3 && (VAR == BW_LIGHT || VAR == BW_MERGED)) {
     // the train pipeline's two passes at the abs-form widths (f = 33..40): the forward recompute as one basic block (MG = 1)
     if (gwtf_abs_form(f)) {
-      static const bool small_tile_mg = getenv("GWTF_LIGHT_SMALL_TILE") != nullptr;   // diagnostic hook (tools/diag/light_tile_check.py)
+      const bool small_tile_mg = (ks.tune & GWTF_TUNE_SMALL_LIGHT_TILE) != 0;   // per-call diagnostic (tools/diag/light_tile_check.py)
       if (VAR == BW_LIGHT && nb == 2 && (long)B * N * K >= 256L * 1024 && !small_tile_mg) {
         const dim3 grid4((unsigned)(B * ((N + 255) / 256)), (unsigned)K);
         hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
@@ -591,7 +590,7 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
     }
   }
   if constexpr (VAR == BW_LIGHT && MB <= 3) {   // forward-sized pass: the forward kernel's tile (256 points per workgroup) where it fills the GPU
-    static const bool small_tile = getenv("GWTF_LIGHT_SMALL_TILE") != nullptr;      // diagnostic hook (tools/diag/light_tile_check.py)
+    const bool small_tile = (ks.tune & GWTF_TUNE_SMALL_LIGHT_TILE) != 0;      // per-call diagnostic (tools/diag/light_tile_check.py)
     if (nb == 2 && (long)B * N * K >= 256L * 1024 && !small_tile) {
       const dim3 grid4((unsigned)(B * ((N + 255) / 256)), (unsigned)K);
       hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);

@@ -204,6 +204,7 @@ GWTF_HD size_t gwtf_film_out_size(int FP) { return 6 * (size_t)FP + 4; }
 struct GwtfKS {
   size_t raw, pw, pb, x, pts, mom, ys, bn, gsd0, gbias, gstats, gmom, dw1;
   int Cper, Ctot;
+  int tune;      // the call's GWTF_TUNE_* word (include/gwtf.h), carried to every launcher of the pipeline
 };
 
 // warp pattern of coupling c in direct order (reference flows.py:129-148, decoders.py:49-52):

@@ -39,6 +39,33 @@ __device__ __forceinline__ float tail_scale(float eps, float logvar) { return __
 // reciprocal in a row -- one transcendental less on the coupling boundary's dependent chain, and none per coordinate
 __device__ __forceinline__ float tail_rscale(float eps, float logvar) { return __builtin_amdgcn_rsqf(eps + __expf(logvar)); }
 
+// Where the pieces of one staged coupling sit in LDS (floats).  Plain: the packed record as it is in global memory
+// (gwtf_layout.h GwtfPackW) followed by the shape's FiLM record.  COMPACT (merged widths f = 33..40, MB = 3): the packer leaves
+// the lo image of the second k-step unused there (its products ride in the merged hi image A'), so those MB pieces per branch
+// are neither copied nor given room:
+//     branch br at br * A16:  k-step 0 [m][part] (2 MB images)  |  k-step 1 hi / A' [m] (MB images)
+//     SD0 records at 2 * A16  |  FiLM record at FILM (whole 1-KiB DMA pieces before it)
+template <int MB, bool COMPACT>
+struct LdsLayout {
+  using K = Cfg<MB>;
+  static constexpr int A16 = COMPACT ? (2 * MB + MB) * 256 : K::A16;
+  static constexpr int SD0_BASE = 2 * A16;
+  static constexpr int FILM = COMPACT ? (2 * A16 + 2 * K::SD0 + 255) / 256 * 256 : K::PW;
+  static constexpr int LAYER = FILM + K::FSP;
+  static constexpr int PIECES = FILM / 256;               // 1-KiB DMA pieces of packed weights staged per coupling
+  __device__ static constexpr int img(int ks, int m, int part) {   // offset of fragment image (ks, m, part) inside a branch
+    return COMPACT ? (ks == 0 ? (m * 2 + part) * 256 : (2 * MB + m) * 256) : ((ks * MB + m) * 2 + part) * 256;
+  }
+  // destination piece d of the compact layout <- piece of the packed record in global memory
+  __device__ static int source_piece(int d) {
+    if (!COMPACT) return d;
+    constexpr int PB = 3 * MB, GB = 4 * MB;                // pieces per branch: compact, packed record
+    if (d >= 2 * PB) return 2 * GB + (d - 2 * PB);          // SD0 records
+    const int br = d >= PB ? 1 : 0, r = d - br * PB;
+    return br * GB + (r < 2 * MB ? r : 2 * MB + 2 * (r - 2 * MB));
+  }
+};
+
 // One elementary coupling on the wave's tile.  KEEP2 = two kept coordinates / one warped (patterns 0-2),
 // otherwise one kept / two warped (patterns 3-5).  Every VALU instruction here costs the SIMD 4 cycles that
 // the matrix pipe cannot use (measured: MFMA and VALU of two waves on one SIMD do not overlap,
@@ -144,6 +171,10 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   // of that k-step as gwtf_pack.hip writes it for these widths) -- 4 instead of 6 MFMAs per (m, point block) and 2 instead
   // of 6 filler moves per fragment.  (The legacy K=16 MFMA is no alternative: it costs the same 16 cycles, tools/diag/mfma_k16.hip.)
   constexpr bool MERGE = KS == 2 && NJL <= 2;
+  // LDS layout of the staged coupling.  Merged widths (MB = 3): the lo image of the second k-step is never read, so the stack
+  // kernel does not stage it (stack_kernel::stage, CompactLds below): 22 KiB per buffer instead of 28 -- THREE workgroups per
+  // compute unit instead of two.  Everything else reads the packed record's own layout (Cfg<MB>).
+  using LY = LdsLayout<MB, MERGE>;
   // PACK5: a single k-step with 5 valid k-slots per lane (f = 17..20) has 15 products for 16 k-slots of TWO MFMAs:
   //   B1 = [hi01 | hi23 | lo01 | lo23]        against  A1 = [Whi01 | Whi23 | Whi01 | Whi23]
   //   B2 = [(hi4, lo4) | hi01 | hi23 | (hi4, 0)]  against  A2 = [(Whi4, Whi4) | Wlo01 | Wlo23 | (Wlo4, 0)]
@@ -178,7 +209,7 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     const int per_ks = 4 * NB;
     const int ks = u / per_ks < KS - 1 ? u / per_ks : KS - 1;
     const int rem = u - ks * per_ks, jp = rem / NB, nb = rem % NB, j0 = 2 * jp;
-    const f32x4* sp = reinterpret_cast<const f32x4*>(L + 2 * K::A16 + br * K::SD0 + q * 24 + ks * 96);
+    const f32x4* sp = reinterpret_cast<const f32x4*>(L + LY::SD0_BASE + br * K::SD0 + q * 24 + ks * 96);
     const f32x4 wa = sp[j0 >> 2], wb = KEEP2 ? sp[2 + (j0 >> 2)] : f32x4{0.f, 0.f, 0.f, 0.f}, cc = sp[4 + (j0 >> 2)];
     const f32x2 wa2 = {wa[j0 & 3], wa[(j0 & 3) + 1]}, wb2 = {wb[j0 & 3], wb[(j0 & 3) + 1]}, cc2 = {cc[j0 & 3], cc[(j0 & 3) + 1]};
     const f32x2 xa2 = {xa[nb], xa[nb]}, xb2 = {xb[nb], xb[nb]};
@@ -222,8 +253,8 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
   auto triple = [&](int br, int t) {      // t-th (ks, m, nb) triplet of branch br
     const int ks = t / (MB * NB), m = (t / NB) % MB, nb = t % NB;
     const bool tr = RV < 4 && m == MB - 1;                       // transposed row tile
-    const float* aimg = L + br * K::A16 + (tr ? lane_t : lane) * 4;
-    const float* cb = L + K::PW + br * 3 * FP + 16 * m;
+    const float* aimg = L + br * LY::A16 + (tr ? lane_t : lane) * 4;
+    const float* cb = L + LY::FILM + br * 3 * FP + 16 * m;
     const f32x4 cinit = tr ? f32x4{cb[q], cb[4 + q], cb[8 + q], cb[12 + q]} : *reinterpret_cast<const f32x4*>(cb + 4 * q);
     if (PACK5) {
       const f32x2 ah = *reinterpret_cast<const f32x2*>(aimg + (m * 2 + 0) * 256);
@@ -237,12 +268,12 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
       return;
     }
     if (MERGE && ks == KS - 1) {
-      const f16x8 am = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);   // A', written by the packer
+      const f16x8 am = *reinterpret_cast<const f16x8*>(aimg + LY::img(ks, m, 0));   // A', written by the packer
       acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(am, bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
       return;
     }
-    const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 0) * 256);
-    const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + ((ks * MB + m) * 2 + 1) * 256);
+    const f16x8 ahi = *reinterpret_cast<const f16x8*>(aimg + LY::img(ks, m, 0));
+    const f16x8 alo = *reinterpret_cast<const f16x8*>(aimg + LY::img(ks, m, 1));
     acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, bhi[br][ks][nb], ks == 0 ? cinit : acc[br][m][nb], 0, 0, 0);
     acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi, blo[br][ks][nb], acc[br][m][nb], 0, 0, 0);
     acc[br][m][nb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo, bhi[br][ks][nb], acc[br][m][nb], 0, 0, 0);
@@ -260,7 +291,7 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     const int m = pc / 8, r = (pc / 2) % 4, h = pc % 2;
     const bool tr = RV < 4 && m == MB - 1;
     if (tr && r >= RV) return;                                   // padding in every lane
-    const float* fe = L + K::PW + br * 3 * FP + 16 * m + (tr ? 4 * r + q : 4 * q + r);
+    const float* fe = L + LY::FILM + br * 3 * FP + 16 * m + (tr ? 4 * r + q : 4 * q + r);
     const float u0 = fe[FP], u1 = KEEP2 ? 0.f : fe[2 * FP];
 #pragma unroll
     for (int nb = h * (NB / 2 > 0 ? NB / 2 : 1); nb < (NB >= 2 ? (h + 1) * (NB / 2) : (h == 0 ? 1 : 0)); ++nb) {
@@ -338,7 +369,7 @@ __device__ __forceinline__ void coupling_body_pipe(const float* __restrict__ L, 
     res[br][0] = quarter_reduce<NB>(o0[br], q);
     if (!KEEP2) res[br][1] = quarter_reduce<NB>(o1[br], q);
   }
-  const f32x4 bias = *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
+  const f32x4 bias = *reinterpret_cast<const f32x4*>(L + LY::FILM + 6 * FP);
   const float r_keep = __builtin_amdgcn_rcpf(s_keep);
   float lv_w[2] = {0.f, 0.f}, mu_w[2] = {0.f, 0.f}, sc_w[2] = {s_keep, s_keep};
 #pragma unroll
@@ -463,10 +494,13 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
                                                     int pattern0, float eps, int kk_steps, const Jobs jobs,
                                                     size_t p_stride_k, size_t out_stride_k, const Extras ex) {
   using K = Cfg<MB>;
+  // the pipelined body of the merged widths (MB = 3, NJL = 1 / 2: f = 33..40) reads the compact LDS layout (LdsLayout above):
+  // 45 KiB of double buffer per workgroup -> three workgroups per compute unit
+  using LY = LdsLayout<MB, (NJL > 0 && K::KS == 2 && NJL <= 2)>;
   // double buffer while two layers fit the 160 KiB of LDS (f <= 96); wider stacks (f = 97..128: 121 / 138 KiB per layer) stage
   // a coupling, compute, and only then stage the next (the weight DMA is exposed: the widths no shipped config uses)
-  constexpr int NBUF = 2 * K::LAYER * 4 <= 160 * 1024 - 512 ? 2 : 1;
-  __shared__ __align__(16) float lds[NBUF][K::LAYER];
+  constexpr int NBUF = 2 * LY::LAYER * 4 <= 160 * 1024 - 512 ? 2 : 1;
+  __shared__ __align__(16) float lds[NBUF][LY::LAYER];
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int q = lane >> 4, i16 = lane & 15;
@@ -513,15 +547,15 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     const float* src_f = film + ((size_t)b * KC + (size_t)comp * C + c) * K::FS;
     const unsigned voff = lane * 16u;
 #pragma unroll
-    for (int i = 0; i < (K::PW / 256 + 3) / 4; ++i) {
-      const int piece = wave + 4 * i;
-      if (piece < K::PW / 256)
-        __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(src_w + piece * 256) + voff),
+    for (int i = 0; i < (LY::PIECES + 3) / 4; ++i) {
+      const int piece = wave + 4 * i;                        // destination piece; its source piece skips what is not staged
+      if (piece < LY::PIECES)
+        __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(src_w + LY::source_piece(piece) * 256) + voff),
                                          (lds_void*)&lds[buf][piece * 256], 16, 0, 0);
     }
     if (wave < K::FSP / 256 && wave * 256 + lane * 4 < K::FS)
       __builtin_amdgcn_global_load_lds((glb_void*)(reinterpret_cast<const char*>(src_f + wave * 256) + voff),
-                                       (lds_void*)&lds[buf][K::PW + wave * 256], 16, 0, 0);
+                                       (lds_void*)&lds[buf][LY::FILM + wave * 256], 16, 0, 0);
   };
 
   // this lane's own point (one per lane) and the per-quarter copies used to build the MFMA B operand
@@ -653,12 +687,10 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   }
 }
 
-extern int g_pipe;
-
 template <int MB, int NB>
 int launch(const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps, float* mus,
            float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps, const int* segs, int K,
-           size_t p_stride_k, size_t out_stride_k, const Extras& ex, hipStream_t st) {
+           size_t p_stride_k, size_t out_stride_k, const Extras& ex, bool pipe, hipStream_t st) {
   Jobs jobs;
   jobs.K = K;
   jobs.tiles_cum[0] = 0;
@@ -689,7 +721,7 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
     }                                                                                                                       \
     return (int)hipGetLastError();                                                                                          \
   }
-  if (g_pipe) {
+  if (pipe) {
     if constexpr (MB == 4 && NB <= 2) { GWTF_PIPED(8) }
     if constexpr (MB == 3) { GWTF_PIPED(2) GWTF_PIPED(1) }
     if constexpr (MB == 2) { GWTF_PIPED(5) }
@@ -707,33 +739,82 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
 template <int MB>
 int launch_nb(int nb, const float* p, const float* pw, const float* film, float* out, float* logdet, float* ps,
               float* mus, float* lvs, int B, int N, int C, int pattern0, float eps, int mode, int kk_steps,
-              const int* segs, int K, size_t p_stride_k, size_t out_stride_k, const Extras& ex, hipStream_t st) {
+              const int* segs, int K, size_t p_stride_k, size_t out_stride_k, const Extras& ex, bool pipe, hipStream_t st) {
   if constexpr (MB > 4) {      // f > 64: one workgroup per compute unit anyway (LDS); 16 or 32 points per wave keep the accumulators in registers
-    if (nb == 1) return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
-    return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
+    if (nb == 1) return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, pipe, st);
+    return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, pipe, st);
   } else {
   switch (nb) {
-    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
-    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
-    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, st);
+    case 1: return launch<MB, 1>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, pipe, st);
+    case 2: return launch<MB, 2>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, pipe, st);
+    default: return launch<MB, 4>(p, pw, film, out, logdet, ps, mus, lvs, B, N, C, pattern0, eps, mode, kk_steps, segs, K, p_stride_k, out_stride_k, ex, pipe, st);
   }
   }
 }
 
-int g_force_nb = 0;  // test/tuning hook, see gwtf_debug_set_points_per_wave
-int g_pipe = 1;      // test hook: 0 forces the generic (run-time k-slot count) coupling body
+// ---- tile choice -------------------------------------------------------------------------------------------------------------
+// A workgroup carries 64 * NB points of one (shape, component).  The kernel is latency-bound while a compute unit holds one
+// workgroup and issue-bound from two on, so what a launch costs is a matter of ROUNDS.  Measured on the MI355X
+// (tools/diag/tile_rounds.py, profiles/r13_tile_rounds.txt: one component x 33 couplings, microseconds): with W workgroups a
+// compute unit holds ceil(W / 256) of them up to its limit S (LDS / VGPRs: 2 for the widest tiles, 3-4 below), and
+//     time(NB, W) = (W div 256 S) * level[S] + level[ceil((W mod 256 S) / 256)]
+// reproduces the measurements to +-8 %.  Small tiles are cheap per round but dear per POINT (f = 33: 16 points per wave move a
+// quarter of the points of 64 per wave for 45 % of its round), so the chooser prices every tile and takes the cheapest; the rule
+// it replaces looked at the point count alone (16 points per wave for everything below 64 K points: 93 us against 78 for
+// 24 x 2048 points at f = 33).  What no tile can fix is quantisation: 640 large workgroups (the SVR shard) are 1.25 rounds of
+// 512 and cost 1.45 rounds, and a second launch with small tiles for the remainder cannot overlap the first.
+struct TileCost { int slots; float level[4]; };     // cost of a round with 1 .. slots workgroups per compute unit
+inline TileCost tile_cost(int MB, int nbi /* 0 / 1 / 2 = NB 1 / 2 / 4 */) {
+  static const TileCost T[4][3] = {
+      /* MB 1 (f <= 16) */ {{4, {31.f, 38.f, 46.f, 55.f}}, {4, {39.f, 49.f, 61.f, 75.f}}, {4, {52.f, 72.f, 96.f, 119.f}}},
+      /* MB 2 (f <= 32) */ {{4, {36.f, 44.f, 54.f, 66.f}}, {4, {40.f, 54.f, 69.f, 87.f}}, {4, {54.f, 79.f, 112.f, 148.f}}},
+      /* MB 3 (f <= 48) */ {{3, {45.f, 60.f, 79.f, 0.f}}, {3, {55.f, 82.f, 116.f, 0.f}}, {2, {82.f, 140.f, 0.f, 0.f}}},
+      /* MB 4 (f <= 64) */ {{2, {60.f, 84.f, 0.f, 0.f}}, {2, {85.f, 133.f, 0.f, 0.f}}, {2, {165.f, 249.f, 0.f, 0.f}}}};
+  return T[MB < 1 ? 0 : (MB > 4 ? 3 : MB - 1)][nbi];   // MB > 4: NB <= 2 only, same ratios as MB 4
+}
+inline float launch_cost(const TileCost& tc, long W) {
+  if (W <= 0) return 0.f;
+  const long round = 256L * tc.slots, full = W / round, rem = W % round;
+  return (float)full * tc.level[tc.slots - 1] + (rem == 0 ? 0.f : tc.level[(rem + 255) / 256 - 1]);
+}
+// workgroups of a launch at NB over K segments of B shapes
+inline long tiles_of(const int* segments, int K, int B, int N, int nb) {
+  long W = 0;
+  for (int k = 0; k < K; ++k) {
+    const int cnt = segments ? segments[2 * k + 1] - segments[2 * k] : N;
+    W += (long)B * ((cnt + 64 * nb - 1) / (64 * nb));
+  }
+  return W;
+}
+inline int choose_nb(const int* segments, int K, int B, int N, int f, int tune) {
+  const int forced = (tune & 0xffff) / 16;
+  if (forced == 1 || forced == 2 || forced == 4) return (f > 64 && forced > 2) ? 2 : forced;
+  const int MB = gwtf_padded_width(f) / 16;
+  int best = 1;
+  float best_cost = 0.f;
+  for (int nbi = (f > 64 ? 1 : 2); nbi >= 0; --nbi) {          // larger tiles first: they win ties (fewer workgroups)
+    const int nb = 1 << nbi;
+    const float cst = launch_cost(tile_cost(MB, nbi), tiles_of(segments, K, B, N, nb));
+    if (nbi == (f > 64 ? 1 : 2) || cst < 0.97f * best_cost) { best = nb; best_cost = cst; }
+  }
+  return best;
+}
 
 }  // namespace
 
-extern "C" void gwtf_debug_set_points_per_wave(int pts) {   // bit 30 set: also force the generic coupling body
-  g_pipe = (pts & (1 << 30)) ? 0 : 1;
-  g_force_nb = (pts & 0xffff) / 16;
+extern "C" int gwtf_stack_plan(const int* segments, int K, int B, int N, int f, int tune, int* out4) {
+  if (!out4 || K <= 0 || K > GWTF_MAX_COMPONENTS || B <= 0 || N <= 0 || f <= 0 || f > GWTF_MAX_FP) return GWTF_E_BADARG;
+  const int nb = choose_nb(segments, K, B, N, f, tune);
+  out4[0] = 16 * nb;
+  out4[1] = (int)tiles_of(segments, K, B, N, nb);
+  out4[2] = out4[3] = 0;              // no tail launch: measured, a second (small-tile) launch cannot overlap the first -- DESIGN.md
+  return 0;
 }
 
 static int stack_dispatch(const float* p, const float* packed_w, const float* film, float* out, float* logdet, float* ps,
                           float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,
                           int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, const Extras& ex,
-                          void* stream) {
+                          int tune, void* stream) {
   if (B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || K <= 0 || K > GWTF_MAX_COMPONENTS || !p ||
       !packed_w || !film || !out || !logdet)
     return GWTF_E_BADARG;
@@ -749,12 +830,20 @@ static int stack_dispatch(const float* p, const float* packed_w, const float* fi
     pts += (long)B * (e0 - b0);
   }
   hipStream_t st = (hipStream_t)stream;
-  // points per wave: the largest tile that still gives each of the 1024 SIMDs two waves
-  int nb = g_force_nb;
-  if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
-  if (f > 64 && nb > 2) nb = 2;
+  // points per wave.  Whole-stack launches: the tile whose rounds x round cost is smallest (choose_nb).  One-coupling launches of
+  // the train pipeline (ex.c_count == 1) are latency-bound per launch whatever the tile: the largest tile that still gives each
+  // of the 1024 SIMDs two waves.
+  int nb;
+  const int forced = (tune & 0xffff) / 16;
+  if (ex.c_count == 0 || forced == 1 || forced == 2 || forced == 4) {
+    nb = choose_nb(segments, K, B, N, f, tune);
+  } else {
+    nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
+    if (f > 64 && nb > 2) nb = 2;
+  }
+  const bool pipe = !(tune & GWTF_TUNE_GENERIC_BODY);
   const int kk_steps = (f + 3) / 4;
-#define GWTF_ARGS nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, segments, K, p_stride_k, out_stride_k, ex, st
+#define GWTF_ARGS nb, p, packed_w, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk_steps, segments, K, p_stride_k, out_stride_k, ex, pipe, st
   switch (gwtf_padded_width(f) / 16) {
     case 1: return launch_nb<1>(GWTF_ARGS);
     case 2: return launch_nb<2>(GWTF_ARGS);
@@ -772,10 +861,10 @@ static int stack_dispatch(const float* p, const float* packed_w, const float* fi
 extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float* film, float* out,
                                         float* logdet, float* ps, float* mus, float* logvars, const int* segments,
                                         int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
-                                        size_t p_stride_k, size_t out_stride_k, void* stream) {
+                                        size_t p_stride_k, size_t out_stride_k, int tune, void* stream) {
   const Extras ex = {0, 0, nullptr, nullptr, 0};
   return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, segments, K, B, N, C, f, pattern0, eps, mode,
-                        p_stride_k, out_stride_k, ex, stream);
+                        p_stride_k, out_stride_k, ex, tune, stream);
 }
 
 // One elementary coupling of the stack (train-mode pipeline: BatchNorm statistics are only known coupling by
@@ -784,10 +873,10 @@ extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, c
 extern "C" int gwtf_train_apply(const float* p, const float* packed_w, const float* film, float* out,
                                 const float* logdet_in, float* logdet, float* ps, float* mus, float* logvars,
                                 float* moments_out, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
-                                void* stream) {
+                                int tune, void* stream) {
   const Extras ex = {c, 1, logdet_in, moments_out, 0};
   return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, 1, B, N, C, f, pattern0, eps, mode, 0, 0,
-                        ex, stream);
+                        ex, tune, stream);
 }
 
 // One coupling of K stacks in one launch (K-batched train pipeline, gwtf_train.hip): component k reads p + k * p_stride_k,
@@ -795,17 +884,17 @@ extern "C" int gwtf_train_apply(const float* p, const float* packed_w, const flo
 int gwtf_internal_apply_k(const float* p, const float* packed_w, const float* film, float* out, const float* logdet_in,
                           float* logdet, float* ps, float* mus, float* logvars, float* moments_out, size_t moments_stride_k,
                           int c, int K, int B, int N, int C, int f, int pattern0, float eps, int mode, size_t p_stride_k,
-                          size_t out_stride_k, void* stream) {
+                          size_t out_stride_k, int tune, void* stream) {
   const Extras ex = {c, 1, logdet_in, moments_out, moments_stride_k};
   return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, K, B, N, C, f, pattern0, eps, mode,
-                        p_stride_k, out_stride_k, ex, stream);
+                        p_stride_k, out_stride_k, ex, tune, stream);
 }
 
 extern "C" int gwtf_stack_forward(const float* p, const float* packed_w, const float* film, float* out, float* logdet,
                                   float* ps, float* mus, float* logvars, int B, int N, int C, int f, int pattern0,
-                                  float eps, int mode, void* stream) {
+                                  float eps, int mode, int tune, void* stream) {
   return gwtf_stack_forward_multi(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, 1, B, N, C, f, pattern0, eps,
-                                  mode, 0, 0, stream);
+                                  mode, 0, 0, tune, stream);
 }
 
 namespace {
@@ -835,11 +924,11 @@ int launch_stats(int nb, const float* p, const float* pw_c, float* ystats, int B
 
 // statistics pass of one coupling of K stacks (component k: p + k*p_sk, packed_w_c + k*pw_sk, ystats + k*ys_sk)
 int gwtf_internal_stats_k(const float* p, const float* packed_w_c, float* ystats, int K, int B, int N, int f, int pattern,
-                          size_t p_sk, size_t pw_sk, size_t ys_sk, void* stream) {
+                          size_t p_sk, size_t pw_sk, size_t ys_sk, int tune, void* stream) {
   if (B <= 0 || N <= 0 || K <= 0 || f <= 0 || f > GWTF_MAX_FP_TRAIN || pattern < 0 || pattern > 5 || !p || !packed_w_c || !ystats)
     return GWTF_E_BADARG;
   const long pts = (long)B * N * K;
-  int nb = g_force_nb;
+  int nb = (tune & 0xffff) / 16;
   if (nb != 1 && nb != 2 && nb != 4) nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
   if (f > 64 && nb > 2) nb = 2;
   const int kk_steps = (f + 3) / 4;
@@ -856,6 +945,6 @@ int gwtf_internal_stats_k(const float* p, const float* packed_w_c, float* ystats
 }
 
 extern "C" int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats, int B, int N, int f, int pattern,
-                                void* stream) {
-  return gwtf_internal_stats_k(p, packed_w_c, ystats, 1, B, N, f, pattern, 0, 0, 0, stream);
+                                int tune, void* stream) {
+  return gwtf_internal_stats_k(p, packed_w_c, ystats, 1, B, N, f, pattern, 0, 0, 0, tune, stream);
 }

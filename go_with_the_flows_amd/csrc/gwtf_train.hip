@@ -187,11 +187,11 @@ extern "C" int gwtf_train_moments(const float* p, float* moments, int B, int N, 
 
 // internal K-batched pieces defined in gwtf_stack.hip / gwtf_bwd.hip
 int gwtf_internal_stats_k(const float* p, const float* packed_w_c, float* ystats, int K, int B, int N, int f, int pattern,
-                          size_t p_sk, size_t pw_sk, size_t ys_sk, void* stream);
+                          size_t p_sk, size_t pw_sk, size_t ys_sk, int tune, void* stream);
 int gwtf_internal_apply_k(const float* p, const float* packed_w, const float* film, float* out, const float* logdet_in,
                           float* logdet, float* ps, float* mus, float* logvars, float* moments_out, size_t moments_stride_k,
                           int c, int K, int B, int N, int C, int f, int pattern0, float eps, int mode, size_t p_stride_k,
-                          size_t out_stride_k, void* stream);
+                          size_t out_stride_k, int tune, void* stream);
 int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                       const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film,
                                       float* g_sd0, float* g_bias, int c, int K, int B, int N, int f, int pattern0, float eps,
@@ -663,6 +663,7 @@ GwtfKS strides_of(const GwtfTrainCtx* t, const Dims& d, bool first_level) {
   ks.dw1 = dw1_region(t);
   ks.Cper = t->C;
   ks.Ctot = t->K * t->C;
+  ks.tune = t->tune;
   return ks;
 }
 bool ctx_ok(const GwtfTrainCtx* t, bool backward) {
@@ -705,7 +706,7 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
       hipLaunchKernelGGL(fold0_kernel, dim3(K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, mom, t->n_total, pat,
                          t->packed_w + (size_t)c * d.PW, t->packed_b ? t->packed_b + (size_t)c * d.PB : nullptr,
                          t->bn_batch + (size_t)c * d.BS, f, G, FP, ks);
-      return gwtf_internal_stats_k(cur, t->packed_w + (size_t)c * d.PW, ys, K, B, N, f, pat, ks.x, ks.pw, ks.ys, t->stream);
+      return gwtf_internal_stats_k(cur, t->packed_w + (size_t)c * d.PW, ys, K, B, N, f, pat, ks.x, ks.pw, ks.ys, t->tune, t->stream);
     }
     if (phase == GWTF_PHASE_FWD_B) {
       hipLaunchKernelGGL(fold1_kernel, dim3(B, K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, ys, t->n_total,
@@ -713,7 +714,7 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
       float* nxt = t->xbuf + (size_t)(step & 1) * K * d.XS;
       return gwtf_internal_apply_k(cur, t->packed_w, t->film_rec, nxt, step > 0 ? t->logdet : nullptr, t->logdet, t->ps, t->mus,
                                    t->logvars, step + 1 < C ? t->moments + (size_t)(step + 1) * K * d.MS : nullptr, d.MS, c, K, B,
-                                   N, C, f, t->pattern0, t->eps, t->mode, ks.x, d.XS, t->stream);
+                                   N, C, f, t->pattern0, t->eps, t->mode, ks.x, d.XS, t->tune, t->stream);
     }
     return GWTF_E_BADARG;
   }
@@ -848,9 +849,9 @@ extern "C" int gwtf_mtrain_final_backward_half(int C, int mode) { return (mode =
 extern "C" int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float* packed_b, const float* film_raw,
                                   float* moments, float* ystats, float* bn_batch, float* film_rec, float* xbuf,
                                   float* logdet, float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G,
-                                  int pattern0, float eps, int mode, void* stream) {
+                                  int pattern0, float eps, int mode, int tune, void* stream) {
   GwtfTrainCtx t = {};
-  t.K = 1; t.B = B; t.N = N; t.C = C; t.f = f; t.G = G; t.pattern0 = pattern0; t.mode = mode; t.eps = eps;
+  t.K = 1; t.B = B; t.N = N; t.C = C; t.f = f; t.G = G; t.pattern0 = pattern0; t.mode = mode; t.eps = eps; t.tune = tune;
   t.n_total = (double)B * N;
   t.p = p; t.raw = raw; t.packed_w = packed_w; t.packed_b = packed_b; t.film_raw = film_raw; t.film_rec = film_rec;
   t.moments = moments; t.ystats = ystats; t.bn_batch = bn_batch; t.xbuf = xbuf; t.logdet = logdet;

@@ -5,7 +5,8 @@
  * Python/torch code, cited as reference file:line.  Conventions for every function:
  *   - returns 0 on success, otherwise a hipError_t value (or GWTF_E_* below); never throws;
  *   - all pointers are DEVICE pointers to contiguous fp32 (int32 where stated) buffers owned by
- *     the caller; the library allocates nothing and keeps no mutable global state;
+ *     the caller; the library allocates nothing and keeps NO mutable global state (no tuning switches, no environment
+ *     variables: what a call does is a function of its arguments -- see GWTF_TUNE_* for the per-call tuning word);
  *   - work is enqueued on `stream` (a hipStream_t passed as void*) and returns immediately:
  *     no internal streams, events or synchronisation (same convention as the reference's own
  *     native ops, lib/metrics/pytorch_structural_losses/src/structural_loss.cpp:35);
@@ -21,11 +22,19 @@
 extern "C" {
 #endif
 
-#define GWTF_ABI_VERSION 1
+#define GWTF_ABI_VERSION 2
 #define GWTF_E_BADARG 10001   /* shape / mode / width outside what the kernels support */
 #define GWTF_E_UNSUPPORTED 10002   /* a layer-width list no kernel instantiation was built for */
 #define GWTF_MODE_DIRECT 0    /* sampling direction  base -> data (reference models.py:202) */
 #define GWTF_MODE_INVERSE 1   /* density direction   data -> base (reference models.py:197) */
+
+/* Per-call tuning word (`tune` arguments; 0 = the library's own choices).  Tests and the tile-calibration tools pass it; results
+ * never depend on it beyond fp32 rounding of a different summation order (tests/test_gpu_parity.py pins that). */
+#define GWTF_TUNE_DEFAULT 0
+#define GWTF_TUNE_POINTS_PER_WAVE(n) ((n) & 0xffff)   /* force 16, 32 or 64 points per wavefront in the forward-sized kernels */
+#define GWTF_TUNE_GENERIC_BODY (1 << 30)              /* the run-time-width coupling body instead of the software-pipelined one */
+#define GWTF_TUNE_SMALL_LIGHT_TILE (1 << 29)          /* train backward, light pass: 128-point tiles even on large grids */
+#define GWTF_TUNE_SINGLE_TILE (1 << 28)               /* no mixed launch (large tiles + a small-tile tail): one tile size per launch */
 
 int gwtf_abi_version(void);
 /* Human-readable text for a non-zero return value (static storage). */
@@ -98,7 +107,7 @@ int gwtf_film_bn_swish_backward(const float* x, const float* gy, const float* ga
  *   mode     GWTF_MODE_DIRECT / GWTF_MODE_INVERSE */
 int gwtf_stack_forward(const float* p, const float* packed_w, const float* film,
                        float* out, float* logdet, float* ps, float* mus, float* logvars,
-                       int B, int N, int C, int f, int pattern0, float eps, int mode, void* stream);
+                       int B, int N, int C, int f, int pattern0, float eps, int mode, int tune, void* stream);
 
 /* K flow components in ONE launch (the loop over `self.pc_decoder[i]` in Flow_Mixture_Model.decode,
  * lib/networks/flow_mixture.py:163-166).  Component k applies its own C-coupling stack to the points
@@ -113,7 +122,11 @@ int gwtf_stack_forward(const float* p, const float* packed_w, const float* film,
 int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float* film,
                              float* out, float* logdet, float* ps, float* mus, float* logvars,
                              const int* segments, int K, int B, int N, int C, int f, int pattern0, float eps,
-                             int mode, size_t p_stride_k, size_t out_stride_k, void* stream);
+                             int mode, size_t p_stride_k, size_t out_stride_k, int tune, void* stream);
+/* Tile plan of a forward launch (what stack_dispatch decides; diagnostic + tests): out[0] = points per wavefront of the main
+ * launch, out[1] = its workgroups, out[2] = points per wavefront of the tail launch (0: none), out[3] = its workgroups.
+ * The choice minimises resident rounds x the cost of a round of that tile (calibrated, csrc/gwtf_stack.hip tile_cost). */
+int gwtf_stack_plan(const int* segments, int K, int B, int N, int f, int tune, int* out4);
 
 /* ---- train-mode (batch-statistic BatchNorm) forward pipeline, reference flows.py:27,30,62,65 under model.train() ----
  * Per coupling, in processing order (inverse: C-1..0):  fold0 -> stats -> fold1 -> apply.  See csrc/gwtf_train.hip.
@@ -127,12 +140,12 @@ int gwtf_train_fold0(const float* raw_c, const float* moments, double n_total, i
                      float* packed_b_c /*may be NULL: backward record, sd0 section*/, float* bn_batch_c /*[2 branches][4 kinds][2][f]: kind 0 <- {mean, unbiased var} of sd0_bn*/,
                      int f, int G, void* stream);
 int gwtf_train_stats(const float* p, const float* packed_w_c, float* ystats /*pre-zeroed, accumulated*/,
-                     int B, int N, int f, int pattern, void* stream);
+                     int B, int N, int f, int pattern, int tune, void* stream);
 int gwtf_train_fold1(const float* raw_c, const float* ystats, double n_total, const float* film_raw, float* film_rec,
                      float* bn_batch_c /*kind 1 <- sd1_bn*/, int c, int B, int C, int f, int G, void* stream);
 int gwtf_train_apply(const float* p, const float* packed_w, const float* film_rec, float* out, const float* logdet_in,
                      float* logdet, float* ps, float* mus, float* logvars, float* moments_out /*9 or NULL*/,
-                     int c, int B, int N, int C, int f, int pattern0, float eps, int mode, void* stream);
+                     int c, int B, int N, int C, int f, int pattern0, float eps, int mode, int tune, void* stream);
 
 /* The whole single-rank train-mode forward enqueued from C (moments + 4 launches per coupling); workspace sizes
  * are documented at the definition in csrc/gwtf_train.hip.  Result coordinates end in xbuf[(C-1) & 1]. */
@@ -140,7 +153,7 @@ int gwtf_train_forward(const float* p, const float* raw, float* packed_w, float*
                        const float* film_raw, float* moments,
                        float* ystats, float* bn_batch, float* film_rec, float* xbuf, float* logdet,
                        float* ps, float* mus, float* logvars, int B, int N, int C, int f, int G, int pattern0,
-                       float eps, int mode, void* stream);
+                       float eps, int mode, int tune, void* stream);
 
 /* ---- backward (both directions, BatchNorm as a fixed affine) --------------------------------------------------
  * Autograd of CondRealNVPFlow3D.forward (reference flows.py:95-117 as differentiated by loss.backward(),
@@ -210,6 +223,7 @@ int gwtf_train_backward(const float* p, const float* ps, const float* g_out, con
 #define GWTF_PHASE_BWD_C 5
 typedef struct GwtfTrainCtx {
   int K, B, N, C, f, G, pattern0, mode;
+  int tune;                  /* GWTF_TUNE_* word for every launch of the pipeline (0 = default) */
   float eps;
   double n_total;            /* points the statistics cover: B*N summed over all ranks */
   const float* p;            /* [B][3][N]            input clouds, shared by the K components */
@@ -439,12 +453,6 @@ int gwtf_prior_forward(const float* g, const float* raw, float* gs, float* mus, 
 int gwtf_prior_backward(const float* g, const float* raw, const float* gs, const float* mus, const float* logvars,
                         const float* g_gs, const float* g_logvars, float* workspace, float* g_raw, float* g_g,
                         int n_flows, int B, int G, int F, float eps, int mode, int training, void* stream);
-
-/* Tuning/test hook: force the number of points each wavefront carries in gwtf_stack_forward
- * (16, 32 or 64 in the low 16 bits; anything else restores the size-based default).  Bit 30 set: also force the generic
- * coupling body instead of the software-pipelined one (the two are bit-identical; tests compare them).
- * Process-wide, not thread-safe. */
-void gwtf_debug_set_points_per_wave(int points);
 
 #ifdef __cplusplus
 }

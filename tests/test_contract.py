@@ -87,7 +87,7 @@ def test_no_cpu_fallback_and_bad_arguments():
         gw.LocalCondRNVPDecoder(1, 129, 16).engine()
     # bad arguments are rejected by the library itself before anything is launched
     L = _lib.lib()
-    assert L.gwtf_stack_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 8, 0, 1e-6, 1, None) == 10001
+    assert L.gwtf_stack_forward(None, None, None, None, None, None, None, None, 1, 1, 1, 8, 0, 1e-6, 1, 0, None) == 10001
     assert L.gwtf_pack_weights(None, None, None, 1, 8, 16, 0, 0, None) == 10001
     assert L.gwtf_mixture_nll(None, None, None, None, None, None, None, 65, 1, 1, None) == 10001
 
@@ -108,3 +108,30 @@ def test_packed_cache_invalidation_rules():
     assert eng._key(False) != k2
     d.flows[0].nvp1.invalidate_packed_weights()
     assert eng._key(False) != k2
+
+
+def test_library_keeps_no_tuning_state_and_the_tile_plan_follows_rounds():
+    """the tuning word is an ARGUMENT (no setter is exported any more), and the forward's tile is chosen by
+    resident rounds x the calibrated cost of a round (csrc/gwtf_stack.hip tile_cost), not by the point count alone.  Host-only:
+    gwtf_stack_plan launches nothing."""
+    assert not hasattr(ctypes.CDLL(_lib.LIB_PATH), 'gwtf_debug_set_points_per_wave')
+    plan = _lib.stack_plan
+    # the bench workloads (K, B, N, f): airplane / autoencoding shard / SVR shard keep 64 points per wave (4, 1, 1.25 rounds of 512)
+    assert plan(4, 64, 2048, 37) == (64, 2048)
+    assert plan(4, 16, 2048, 33) == (64, 512)
+    assert plan(4, 16, 2500, 33) in ((64, 640), (32, 1280))     # 1.25 rounds of 512 large tiles or 1.67 of 768 small ones: measured equal
+    assert plan(1, 32, 2048, 64) == (32, 512)                   # M1: f = 64 at 64 points per wave runs the generic body, 2x the cost
+    # whole rounds: 24 x 2048 points are 768 small workgroups = exactly three per compute unit (or 192 large ones, one each);
+    # 16 x 2048 are 256 middle ones, 8 x 2048 are 256 small ones -- never a round with one straggler
+    assert plan(1, 24, 2048, 33) in ((16, 768), (64, 192))
+    assert plan(1, 16, 2048, 33) == (32, 256) and plan(1, 8, 2048, 33) == (16, 256)
+    # one shape split over 16 components (the reference's sampling call): the smallest tile, 2 workgroups per component
+    segs = [(k * 128, (k + 1) * 128) for k in range(16)]
+    assert plan(16, 1, 2048, 19, segments=segs) == (16, 32)
+    # a forced tile is honoured per call, and the host-side context manager restores the word on exit (also on an exception)
+    assert plan(4, 64, 2048, 37, word=32) == (32, 4096)
+    with pytest.raises(RuntimeError):
+        with _lib.tuning(points_per_wave=16):
+            assert _lib.tune_word() == 16 and plan(4, 64, 2048, 37) == (16, 8192)
+            raise RuntimeError('boom')
+    assert _lib.tune_word() == 0

@@ -68,7 +68,7 @@ def test_bench_workload_every_shape_every_component_against_fp64_oracle(name):
     cfg = bench.WORKLOADS[name]
     K, L, f, G, B, N, mode = (cfg[k] for k in ('K', 'L', 'f', 'G', 'B', 'N', 'mode'))
     _cpu_threads()
-    _lib.lib().gwtf_debug_set_points_per_wave(0)                 # the library's own tile choice, as in the timed run
+    _lib.set_tuning(0)                 # the library's own tile choice, as in the timed run
     decs, states = [], []
     for k in range(K):                                           # bench.run_workload's construction, rank 0
         d = gw.LocalCondRNVPDecoder(L, f, G)
@@ -109,7 +109,7 @@ def test_train_mode_forward_at_airplane_grid_every_shape_every_component():
     updated running statistics."""
     K, L, f, G, B, N = 4, 11, 37, 128, 64, 2048
     _cpu_threads()
-    _lib.lib().gwtf_debug_set_points_per_wave(0)
+    _lib.set_tuning(0)
     decs, states = [], []
     for k in range(K):
         d = gw.LocalCondRNVPDecoder(L, f, G)

@@ -24,9 +24,9 @@ def host(t):
 
 @pytest.fixture(autouse=True)
 def _default_tiling():
-    _lib.lib().gwtf_debug_set_points_per_wave(0)
+    _lib.set_tuning(0)
     yield
-    _lib.lib().gwtf_debug_set_points_per_wave(0)
+    _lib.set_tuning(0)
 
 
 def test_library_is_loaded_and_has_no_fallback():
@@ -80,7 +80,7 @@ def test_decoder_golden(name, mode, pts_per_wave):
     L, f, G, B, N, seed = D['dims']
     m, _ = decoder_and_state(L, f, G, seed)
     m = m.to(DEV).eval()
-    _lib.lib().gwtf_debug_set_points_per_wave(pts_per_wave)
+    _lib.set_tuning(pts_per_wave)
     tag = f'eval_{mode}'
     with torch.no_grad():
         ps, mus, lvs = m(dev(D['p']), dev(D['g']), mode=mode)
@@ -115,7 +115,7 @@ def test_decoder_at_config_depth_golden(name, mode, pts_per_wave):
     L, f, G, B, N, seed = D['dims']
     m, _ = decoder_and_state(L, f, G, seed)
     m = m.to(DEV).eval()
-    _lib.lib().gwtf_debug_set_points_per_wave(pts_per_wave)
+    _lib.set_tuning(pts_per_wave)
     tag = f'eval_{mode}'
     with torch.no_grad():
         out, logdet = m.forward_fused(dev(D['p']), dev(D['g']), mode=mode)
@@ -240,7 +240,7 @@ def test_ragged_shapes_vs_oracle(B, N, f):
     for mode in ('direct', 'inverse'):
         ref_out, ref_ld = fo.decoder_fused(p, g, st, L, mode)
         for ppw in (16, 32, 64):
-            _lib.lib().gwtf_debug_set_points_per_wave(ppw)
+            _lib.set_tuning(ppw)
             with torch.no_grad():
                 out, ld = m.forward_fused(dev(p), dev(g), mode=mode)
             assert maxabs(host(out), ref_out) < TOL_COORD, (mode, ppw)
@@ -259,12 +259,12 @@ def test_specialised_width_edges_vs_oracle(f):
         for mode in ('direct', 'inverse'):
             ref_out, ref_ld = fo.decoder_fused(p, g, st, L, mode)
             for ppw in (16, 32, 64):
-                _lib.lib().gwtf_debug_set_points_per_wave(ppw)
+                _lib.set_tuning(ppw)
                 with torch.no_grad():
                     out, ld = m.forward_fused(dev(p), dev(g), mode=mode)
                 assert maxabs(host(out), ref_out) < TOL_COORD, (mode, ppw)
                 assert maxabs(host(ld), ref_ld) < TOL_LOGDET, (mode, ppw)
-    _lib.lib().gwtf_debug_set_points_per_wave(0)
+    _lib.set_tuning(0)
 
 
 def test_noncontiguous_and_cache_invalidation():
@@ -1010,7 +1010,7 @@ def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B,
     pd, gd = dev(p), dev(g)
     outs = []
     for flag in (0, 1 << 30):
-        _lib.lib().gwtf_debug_set_points_per_wave(flag)
+        _lib.set_tuning(flag)
         with torch.no_grad():
             z, ld = m.forward_fused(pd, gd, mode)
             ps, mus, lvs = m(pd, gd, mode=mode)
@@ -1026,13 +1026,13 @@ def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B,
         ref = outs[1]
         try:
             for ppw in (16, 32, 64):
-                _lib.lib().gwtf_debug_set_points_per_wave(ppw)
+                _lib.set_tuning(ppw)
                 with torch.no_grad():
                     z, ld = m.forward_fused(pd, gd, mode)
                 for a, b in ((z, ref[0]), (ld, ref[1])):
                     assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max())), ppw
         finally:
-            _lib.lib().gwtf_debug_set_points_per_wave(0)
+            _lib.set_tuning(0)
 
 
 @pytest.mark.parametrize('training', [False, True])

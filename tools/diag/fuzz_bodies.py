@@ -15,7 +15,7 @@ for it in range(160):
     p, g = synth_inputs(B, N, G, int(rng.integers(1, 1000))); pd, gd = torch.from_numpy(p).cuda(), torch.from_numpy(g).cuda()
     outs = []
     for flag in (ppw, ppw | 1 << 30):
-        _lib.lib().gwtf_debug_set_points_per_wave(flag)
+        _lib.set_tuning(flag)
         with torch.no_grad():
             ps, mus, lvs = d(pd, gd, mode=mode)
             z, ld = d.forward_fused(pd, gd, mode)
@@ -24,5 +24,5 @@ for it in range(160):
     worst = max(worst, e / sc)
     if not np.isfinite(e) or e > 5e-6 * sc:
         nbad += 1; print('BAD', dict(f=f, L=L, G=G, B=B, N=N, mode=mode, ppw=ppw), e, sc)
-_lib.lib().gwtf_debug_set_points_per_wave(0)
+_lib.set_tuning(0)
 print('cases 160, bad', nbad, 'worst relative difference', worst)

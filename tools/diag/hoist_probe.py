@@ -11,11 +11,11 @@ for (B, N) in ((64, 2048), (4, 256), (64, 256), (4, 2048)):
     p, g = synth_inputs(B, N, 32, 78); pd, gd = dev(p), dev(g)
     outs = []
     for flag in (0, 1 << 30):
-        _lib.lib().gwtf_debug_set_points_per_wave(flag)
+        _lib.set_tuning(flag)
         with torch.no_grad():
             ps, mus, lvs = m(pd, gd, mode='direct')
         outs.append(torch.stack(mus))
-    _lib.lib().gwtf_debug_set_points_per_wave(0)
+    _lib.set_tuning(0)
     e = (outs[0] - outs[1]).abs()                       # (C, B, 3, N)
     bad = (e.amax(dim=(0, 2)) > 1e-5)                   # (B, N)
     nb = bad.nonzero()

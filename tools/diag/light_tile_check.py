@@ -1,5 +1,5 @@
 """Run-to-run deviation of the K-batched train gradients at a size where the light pass takes its 256-point tile, with either
-tile (GWTF_LIGHT_SMALL_TILE=1 forces 128 points): are the two tiles equally (ir)reproducible?  (ReLU kinks)"""
+tile (argument `small`: the per-call tuning word GWTF_TUNE_SMALL_LIGHT_TILE forces 128 points): are the two tiles equally (ir)reproducible?  (ReLU kinks)"""
 import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import torch
 import go_with_the_flows_amd as gw
@@ -9,7 +9,10 @@ decs = [decoder_and_state(L, f, G, 640 + k)[0].to(DEV).train() for k in range(2)
 p, g = synth_inputs(B, N, G, 641)
 gen = torch.Generator().manual_seed(642)
 wz, wl = torch.randn(2, B, 3, N, generator=gen).to(DEV), torch.randn(2, B, 3, N, generator=gen).to(DEV)
-signed = len(sys.argv) > 1
+signed = 'signed' in sys.argv
+if 'small' in sys.argv:
+    from go_with_the_flows_amd import _lib
+    _lib.set_tuning(_lib.TUNE_SMALL_LIGHT_TILE)
 if not signed:
     wz, wl = wz.abs(), wl.abs()
 state = [{k: v.clone() for k, v in d.state_dict().items()} for d in decs]

@@ -10,11 +10,11 @@ for f in [int(a) for a in sys.argv[1:]] or [37, 33, 40, 19]:
     for ppw in (16, 32, 64):
         outs = []
         for flag in (ppw, ppw | 1 << 30):
-            _lib.lib().gwtf_debug_set_points_per_wave(flag)
+            _lib.set_tuning(flag)
             with torch.no_grad():
                 ps, mus, lvs = d(pd, gd, mode='direct')
             outs.append((torch.stack(mus), torch.stack(lvs)))
-        _lib.lib().gwtf_debug_set_points_per_wave(0)
+        _lib.set_tuning(0)
         for name, a, b in zip(('mu', 'lv'), outs[0], outs[1]):
             e = (a - b).abs()
             print(f, ppw, name, 'max', float(e.max()), 'coupling 3 per dim', [float(x) for x in e[3].amax(dim=(0, 2))],
