@@ -101,6 +101,11 @@ _SIGNATURES = {
     'gwtf_mtrain_backward': (ctypes.c_int, [ctypes.c_void_p]),
     'gwtf_mtrain_final_forward_half': (ctypes.c_int, [ctypes.c_int]),
     'gwtf_mtrain_final_backward_half': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    'gwtf_head_layer_supported': (ctypes.c_int, [ctypes.c_int] * 4),
+    'gwtf_head_layer_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_float, ctypes.c_float] + [ctypes.c_int] * 3 + [_c_fp] * 3 +
+                                [ctypes.c_int] * 3 + [_c_fp]),
+    'gwtf_head_layer_backward': (ctypes.c_int, [_c_fp] * 9 + [ctypes.c_int] * 2 + [_c_fp] * 2 + [ctypes.c_int] + [_c_fp] * 4 +
+                                 [ctypes.c_int] * 3 + [_c_fp]),
 }
 
 PHASE_FWD_INIT, PHASE_FWD_A, PHASE_FWD_B, PHASE_BWD_A, PHASE_BWD_B, PHASE_BWD_C = range(6)
@@ -245,9 +250,10 @@ def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists):
     return out, logdet, lists
 
 
-def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segments=None, shared_points=True):
+def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segments=None, shared_points=True, out=None, logdet=None):
     """K components in one launch.  shared_points=True: every component maps all of p -> outputs (K,B,3,N).
-    Otherwise ``segments`` (list of K (begin,end)) partitions the N points among the components -> (B,3,N)."""
+    Otherwise ``segments`` (list of K (begin,end)) partitions the N points among the components -> (B,3,N).
+    out / logdet: optional preallocated result tensors (a timing probe brackets the launch alone with them)."""
     L = lib()
     B, three, N = p.shape
     if three != 3:
@@ -261,13 +267,19 @@ def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segment
             raise GwtfError('segments must hold K (begin, end) pairs')
         seg = (ctypes.c_int * (2 * K))(*flat)
     if shared_points:
-        out = torch.empty(K, B, 3, N, device=p.device, dtype=torch.float32)
-        logdet = torch.empty(K, B, 3, N, device=p.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(K, B, 3, N, device=p.device, dtype=torch.float32)
+            logdet = torch.empty(K, B, 3, N, device=p.device, dtype=torch.float32)
         stride = B * 3 * N
     else:
-        # points outside every segment are not touched by the kernel: define them
-        out = torch.zeros(B, 3, N, device=p.device, dtype=torch.float32)
-        logdet = torch.zeros(B, 3, N, device=p.device, dtype=torch.float32)
+        if out is None:
+            # points outside every segment are not touched by the kernel: define them -- unless the segments tile [0, N) (the
+            # sampling partition of flow_mixture.py:146-177 always does): two fill launches less per call
+            covered = sorted((int(b), int(e)) for b, e in segments if int(e) > int(b))
+            tiled = bool(covered) and covered[0][0] == 0 and covered[-1][1] == N and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+            make = torch.empty if tiled else torch.zeros
+            out = make(B, 3, N, device=p.device, dtype=torch.float32)
+            logdet = make(B, 3, N, device=p.device, dtype=torch.float32)
         stride = 0
     with torch.cuda.device(p.device):
         check(L.gwtf_stack_forward_multi(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),

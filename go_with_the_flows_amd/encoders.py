@@ -323,6 +323,60 @@ class PointNetCloudEncoder(nn.Module):
         return self._fused(input, False, True)[1]
 
 
+class _HeadLayerFn(torch.autograd.Function):
+    """One layer of a per-shape head on the HIP device (csrc/gwtf_heads.hip): out = act(BatchNorm(x W^T + bias)), forward and
+    backward one C call each.  bn: the BatchNorm module whose buffers the forward updates (None: no BatchNorm);
+    bn_mode 0 none / 1 batch statistics / 2 running statistics; act 0 none / 1 swish / 2 log_softmax."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, gamma, beta, bn, bn_mode, bn_updates, act):
+        L = _lib.lib()
+        x, W = x.contiguous(), W.contiguous()
+        B, Din = x.shape
+        Dout = W.shape[0]
+        dev = x.device
+        ypre = torch.empty(B, Dout, device=dev, dtype=torch.float32)
+        out = torch.empty(B, Dout, device=dev, dtype=torch.float32)
+        stats = torch.empty(3, Dout, device=dev, dtype=torch.float32) if bn_mode else None
+        P = lambda t: None if t is None else _ptr(t.contiguous() if not t.is_contiguous() else t, 'head operand')
+        tracked = bn is not None and bn.track_running_stats and bn.running_mean is not None
+        rm, rv = (bn.running_mean, bn.running_var) if tracked else (None, None)
+        nbt = bn.num_batches_tracked.data_ptr() if (tracked and bn.num_batches_tracked is not None) else None
+        with torch.cuda.device(dev):
+            check(L.gwtf_head_layer_forward(P(x), P(W), P(bias), P(gamma), P(beta), P(rm), P(rv), nbt,
+                                            float(bn.momentum) if bn is not None and bn.momentum is not None else 0.0,
+                                            float(bn.eps) if bn is not None else 1e-5, bn_mode, int(bn_updates), act, P(ypre), P(stats),
+                                            P(out), B, Din, Dout, _stream(x)))
+        if bn_mode == 1 and tracked:
+            torch._C._increment_version([t for t in (rm, rv, bn.num_batches_tracked) if t is not None])   # written through raw pointers
+        ctx.save_for_backward(x, W, bias, gamma, beta, ypre, stats, out)
+        ctx.meta = (bn_mode, act)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L = _lib.lib()
+        x, W, bias, gamma, beta, ypre, stats, out = ctx.saved_tensors
+        bn_mode, act = ctx.meta
+        B, Din = x.shape
+        Dout = W.shape[0]
+        dev = x.device
+        new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        g_out = g_out.contiguous().float()
+        need = ctx.needs_input_grad
+        g_y = new(B, Dout)
+        g_x = new(B, Din) if need[0] else None
+        g_W = new(Dout, Din) if need[1] else None
+        g_b = new(Dout) if (bias is not None and need[2]) else None
+        g_ga = new(Dout) if (gamma is not None and need[3]) else None
+        g_be = new(Dout) if (beta is not None and need[4]) else None
+        P = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(dev):
+            check(L.gwtf_head_layer_backward(P(x), P(W), P(bias), P(gamma), P(beta), P(ypre), P(stats), P(out), P(g_out), bn_mode, act,
+                                             P(g_y), P(g_x), 0, P(g_W), P(g_b), P(g_ga), P(g_be), B, Din, Dout, _stream(x)))
+        return g_x, g_W, g_b, g_ga, g_be, None, None, None, None
+
+
 class FeatureEncoder(nn.Module):
     """Per-shape MLP with Gaussian heads (reference encoders.py:31-85)."""
 
@@ -388,6 +442,33 @@ class FeatureEncoder(nn.Module):
                 h = mod(h)
         return h
 
+    def _hip_layers(self, input):
+        """[(Linear, BatchNorm or None)] of the trunk when csrc/gwtf_heads.hip covers this call (fp32 rows on the HIP device, at most
+        128 of them, plain Linear -> [BatchNorm1d with a momentum] -> Swish layers), else None: the library modules then run --
+        on the CPU (host-logic tests), for other dtypes, for more rows."""
+        if not (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and 1 <= input.shape[0] <= 128):
+            return None
+        layers, mods = [], list(self.features) if self.n_layers > 0 else []
+        i = 0
+        while i < len(mods):
+            lin = mods[i]
+            bn = mods[i + 1] if (i + 1 < len(mods) and isinstance(mods[i + 1], nn.modules.batchnorm._BatchNorm)) else None
+            sw = mods[i + (2 if bn is not None else 1)] if i + (2 if bn is not None else 1) < len(mods) else None
+            if not (isinstance(lin, nn.Linear) and lin.bias is None and isinstance(sw, Swish) and lin.weight.dtype == torch.float32):
+                return None
+            if bn is not None and (bn.momentum is None or (bn.training and input.shape[0] < 2)):
+                return None
+            layers.append((lin, bn))
+            i += 3 if bn is not None else 2
+        ok = _lib.lib().gwtf_head_layer_supported
+        dims = [(l.weight.shape[1], l.weight.shape[0], 1) for l, _ in layers] + \
+               [(m[-1].weight.shape[1], m[-1].weight.shape[0], self._head_act) for m in ([self.mus] if self.deterministic else [self.mus, self.logvars])]
+        if not all(ok(input.shape[0], din, dout, act) for din, dout, act in dims):
+            return None
+        return layers
+
+    _head_act = 0          # activation code of the mu head in csrc/gwtf_heads.hip (WeightsEncoder: 2 = log_softmax)
+
     def _hidden(self, input, bn_updates=1):
         """The shared trunk: Linear -> BatchNorm -> Swish per layer.  In a synchronised data-parallel run (SyncBatchNorm modules,
         train_ae.py:152) every rank evaluates the trunk on the rows of ALL ranks and keeps its own (dist.gather_rows): one
@@ -397,23 +478,38 @@ class FeatureEncoder(nn.Module):
         bns = self._bn_modules()
         from .dist import gather_rows, syncs_statistics
         sync = self.training and bool(bns) and syncs_statistics(bns)
-        if not sync and bn_updates == 1:
-            return self.features(input)
         rows = input.shape[0]
         if sync:
             input, lay = gather_rows(input)
-        h = self._features_functional(input, bn_updates)
+        layers = self._hip_layers(input)
+        if layers is not None:
+            h = input
+            for lin, bn in layers:
+                mode = 0 if bn is None else (1 if (bn.training or not bn.track_running_stats) else 2)
+                h = _HeadLayerFn.apply(h, lin.weight, None, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+                                       bn, mode, bn_updates, 1)
+        elif not sync and bn_updates == 1:
+            h = self.features(input)
+        else:
+            h = self._features_functional(input, bn_updates)
         return h[lay.row0:lay.row0 + rows] if sync else h
+
+    def _head(self, seq, h, act=0):
+        lin = seq[-1]
+        if h.is_cuda and h.dtype == torch.float32 and len(seq) == 1 and lin.weight.dtype == torch.float32 and h.shape[0] <= 128 and \
+                _lib.lib().gwtf_head_layer_supported(h.shape[0], lin.weight.shape[1], lin.weight.shape[0], act):
+            return _HeadLayerFn.apply(h, lin.weight, lin.bias, None, None, None, 0, 1, act)
+        out = seq(h)
+        return nn.functional.log_softmax(out, dim=1) if act == 2 else out
 
     def forward(self, input, bn_updates=1):
         h = self._hidden(input, bn_updates)
         if self.deterministic:
-            return self.mus(h)
-        return self.mus(h), self.logvars(h)
+            return self._head(self.mus, h, self._head_act)
+        return self._head(self.mus, h, self._head_act), self._head(self.logvars, h)
 
 
 class WeightsEncoder(FeatureEncoder):
     """Mixture-weight head: log-softmax of the deterministic output (reference encoders.py:87-91)."""
 
-    def forward(self, input, bn_updates=1):
-        return nn.functional.log_softmax(super().forward(input, bn_updates), dim=1)
+    _head_act = 2          # the log_softmax is fused into the head's kernel (and applied by FeatureEncoder._head otherwise)

@@ -602,6 +602,49 @@ def g17_encoder_train():
     save('g17_encoder_train', **out)
 
 
+def g20_heads():
+    """The per-shape heads at the sizes the shipped configs give them (models.py:51-59, flow_mixture.py:28-32): g_posterior =
+    FeatureEncoder(1, 512, 128), p_prior = FeatureEncoder(1, 128, 3), mixture_weights_encoder = WeightsEncoder(3, 128, 4,
+    deterministic) -- the genuine reference modules (encoders.py:31-91) in train mode (batch statistics, running statistics after
+    the step) and eval mode: outputs, and the gradient of a weighted sum of the outputs w.r.t. the input and every parameter,
+    fp32 as the reference runs and fp64 for the noise floor."""
+    from lib.networks import encoders as renc
+    from go_with_the_flows_amd import encoders as oenc
+    out = {}
+    cases = (('post', renc.FeatureEncoder, oenc.FeatureEncoder, (1, 512, 128), dict(deterministic=False), 7, 2000),
+             ('pprior', renc.FeatureEncoder, oenc.FeatureEncoder, (1, 128, 3), dict(deterministic=False), 64, 2010),
+             ('wts', renc.WeightsEncoder, oenc.WeightsEncoder, (3, 128, 4), dict(deterministic=True), 33, 2020))
+    for tag, cls_r, cls_o, ctor, kw, B, seed in cases:
+        rng = np.random.default_rng(seed + 1)
+        x = rng.standard_normal((B, ctor[1])).astype(np.float32)
+        n_out = 1 if kw['deterministic'] else 2
+        wgt = rng.standard_normal((n_out, B, ctor[2])).astype(np.float32)
+        out[f'{tag}_x'], out[f'{tag}_wgt'], out[f'{tag}_ctor'] = x, wgt, np.array(ctor)
+        for training in (True, False):
+            t = 'train' if training else 'eval'
+            res = {}
+            for dt, suffix in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+                ref, mine = cls_r(*ctor, **kw), cls_o(*ctor, **kw)
+                load_into(ref, mine, seed)
+                ref = ref.to(dt).train(training)
+                xin = T(x).to(dt).requires_grad_(True)
+                y = ref(xin)
+                ys = y if isinstance(y, tuple) else (y,)
+                sum((o * T(wgt[i]).to(dt)).sum() for i, o in enumerate(ys)).backward()
+                res[suffix] = dict({f'out{i}': npy(o) for i, o in enumerate(ys)}, gx=npy(xin.grad),
+                                   **{f'grad.{name}': npy(prm.grad) for name, prm in ref.named_parameters()})
+                if training and suffix == 'f32':
+                    for name, buf in ref.named_buffers():
+                        out[f'{tag}_buf.{name}'] = npy(buf)
+            # stored: the fp64 run (rounded to fp32 once; large weight gradients every 8th row) and, per tensor, the distance of
+            # the reference's own fp32 run from it relative to the tensor's largest entry -- the noise floor a test may allow
+            for key, v64 in res['f64'].items():
+                v32 = res['f32'][key]
+                out[f'{tag}_{t}_noise.{key}'] = np.float64(np.abs(v32 - v64).max() / max(np.abs(v64).max(), 1e-30))
+                out[f'{tag}_{t}_{key}'] = (v64[::8] if v64.size > 65536 else v64).astype(np.float32)
+    save('g20_heads', **out)
+
+
 CASES = {
     'contract': contract,
     'g1': g1_single_couplings,
@@ -620,6 +663,7 @@ CASES = {
     'g10': g10_optimizer,
     'g11': g11_encoder,
     'g17': g17_encoder_train,
+    'g20': g20_heads,
     'g12': g12_prior,
     'g13': g13_full_model,
     'g19': g19_autoencoding,
