@@ -460,6 +460,8 @@ class FeatureEncoder(nn.Module):
                 return None
             layers.append((lin, bn))
             i += 3 if bn is not None else 2
+        if any(max(l.weight.shape) > self.hip_max_width for l, _ in layers):
+            return None
         ok = _lib.lib().gwtf_head_layer_supported
         dims = [(l.weight.shape[1], l.weight.shape[0], 1) for l, _ in layers] + \
                [(m[-1].weight.shape[1], m[-1].weight.shape[0], self._head_act) for m in ([self.mus] if self.deterministic else [self.mus, self.logvars])]
@@ -468,6 +470,12 @@ class FeatureEncoder(nn.Module):
         return layers
 
     _head_act = 0          # activation code of the mu head in csrc/gwtf_heads.hip (WeightsEncoder: 2 = log_softmax)
+    # Widest trunk layer the HIP layer kernels take by default.  Measured on the MI355X, forward + backward inside a hipGraph
+    # (tools/diag/heads_time.py, B = 64): p_prior (128 wide) 104 us against 111 for the library modules, the mixture-weight
+    # encoder (3 x 128) 155 against 190 -- but g_posterior (512 wide) 255 against 148: a product with K = 512 is eight dependent
+    # memory round trips per workgroup here where hipBLASLt splits K over many.  Set to 4096 to run every head on the HIP kernels
+    # (tests do); a split-K mapping (K over the 8 wavefronts of a workgroup + an LDS reduction) is the known fix.
+    hip_max_width = 256
 
     def _hidden(self, input, bn_updates=1):
         """The shared trunk: Linear -> BatchNorm -> Swish per layer.  In a synchronised data-parallel run (SyncBatchNorm modules,
@@ -497,7 +505,7 @@ class FeatureEncoder(nn.Module):
     def _head(self, seq, h, act=0):
         lin = seq[-1]
         if h.is_cuda and h.dtype == torch.float32 and len(seq) == 1 and lin.weight.dtype == torch.float32 and h.shape[0] <= 128 and \
-                _lib.lib().gwtf_head_layer_supported(h.shape[0], lin.weight.shape[1], lin.weight.shape[0], act):
+                max(lin.weight.shape) <= self.hip_max_width and _lib.lib().gwtf_head_layer_supported(h.shape[0], lin.weight.shape[1], lin.weight.shape[0], act):
             return _HeadLayerFn.apply(h, lin.weight, lin.bias, None, None, None, 0, 1, act)
         out = seq(h)
         return nn.functional.log_softmax(out, dim=1) if act == 2 else out

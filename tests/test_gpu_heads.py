@@ -35,6 +35,7 @@ def rel(a, b):
 def test_heads_match_the_reference_outputs_gradients_and_buffers(tag, training):
     D = golden('g20_heads')
     m = build(tag, D).to(DEV).train(training)
+    m.hip_max_width = 4096                                     # every head on the HIP kernels (the default leaves trunks beyond 256 wide to the library)
     t = 'train' if training else 'eval'
     x = torch.from_numpy(D[f'{tag}_x']).to(DEV).requires_grad_(True)
     assert m._hip_layers(x) is not None                        # this call is served by the HIP kernels, not by library modules
@@ -70,6 +71,7 @@ def test_heads_odd_sizes_against_the_library_modules_in_fp64(B, din, dout, layer
         m = encoders.FeatureEncoder(layers, din, dout, deterministic=False, batch_norm=batch_norm, easy_init=True)
         m.load_state_dict({k: v.float() if v.is_floating_point() else v for k, v in ref.state_dict().items()})
         m = m.to(DEV).train()
+        m.hip_max_width = 4096
         x64 = torch.randn(B, din, dtype=torch.float64)
         w = torch.randn(2, B, dout, dtype=torch.float64)
         xr = x64.clone().requires_grad_(True)
