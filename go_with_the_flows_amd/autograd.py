@@ -1,6 +1,6 @@
 """Differentiable density passes of a coupling stack: HIP forward + HIP backward behind torch.autograd.Function.
 
-Structure (DESIGN.md sections 4.6 / 4.7).  Everything per point -- the forward stack and, per coupling, the recompute,
+Structure (docs/LOG.md sections 4.6 / 4.7).  Everything per point -- the forward stack and, per coupling, the recompute,
 dacc, dh = W1p^T dacc, the sd0 / FiLM-record gradient reductions, dx and the f x f weight gradient (accumulated inside
 the backward kernel, summed by gwtf_dw1_reduce) -- is hand-written HIP (csrc/gwtf_stack.hip, gwtf_bwd.hip,
 gwtf_train.hip).  What is O(f^2 + B*f*G) stays a small torch graph on views of ONE flat parameter arena: the "fold" from

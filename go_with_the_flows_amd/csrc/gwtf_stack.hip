@@ -762,7 +762,7 @@ int launch_nb(int nb, const float* p, const float* pw, const float* film, float*
 // quarter of the points of 64 per wave for 45 % of its round), so the chooser prices every tile and takes the cheapest; the rule
 // it replaces looked at the point count alone (16 points per wave for everything below 64 K points: 93 us against 78 for
 // 24 x 2048 points at f = 33).  What no tile can fix is quantisation: 640 large workgroups (the SVR shard) are 1.25 rounds of
-// 512 and cost 1.45 rounds, and a second launch with small tiles for the remainder cannot overlap the first (DESIGN.md).
+// 512 and cost 1.45 rounds, and a second launch with small tiles for the remainder cannot overlap the first (DESIGN.md 3.1).
 struct TileCost { int slots; float level[4]; };     // cost of a round with 1 .. slots workgroups per compute unit
 inline TileCost tile_cost(int MB, int nbi /* 0 / 1 / 2 = NB 1 / 2 / 4 */) {
   static const TileCost T[4][3] = {
@@ -807,7 +807,7 @@ extern "C" int gwtf_stack_plan(const int* segments, int K, int B, int N, int f, 
   const int nb = choose_nb(segments, K, B, N, f, tune);
   out4[0] = 16 * nb;
   out4[1] = (int)tiles_of(segments, K, B, N, nb);
-  out4[2] = out4[3] = 0;              // no tail launch: measured, a second (small-tile) launch cannot overlap the first -- DESIGN.md
+  out4[2] = out4[3] = 0;              // no tail launch: measured, a second (small-tile) launch cannot overlap the first -- DESIGN.md 3.1
   return 0;
 }
 

@@ -2,7 +2,7 @@
 EVERY component compared to the fp64 oracle (oracle/torch_port.py).  Needs an MI355X.
 
 Why all shapes: the stack kernel places VALU instructions by hand beside VGPR-form MFMAs (inline asm, outside LLVM's hazard
-recogniser); the three hazards met so far ("asm hazards") were shape- and occupancy-dependent -- wrong values in the
+recogniser); the three hazards met so far (docs/LOG.md 4.1) were shape- and occupancy-dependent -- wrong values in the
 last point block of some waves, only with two workgroups resident per compute unit, only for some shapes.  A check that samples
 three shapes of 64 can miss that; this one cannot.  Each launch also runs twice and must repeat bit for bit (a timing-dependent
 hazard shows up as run-to-run differences before it shows up against the oracle).

@@ -78,7 +78,7 @@ def test_fused_training_step_is_differentiable_and_matches_list_api(base_type):
     # The golden clouds moved by 1e-3: with them as they are and base type 'freevar', one first-layer pre-activation (decoder 0,
     # coupling 1, logvar branch) lies 1.3e-7 from the ReLU kink, closer than the run-to-run rounding of the batch statistics (float
     # atomics), so that ReLU's derivative -- and with it the gradient, by 8.7e-5 of its norm -- takes one of two values from run to
-    # run whichever API is called (tools/diag/relu_margin.py, run_to_run_noise.py).  This test compares two calls.
+    # run whichever API is called (tools/diag/relu_margin.py, run_to_run_noise.py; docs/LOG.md 4.11).  This test compares two calls.
     gen = torch.Generator().manual_seed(7)
     gcloud = dev(D['gcloud']) + 1e-3 * torch.randn(D['gcloud'].shape, generator=gen).to(DEV)
     pcloud = dev(D['pcloud']) + 1e-3 * torch.randn(D['pcloud'].shape, generator=gen).to(DEV)

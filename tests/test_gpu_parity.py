@@ -442,7 +442,7 @@ def test_train_backward_light_pass_tile_shapes_agree():
     """The train backward's light pass (FiLM-record sums, csrc/gwtf_bwd.hip BW_LIGHT) takes 256 points per workgroup from B*N*K =
     256 Ki points up and 128 below: K = 2 components in one pipeline pass (large tile) give the gradients of the two K = 1
     passes (small tile).  Two evaluations at this size are not equal to rounding: of the ~10^7 ReLU pre-activations a few lie
-    within the run-to-run rounding of the batch statistics of their kink and flip (with either tile,
+    within the run-to-run rounding of the batch statistics of their kink and flip (docs/LOG.md 4.11; with either tile,
     tools/diag/light_tile_check.py).  A flip changes its point's cloud gradient by O(1), the latent gradients by ~1/N and
     a few parameter tensors by up to ~1e-3 (less with the positive loss weights used here: no cancellation in the sums), so the
     bars are: the typical tensor / point / shape agrees to rounding, and only a handful are off at all.  A wrong tile would be off
@@ -718,7 +718,7 @@ def test_train_mode_gradients_at_full_tile_sizes_f37_vs_torch_cpu_autograd(B):
     """The same comparison at the sizes the training step runs at -- 128 x 2048 points, f = 37: the statistics pass and the light
     backward pass on their 256-point tiles, the merged pass on its 128-point tile, the abs-form contraction with its compile-time
     merged flag (csrc/gwtf_device.h sd1_contract MG = 1) -- against CPU autograd of the oracle.  Loss weights are positive (a few of
-    the 2.9e7 ReLU pre-activations sit within rounding of their kink and differ between ANY two evaluations, DESIGN.md 4.11: with
+    the 2.9e7 ReLU pre-activations sit within rounding of their kink and differ between ANY two evaluations, docs/LOG.md 4.11: with
     random-sign weights the sums cancel and one flipped point shows at 1e-3 of a tensor's gradient)."""
     from oracle import torch_port as tp
     L, f, G, N = 1, 37, 16, 2048          # B = 16: the 64-point tiles (512 workgroups: still two per compute unit); 128: the large ones
@@ -1022,7 +1022,7 @@ def test_pipelined_coupling_body_is_bit_identical_to_the_generic_one(L, f, G, B,
             assert torch.equal(a, b)
     if B * N >= 32 * 2048:
         # every tile shape at a grid that puts two workgroups on a compute unit (the inline-asm splits have shown a hazard that
-        # only such grids expose): 16 / 32 / 64 points per wave forced, pipelined against the generic reference above
+        # only such grids expose, docs/LOG.md 4.1): 16 / 32 / 64 points per wave forced, pipelined against the generic reference above
         ref = outs[1]
         try:
             for ppw in (16, 32, 64):

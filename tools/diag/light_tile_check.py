@@ -1,5 +1,5 @@
 """Run-to-run deviation of the K-batched train gradients at a size where the light pass takes its 256-point tile, with either
-tile (argument `small`: the per-call tuning word GWTF_TUNE_SMALL_LIGHT_TILE forces 128 points): are the two tiles equally (ir)reproducible?  (ReLU kinks)"""
+tile (argument `small`: the per-call tuning word GWTF_TUNE_SMALL_LIGHT_TILE forces 128 points): are the two tiles equally (ir)reproducible?  (ReLU kinks, docs/LOG.md 4.11.)"""
 import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import torch
 import go_with_the_flows_amd as gw

@@ -1,7 +1,7 @@
 """Run-to-run deviation of the whole-model training gradients (fused step, state restored every time).
 usage: run_to_run_noise.py [base_type] [jitter_seed]   -- jitter_seed adds 1e-3 * randn to the clouds (0 = the golden clouds)
 
-Finding: with the golden clouds and base type 'freevar', one first-layer pre-activation of decoder 0 / coupling 1 /
+Finding (docs/LOG.md 4.11): with the golden clouds and base type 'freevar', one first-layer pre-activation of decoder 0 / coupling 1 /
 logvar branch sits 1.3e-7 from the ReLU kink (tools/diag/relu_margin.py); the batch statistics are summed with float atomics, so
 the value lands on either side from run to run and the whole gradient takes one of TWO values (8.7e-5 of its norm apart)."""
 import sys; sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
