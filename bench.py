@@ -109,7 +109,7 @@ def cpu_baseline(cfg, budget_s=15.0):
                       f'(min / max = slowest / fastest rep)'}
 
 
-def _run_bench_train(extra_args, env, timeout=300, graph=True):
+def _run_bench_train(extra_args, env, timeout=200, graph=True):
     """One run of tools/bench_train.py in a child process -> {label: ms per step} parsed from its report, or {'error': ...}."""
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
@@ -178,7 +178,7 @@ def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backen
         graph = backend == 'nccl'
         key = 'hipGraph' if graph else 'eager'
         ms = _run_bench_train(['--batch', str(per_rank), '--backend', backend] + (['--share-device'] if share_device else []),
-                              dict(env, MASTER_PORT=str(port)), graph=graph)
+                              dict(env, MASTER_PORT=str(port)), timeout=150, graph=graph)   # a hang must not cost the headline line
         ok = torch.tensor([1.0 if ms.get('rc') == 0 and (rank != 0 or key in ms) else 0.0], device=dev if graph else 'cpu')
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # also keeps the parents in step between the two runs
         if float(ok) == 0.0:
@@ -333,12 +333,17 @@ def roofline_record(name, m):
     exceed 1 because that unit is not the one doing the work."""
     cfg = m['cfg']
     peak = MFMA_F16_PEAK_TFLOPS / 3
-    traffic = None
+    # HBM-side bytes per launch: NOT measured by this run (PMC counters need rocprofv3) -- read from the committed profile set, whose
+    # tag is reported beside it; null for a shape that set does not cover
+    traffic, traffic_source = None, None
     tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
     if os.path.exists(tfile):
-        traffic = json.load(open(tfile)).get(name)
+        tj = json.load(open(tfile))
+        traffic = tj.get(name)
+        if traffic is not None:
+            traffic_source = f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/profile.sh, tag {tj.get('_tag', 'r07')}; static, not this run)"
     return {'bound': 'mfma', 'achieved': round(m['achieved'], 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
-            'frac': round(m['achieved'] / peak, 4), 'traffic': traffic,
+            'frac': round(m['achieved'] / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
             'peak_basis': 'dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 product (the executing unit)',
             'peak_fp32_mfma': MFMA_F32_PEAK_TFLOPS, 'ratio_vs_fp32_mfma': round(m['achieved'] / MFMA_F32_PEAK_TFLOPS, 4),
             'kernel': 'stack_kernel (fused coupling stack)', 'kernel_ms': round(m['kern_ms'], 4),

@@ -100,6 +100,11 @@ __device__ __forceinline__ float quarter_reduce(const float (&o)[NB], int q) {
   // (test_full_size_properties).  Inline asm, because hipcc 7.2 miscompiles the two-result builtins when both results feed arithmetic
   // (reads the second result from the first register, tools/diag/qr_probe.hip); the two v_nop are the wait states a VALU write of an
   // operand needs before the swap reads it (cdna_hip_programming.md T21) -- the hazard recogniser does not look inside asm.
+  // PRECONDITION (also of wave_sum / wave_max below): every operand is the result of a PLAIN VALU instruction (v_add / v_fma / v_max /
+  // v_mov ...).  An MFMA accumulator or the result of a transcendental (v_exp / v_rcp / v_rsq / v_sqrt: their own forwarding latency)
+  // handed in directly needs more wait states than the two v_nop provide and the compiler will not add them -- pass such a value
+  // through an arithmetic instruction first.  Every caller today passes v_fmac / v_add / v_max results; the guards are
+  // test_backward_is_reproducible_run_to_run and the full-grid tests (tests/test_gpu_fullgrid.py: every launch twice, bit for bit).
   if constexpr (NB == 4) {
     float a0 = o[0], a1 = o[1], a2 = o[2], a3 = o[3];
     asm("v_nop\n\tv_nop\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"      // one pair of wait states covers both

@@ -89,6 +89,9 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
                 out['_prior_handle'] = self.g_prior.forward_async(out['g_posterior_samples'], mode='inverse')
                 return out
             buf_g = self.g_prior(out['g_posterior_samples'], mode='inverse')
+            from .prior import stacked_lists
+            if stacked_lists(self.g_prior) is not None:
+                out['_g_prior_logvars_stacked'] = stacked_lists(self.g_prior)[2]
             out['g_prior_samples'] = buf_g[0] + [out['g_posterior_samples']]
         elif self.mode == 'generating':
             out['g_prior_samples'] = [self.reparameterize(out['g_prior_mus'][0], out['g_prior_logvars'][0])]
@@ -105,6 +108,10 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
         handle = out.pop('_prior_handle', None)
         if handle is not None:
             buf_g = handle.result()
+            from .prior import stacked_lists
+            stacked = stacked_lists(self.g_prior)
+            if stacked is not None:
+                out['_g_prior_logvars_stacked'] = stacked[2]
             out['g_prior_samples'] = buf_g[0] + [out['g_posterior_samples']]
             out['g_prior_mus'] += buf_g[1]
             out['g_prior_logvars'] += buf_g[2]
@@ -348,7 +355,8 @@ class Flow_Mixture_Loss(nn.Module):
         self.PNLL, self.GNLL, self.GENT = FlowMixtureNLL(), GaussianFlowNLL(), GaussianEntropy()
 
     def _combine(self, pnll, output_prior):
-        gnll = self.GNLL(output_prior['g_prior_samples'], output_prior['g_prior_mus'], output_prior['g_prior_logvars'])
+        gnll = self.GNLL(output_prior['g_prior_samples'], output_prior['g_prior_mus'], output_prior['g_prior_logvars'],
+                         output_prior.get('_g_prior_logvars_stacked'))
         gent = self.GENT(output_prior['g_posterior_logvars'])
         return self.pnll_weight * pnll + self.gnll_weight * gnll - self.gent_weight * gent, pnll, gnll, gent
 

@@ -175,6 +175,9 @@ class GlobalRNVPDecoder(nn.Module):
                                                  eps, mode, training)
         if g.shape[0] != rows:
             gs, mus, lvs = (t[:, row0:row0 + rows] for t in (gs, mus, lvs))
+        # the lists below are unbound views of these stacked tensors: a consumer that only needs sum_j logvars_j (GaussianFlowNLL) can
+        # take lvs.sum(0) -- one kernel forward, one expand backward -- instead of 2 n_flows - 1 adds and an UnbindBackward per slot
+        _STACKED[self] = (gs, mus, lvs)
         if training:
             # running = (1 - m) running + m batch, unbiased batch variance, num_batches_tracked += 1 (nn.BatchNorm1d)
             B = g.shape[0]
@@ -201,6 +204,7 @@ class GlobalRNVPDecoder(nn.Module):
         fill the other 255 compute units -- in between: the prior flow then costs no time on the critical path, forward or
         backward (autograd runs a node's backward on the stream of its forward).  Capturable: the fork / join pair becomes a
         branch of the hipGraph.  Falls back to the synchronous evaluation when the fused path does not apply."""
+        _STACKED.pop(self, None)
         if not self._fused_ok(g, self._rows_seen(g)):
             return _PriorResult(self.forward(g, mode), None, None)
         cur = torch.cuda.current_stream(g.device)
@@ -221,6 +225,7 @@ class GlobalRNVPDecoder(nn.Module):
         return g.shape[0]
 
     def forward(self, g, mode='direct'):
+        _STACKED.pop(self, None)
         if self._fused_ok(g, self._rows_seen(g)):
             return self._forward_fused(g, mode)
         gs, mus, logvars = [], [], []
@@ -238,6 +243,14 @@ class GlobalRNVPDecoder(nn.Module):
 
 
 _SIDE_STREAMS = {}
+# module -> the stacked (gs, mus, logvars) of its LAST fused forward (kept outside the module: graph tensors in a module's __dict__
+# would break copy.deepcopy / pickling of a model that has run)
+import weakref
+_STACKED = weakref.WeakKeyDictionary()
+
+
+def stacked_lists(module):
+    return _STACKED.get(module)
 
 
 class _PriorResult:
@@ -312,9 +325,12 @@ class _PriorFlowFn(torch.autograd.Function):
 class GaussianFlowNLL(nn.Module):
     """reference losses.py:24-33: 0.5 * (sum(sum_j logvars_j + (z - mu0)^2 / exp(logvar0)) / B + G log 2 pi)."""
 
-    def forward(self, samples, mus, logvars):
+    def forward(self, samples, mus, logvars, stacked_flow_logvars=None):
+        """stacked_flow_logvars: logvars[1:] as ONE (2 n_flows, B, G) tensor when the fused prior flow produced them (same values;
+        the sum then costs one kernel instead of 2 n_flows adds)."""
         z, B, G = samples[0], samples[0].shape[0], samples[0].shape[1]
-        total = torch.sum(sum(logvars) + (z - mus[0]) ** 2 / torch.exp(logvars[0])) / B
+        lv_sum = sum(logvars) if stacked_flow_logvars is None else logvars[0] + stacked_flow_logvars.sum(0)
+        total = torch.sum(lv_sum + (z - mus[0]) ** 2 / torch.exp(logvars[0])) / B
         return 0.5 * (total + float(np.log(2.0 * np.pi)) * G)
 
 

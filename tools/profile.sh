@@ -10,7 +10,12 @@ for w in airplane m1; do
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$w -o $w -- python3 bench.py --workload $w --no-cpu-baseline --no-also --eager --steps 5 --warmup 2 > $OUT/pmc_fetch_$w.log 2>&1
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$w -o $w -- python3 bench.py --workload $w --no-cpu-baseline --no-also --eager --steps 5 --warmup 2 > $OUT/pmc_write_$w.log 2>&1
 done
-python3 tools/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
+# HBM traffic of the stack kernel for the other bench shapes (roofline.traffic of the `also` records): FETCH_SIZE / WRITE_SIZE only
+for w in ae svr k16; do
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$w -o $w -- python3 bench.py --workload $w --no-cpu-baseline --no-also --eager --steps 5 --warmup 2 > $OUT/pmc_fetch_$w.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$w -o $w -- python3 bench.py --workload $w --no-cpu-baseline --no-also --eager --steps 5 --warmup 2 > $OUT/pmc_write_$w.log 2>&1
+done
+python3 tools/summarize_profile.py $OUT $TAG > $OUT/summary.txt 2>&1
 for w in airplane m1; do echo "bench.py's own line under the profiler ($w): $(grep -o '"value": [0-9.]*' $OUT/trace_$w.log | head -1), $(grep -o '"kernel_ms": [0-9.]*' $OUT/trace_$w.log | head -1)" >> $OUT/summary.txt; done
 cat $OUT/summary.txt
 # keep what the summaries cite, drop the bulky raw traces (gpurun merges at most 64 MiB back)
