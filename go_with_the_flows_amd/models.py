@@ -90,8 +90,9 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
                 return out
             buf_g = self.g_prior(out['g_posterior_samples'], mode='inverse')
             from .prior import stacked_lists
-            if stacked_lists(self.g_prior) is not None:
-                out['_g_prior_logvars_stacked'] = stacked_lists(self.g_prior)[2]
+            stacked = stacked_lists(self.g_prior)
+            if stacked is not None:
+                out['_g_prior_logvars_stacked'] = stacked[2]
             out['g_prior_samples'] = buf_g[0] + [out['g_posterior_samples']]
         elif self.mode == 'generating':
             out['g_prior_samples'] = [self.reparameterize(out['g_prior_mus'][0], out['g_prior_logvars'][0])]

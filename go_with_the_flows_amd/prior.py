@@ -250,7 +250,9 @@ _STACKED = weakref.WeakKeyDictionary()
 
 
 def stacked_lists(module):
-    return _STACKED.get(module)
+    """ONE-SHOT: hands the stacked tensors of the module's last fused forward over and forgets them -- the entry must not keep
+    an autograd graph alive beyond the step that made it (a hipGraph capture crashes when an earlier iteration's graph lives)."""
+    return _STACKED.pop(module, None)
 
 
 class _PriorResult:
