@@ -109,12 +109,12 @@ def cpu_baseline(cfg, budget_s=15.0):
                       f'(min / max = slowest / fastest rep)'}
 
 
-def _run_bench_train(extra_args, env, timeout=200, graph=True):
+def _run_bench_train(extra_args, env, timeout=200, graph=True, steps=20):
     """One run of tools/bench_train.py in a child process -> {label: ms per step} parsed from its report, or {'error': ...}."""
     import subprocess
     here = os.path.dirname(os.path.abspath(__file__))
     try:
-        r = subprocess.run([sys.executable, os.path.join(here, 'tools', 'bench_train.py'), '--steps', '20'] + (['--graph'] if graph else []) + extra_args,
+        r = subprocess.run([sys.executable, os.path.join(here, 'tools', 'bench_train.py'), '--steps', str(steps)] + (['--graph'] if graph else []) + extra_args,
                            cwd=here, env=env, capture_output=True, text=True, timeout=timeout)
     except Exception as e:      # a secondary figure must never cost the headline line
         return {'error': repr(e)[:300]}
@@ -128,7 +128,7 @@ def _run_bench_train(extra_args, env, timeout=200, graph=True):
     return ms
 
 
-def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backend='nccl', share_device=False):
+def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backend='nccl', share_device=False, steps=20):
     """The airplane config's whole training step (encoder + posterior + prior flow + 4 decoders with batch-statistic BatchNorm +
     mixture NLL + backward in one hipGraph, fused AMSGrad), timed by tools/bench_train.py in child processes after the headline
     measurement.  Secondary figures: never part of `value`.
@@ -149,13 +149,13 @@ def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backen
     if world == 1:
         for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_PORT', 'GWTF_FORCE_SHARDED'):
             base_env.pop(k, None)
-        ms = _run_bench_train(['--api', 'both'], base_env)
+        ms = _run_bench_train(['--api', 'both'], base_env, steps=steps)
         if 'hipGraph' not in ms:
             return ms if 'error' in ms else {'error': 'no hipGraph line'}
-        rec = {'ms_per_step': ms['hipGraph'], 'eager_ms_per_step': ms.get('eager'), 'steps': 20,
+        rec = {'ms_per_step': ms['hipGraph'], 'eager_ms_per_step': ms.get('eager'), 'steps': steps,
                'list_api_ms_per_step': ms.get('hipGraph list API'),        # the reference's own call: model(g, p) -> lists -> loss
                'workload': wl + ', B=64'}
-        sh = _run_bench_train([], dict(base_env, GWTF_FORCE_SHARDED='1'))
+        sh = _run_bench_train([], dict(base_env, GWTF_FORCE_SHARDED='1'), steps=steps)
         rec['data_parallel_path_1rank'] = ({'ms_per_step': sh.get('hipGraph'), 'statistic_all_reduces_in_graph': sh.get('collectives'),
                                             'note': 'SyncBatchNorm model, phase-split pipeline, every collective captured in the hipGraph, '
                                                     'RCCL 1-rank group'} if 'hipGraph' in sh else sh)
@@ -172,13 +172,13 @@ def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backen
     env = dict(base_env, RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1')
     env.pop('GWTF_FORCE_SHARDED', None)
     rec = {'workload': wl + f', {world} ranks, SyncBatchNorm + overlapped gradient all-reduce, all collectives inside the graph',
-           'steps': 20}
+           'steps': steps}
     for label, per_rank, port in (('global_batch_64', max(2, 64 // world), ports[0]), ('per_rank_batch_64', 64, ports[1])):
         # rehearsal on one GPU (--backend gloo --share-device): gloo's collectives are host-side, so no graph -- the eager step only
         graph = backend == 'nccl'
         key = 'hipGraph' if graph else 'eager'
         ms = _run_bench_train(['--batch', str(per_rank), '--backend', backend] + (['--share-device'] if share_device else []),
-                              dict(env, MASTER_PORT=str(port)), timeout=150, graph=graph)   # a hang must not cost the headline line
+                              dict(env, MASTER_PORT=str(port)), timeout=150, graph=graph, steps=steps)   # a hang must not cost the headline line
         ok = torch.tensor([1.0 if ms.get('rc') == 0 and (rank != 0 or key in ms) else 0.0], device=dev if graph else 'cpu')
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)            # also keeps the parents in step between the two runs
         if float(ok) == 0.0:
@@ -359,6 +359,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-also', action='store_true', help='skip the secondary M1 (north-star shape) measurement')
     ap.add_argument('--no-train-step', action='store_true', help='skip the secondary whole-model training-step measurement')
+    ap.add_argument('--train-step-steps', type=int, default=20, help='timed steps of the secondary training-step measurement')
     ap.add_argument('--also-select', default='m1,ae,svr,k16,k16_b1,train_step',
                     help='comma list of the secondary measurements to run beside the airplane headline')
     ap.add_argument('--eager', action='store_true', help='launch through the eager module path instead of one hipGraph per step')
@@ -419,7 +420,7 @@ def main():
                           'workload': a['cfg']['name'], 'roofline': roofline_record(name, a)}
 
         if not args.no_train_step and 'train_step' in selected:
-            ts = train_step_record(world, rank, local_rank, dist, dev, args.backend, args.share_device)      # N > 1: every rank takes part (one child per GPU)
+            ts = train_step_record(world, rank, local_rank, dist, dev, args.backend, args.share_device, args.train_step_steps)      # N > 1: every rank takes part (one child per GPU)
             if rank == 0:
                 also['train_step'] = ts
 

@@ -45,7 +45,7 @@ def test_gpus_2_spawns_itself_and_reports_the_aggregate():
 def test_gpus_2_training_step_record_rehearsal():
     """bench.py --gpus 2 also times the data-parallel training step (one child per rank, the children form their own group):
     rehearsed on the one card over gloo (eager step: gloo's collectives are host-side, nothing to capture)."""
-    line = _run(['--gpus', '2', '--backend', 'gloo', '--share-device', '--also-select', 'train_step'])
+    line = _run(['--gpus', '2', '--backend', 'gloo', '--share-device', '--also-select', 'train_step', '--train-step-steps', '2'])
     ts = line['also']['train_step']
     for label, b in (('global_batch_64', 32), ('per_rank_batch_64', 64)):
         assert 'error' not in ts[label] and ts[label]['per_rank_batch'] == b and ts[label]['ms_per_step'] > 0, ts
