@@ -25,134 +25,6 @@ constexpr int kCols = 64;            // output (pass 1) / input (pass 2) columns
 
 struct HeadDims { int B, Din, Dout; };
 
-// C (M x N) [+]= A (M x K) . B^T (N x K), M <= 128, N <= 64, for the whole workgroup, operands read STRAIGHT from global memory /
-// L2 into the MFMA's registers (v_mfma_f32_16x16x4_f32: exact fp32 products) -- no LDS staging, no barriers: the staged version
-// of gwtf_gemm.h (built for the prior flow's chain of tiny dependent products) spent ~6 us per 64-wide K chunk on scalar
-// staging loads here (g_posterior forward + backward 550 us against 150 us for the library path; tools/diag/heads_time.py).
-// A(i, k) at A + i*sai + k*sak, B(j, k) at Bm + j*sbj + k*sbk.  A K step covers 16 k values: lane (r = lane & 15, q = lane >> 4)
-// holds k = k0 + 4q .. 4q+3 of row r -- ONE 16-byte load when k is the contiguous index (sak == 1, everything 16-byte aligned),
-// four 4-byte loads otherwise (coalesced over the 16 rows when the row index is the contiguous one) -- and MFMA j of the step
-// consumes element j: both operands use the same k order, which is all a contraction needs.
-// Wave w owns column tile w & 3 and the row tiles (w >> 2), (w >> 2) + 2, ...: up to 4 accumulators.
-// Loads carry NO lane-dependent control flow and no select between them (a select after a load is a wait for THAT load: the
-// first version serialised its 12 loads per pass that way, 57 us per launch): rows beyond M / N are read from a clamped
-// (valid) address and simply never stored -- a row of A or B only feeds its own output row / column -- and only the K tail,
-// which does feed valid outputs, is zeroed, after all loads of the pass have been issued.
-template <bool VEC>
-__device__ __forceinline__ f32x4 load_k4_full(const float* __restrict__ rowp, long sk, int k) {
-  f32x4 v;
-  if (VEC) {
-    v = *reinterpret_cast<const f32x4*>(rowp + k);
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = rowp[(long)(k + j) * sk];
-  }
-  return v;
-}
-__device__ __forceinline__ f32x4 load_k4_tail(const float* __restrict__ rowp, long sk, int k, int K) {
-  f32x4 v;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = rowp[(long)min(k + j, K - 1) * sk];
-  return v;
-}
-__device__ __forceinline__ f32x4 zero_tail(f32x4 v, int k, int K) {
-#pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = k + j < K ? v[j] : 0.f;
-  return v;
-}
-template <bool AVEC, bool BVEC, int CNT>
-__device__ __forceinline__ void gemm_wave(int M, int N, int K, const float* __restrict__ A, long sai, long sak,
-                                          const float* __restrict__ Bm, long sbj, long sbk, float* __restrict__ C, long ldc,
-                                          bool accumulate, int nt, int m0, int r16, int q) {
-  constexpr int U = 4;                                         // a pass = 4 steps of 16 k: one memory round trip per 64 k
-  f32x4 acc[CNT];
-  const float* arow[CNT];
-#pragma unroll
-  for (int u = 0; u < CNT; ++u) {
-    acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-    arow[u] = A + (long)min(16 * (m0 + 2 * u) + r16, M - 1) * sai;
-  }
-  const float* brow = Bm + (long)min(16 * nt + r16, N - 1) * sbj;
-  int k0 = 0;
-  // (Measured and rejected: issuing pass p + 1's loads before pass p's MFMAs -- two passes of operands in registers -- made
-  // every product SLOWER, 255 -> 344 us for the g_posterior module: hipcc serialises the doubled register set.)
-#pragma unroll 1
-  for (; k0 + 16 * U <= K; k0 += 16 * U) {
-    f32x4 a[U][CNT], b[U];
-#pragma unroll
-    for (int s = 0; s < U; ++s) {
-      const int ks = k0 + 16 * s + 4 * q;
-      b[s] = load_k4_full<BVEC>(brow, sbk, ks);
-#pragma unroll
-      for (int u = 0; u < CNT; ++u) a[s][u] = load_k4_full<AVEC>(arow[u], sak, ks);
-    }
-#pragma unroll
-    for (int s = 0; s < U; ++s)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int u = 0; u < CNT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][u][j], b[s][j], acc[u], 0, 0, 0);
-  }
-  if (k0 < K) {                                                // the K tail (wave-uniform branch): clamped loads, then zeros
-    f32x4 ta[U][CNT], tb[U];
-#pragma unroll
-    for (int s = 0; s < U; ++s) {
-      const int ks = k0 + 16 * s + 4 * q;
-      tb[s] = load_k4_tail(brow, sbk, ks, K);
-#pragma unroll
-      for (int u = 0; u < CNT; ++u) ta[s][u] = load_k4_tail(arow[u], sak, ks, K);
-    }
-#pragma unroll
-    for (int s = 0; s < U; ++s) {
-      const int ks = k0 + 16 * s + 4 * q;
-      tb[s] = zero_tail(tb[s], ks, K);
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int u = 0; u < CNT; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[s][u][j], tb[s][j], acc[u], 0, 0, 0);
-    }
-  }
-  const int n = 16 * nt + r16;
-  if (n < N) {
-#pragma unroll
-    for (int u = 0; u < CNT; ++u) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = 16 * (m0 + 2 * u) + 4 * q + r;
-        if (m < M) {
-          const long o = (long)m * ldc + n;
-          C[o] = accumulate ? C[o] + acc[u][r] : acc[u][r];
-        }
-      }
-    }
-  }
-}
-template <bool AVEC, bool BVEC>
-__device__ __forceinline__ void gemm_direct_t(int M, int N, int K, const float* __restrict__ A, long sai, long sak,
-                                              const float* __restrict__ Bm, long sbj, long sbk, float* __restrict__ C, long ldc,
-                                              bool accumulate) {
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
-  const int MT = (M + 15) / 16, NT = (N + 15) / 16;
-  const int nt = wave & 3, m0 = wave >> 2;                      // wave w: column tile w & 3, row tiles (w >> 2), (w >> 2) + 2, ...
-  if (nt >= NT || m0 >= MT) return;
-  switch ((MT - m0 + 1) / 2) {                                 // row tiles of this wave: wave-uniform
-    case 1: gemm_wave<AVEC, BVEC, 1>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate, nt, m0, r16, q); break;
-    case 2: gemm_wave<AVEC, BVEC, 2>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate, nt, m0, r16, q); break;
-    case 3: gemm_wave<AVEC, BVEC, 3>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate, nt, m0, r16, q); break;
-    default: gemm_wave<AVEC, BVEC, 4>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate, nt, m0, r16, q); break;
-  }
-}
-__device__ __forceinline__ void gemm_direct(int M, int N, int K, const float* __restrict__ A, long sai, long sak,
-                                            const float* __restrict__ Bm, long sbj, long sbk, float* __restrict__ C, long ldc,
-                                            bool accumulate) {
-  // 16-byte loads where k is the contiguous index and every row starts 16-byte aligned (wave-uniform decision)
-  const bool avec = sak == 1 && (sai & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
-  const bool bvec = sbk == 1 && (sbj & 3) == 0 && (reinterpret_cast<size_t>(Bm) & 15) == 0;
-  if (avec && bvec) gemm_direct_t<true, true>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate);
-  else if (avec) gemm_direct_t<true, false>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate);
-  else gemm_direct_t<false, false>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate);
-}
-
 // s = BatchNorm(y) for a column given its statistics
 __device__ __forceinline__ float bn_apply(float y, float mean, float rstd, float ga, float be) { return fmaf((y - mean) * rstd, ga, be); }
 

@@ -1,6 +1,8 @@
 // gwtf_prior.hip -- the global prior flow on the shape latent: the whole GlobalRNVPDecoder (reference
 // lib/networks/decoders.py:7-38: n_flows RealNVPFlowCouple = 2 n_flows elementary RealNVPFlow, flows.py:163-243) as ONE
 // launch per direction, forward and backward, eval- and train-mode BatchNorm.
+// Round 3: the products run on gwtf_gemm.h's gemm_direct (operands straight from L2 into the MFMA's registers, no LDS staging, no
+// barrier inside a product) instead of the LDS-staged version below it in that header: see the timing note at gwtf_prior_forward.
 //
 // The work is per SHAPE: B <= 128 rows of G latents through 14 flows of two (B x G/2)(G/2 x F) -> BN -> Swish ->
 // (B x F)(F x G/2) MLPs -- a few MFLOP, a chain of ~40 dependent steps.  The reference (and round 1 of this repo) runs it as
@@ -82,7 +84,7 @@ __device__ __forceinline__ void hidden_layer(const Plan& P, const Geom& ge, cons
   const int B = P.B, F = P.F, G = P.G;
   for (int x = 0; x < 2; ++x) {
     const Branch br = branch_of(raw, ge, F, x);
-    gemm_staged(B, F, ge.Gk, gin + ge.koff, G, ge.kstride, br.W0, ge.Gk, 1, hws + (size_t)x * F, 2 * F, false, As, Bs);
+    gemm_direct(B, F, ge.Gk, gin + ge.koff, G, ge.kstride, br.W0, ge.Gk, 1, hws + (size_t)x * F, 2 * F, false);
   }
   phase_sync();
   {
@@ -134,8 +136,8 @@ __global__ __launch_bounds__(kThreads) void prior_fwd_kernel(const Plan P, const
     float* mo = mus + j * BG;
     float* lo = lvs + j * BG;
     const Branch bm = branch_of(raw, ge, F, 0), bl = branch_of(raw, ge, F, 1);
-    gemm_staged(B, ge.Gw, F, hws, 2 * F, 1, bm.W1, F, 1, O, 2 * Gwmax, false, As, Bs);
-    gemm_staged(B, ge.Gw, F, hws + F, 2 * F, 1, bl.W1, F, 1, O + Gwmax, 2 * Gwmax, false, As, Bs);
+    gemm_direct(B, ge.Gw, F, hws, 2 * F, 1, bm.W1, F, 1, O, 2 * Gwmax, false);
+    gemm_direct(B, ge.Gw, F, hws + F, 2 * F, 1, bl.W1, F, 1, O + Gwmax, 2 * Gwmax, false);
     phase_sync();
     // the affine map on the warped latents; kept latents pass through (mu = logvar = 0 there: exp(0) * g + 0)
     for (int t = threadIdx.x; t < B * G; t += kThreads) {
@@ -185,6 +187,13 @@ __global__ __launch_bounds__(kThreads) void prior_bwd_kernel(const Plan P, const
   phase_sync();
   float* Gcur = GA;
   float* Gnext = GB;
+#ifdef GWTF_DBG_PRIOR_STAMPS
+  unsigned long long* stamps = reinterpret_cast<unsigned long long*>(g_raw + geom_at(P.n2 - 1, G, F).raw + (size_t)F * geom_at(P.n2 - 1, G, F).Gk + 2 * F);
+  int n_st = 0;
+#define GWTF_STAMP() do { if (step == 1 && threadIdx.x == 0) stamps[n_st++] = wall_clock64(); } while (0)
+#else
+#define GWTF_STAMP() do {} while (0)
+#endif
   for (int step = 0; step < P.n2; ++step) {
     const int j = P.mode == GWTF_MODE_DIRECT ? P.n2 - 1 - step : step;       // reverse of the forward's processing order
     const Geom ge = geom_at(j, G, F);
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(kThreads) void prior_bwd_kernel(const Plan P, const
     const Branch bm = branch_of(raw, ge, F, 0), bl = branch_of(raw, ge, F, 1);
     float* gr = g_raw + ge.raw;
     const size_t BF = branch_floats(F, ge.Gw, ge.Gk);
+    GWTF_STAMP();
     // ---- B1: through the affine map: dO (both branches), the warped part of the next flowing gradient
     for (int t = threadIdx.x; t < B * ge.Gw; t += kThreads) {
       const int b = t / ge.Gw, w = t % ge.Gw;
@@ -218,16 +228,18 @@ __global__ __launch_bounds__(kThreads) void prior_bwd_kernel(const Plan P, const
       dO[((size_t)b * 2 + 1) * Gwmax + w] = dlv * (1.0f - P.eps * expf(-lv));     // lv = log(eps + e^o): dlv/do = e^o / (eps + e^o)
       Gnext[o] = dx;
     }
+    GWTF_STAMP();
     // ---- B2: recompute the hidden layer (H, XH, statistics used); its barriers also cover B1's stores
     hidden_layer<TRAIN>(P, ge, raw, xin, H, XH, ST, nullptr, As, Bs);
+    GWTF_STAMP();
     // ---- B3: dH = dO . W1 ; dW1 = dO^T . H ; db1 = column sums of dO
     for (int x = 0; x < 2; ++x) {
       const float* W1 = x == 0 ? bm.W1 : bl.W1;
-      gemm_staged(B, F, ge.Gw, dO + (size_t)x * Gwmax, 2 * Gwmax, 1, W1, 1, F, DH + (size_t)x * F, 2 * F, false, As, Bs);
+      gemm_direct(B, F, ge.Gw, dO + (size_t)x * Gwmax, 2 * Gwmax, 1, W1, 1, F, DH + (size_t)x * F, 2 * F, false);
       float* dW1 = gr + (size_t)x * BF + (size_t)F * ge.Gk + 4 * (size_t)F;
       for (int w0 = 0; w0 < ge.Gw; w0 += kMaxM) {
         const int wn = ge.Gw - w0 < kMaxM ? ge.Gw - w0 : kMaxM;
-        gemm_staged(wn, F, B, dO + (size_t)x * Gwmax + w0, 1, 2 * Gwmax, H + (size_t)x * F, 1, 2 * F, dW1 + (size_t)w0 * F, F, false, As, Bs);
+        gemm_direct(wn, F, B, dO + (size_t)x * Gwmax + w0, 1, 2 * Gwmax, H + (size_t)x * F, 1, 2 * F, dW1 + (size_t)w0 * F, F, false);
       }
       for (int w0 = 0; w0 < ge.Gw; w0 += 256) {
         const int wn = ge.Gw - w0 < 256 ? ge.Gw - w0 : 256;
@@ -237,6 +249,7 @@ __global__ __launch_bounds__(kThreads) void prior_bwd_kernel(const Plan P, const
       }
     }
     phase_sync();
+    GWTF_STAMP();
     // ---- B4: through Swish and BatchNorm: DH <- dL/dHpre; dgamma, dbeta
     {
       const ColMap cm = col_map(2 * F);
@@ -268,11 +281,12 @@ __global__ __launch_bounds__(kThreads) void prior_bwd_kernel(const Plan P, const
       }
     }
     phase_sync();
+    GWTF_STAMP();
     // ---- B5: dkept = dHpre . W0 (both branches summed) ; dW0 = dHpre^T . kept
     for (int x = 0; x < 2; ++x) {
       const float* W0 = x == 0 ? bm.W0 : bl.W0;
-      gemm_staged(B, ge.Gk, F, DH + (size_t)x * F, 2 * F, 1, W0, 1, ge.Gk, DK, ge.Gk, x == 1, As, Bs);   // same lane wrote x == 0
-      gemm_staged(F, ge.Gk, B, DH + (size_t)x * F, 1, 2 * F, xin + ge.koff, ge.kstride, G, gr + (size_t)x * BF, ge.Gk, false, As, Bs);
+      gemm_direct(B, ge.Gk, F, DH + (size_t)x * F, 2 * F, 1, W0, 1, ge.Gk, DK, ge.Gk, x == 1);   // same lane wrote x == 0
+      gemm_direct(F, ge.Gk, B, DH + (size_t)x * F, 1, 2 * F, xin + ge.koff, ge.kstride, G, gr + (size_t)x * BF, ge.Gk, false);
     }
     phase_sync();
     for (int t = threadIdx.x; t < B * ge.Gk; t += kThreads) {
@@ -281,6 +295,7 @@ __global__ __launch_bounds__(kThreads) void prior_bwd_kernel(const Plan P, const
       Gnext[o] = Gcur[o] + (Ggs ? Ggs[(size_t)j * BG + o] : 0.f) + DK[(size_t)b * ge.Gk + kk];
     }
     phase_sync();
+    GWTF_STAMP();
     float* tmp = Gcur; Gcur = Gnext; Gnext = tmp;
   }
   for (int t = threadIdx.x; t < (int)BG; t += kThreads) dg0[t] = Gcur[t];
