@@ -96,6 +96,8 @@ _SIGNATURES = {
     'gwtf_bn_running_update': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_gather_table': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_mtrain_dw1_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'gwtf_stat_compact': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_stat_expand': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_mtrain_phase': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'gwtf_mtrain_forward': (ctypes.c_int, [ctypes.c_void_p]),
     'gwtf_mtrain_backward': (ctypes.c_int, [ctypes.c_void_p]),

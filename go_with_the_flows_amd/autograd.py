@@ -518,9 +518,25 @@ COLLECTIVES = {'n': 0}        # statistic all-reduces issued by TrainMixtureFn (
 GRAD_SINK = {'reducer': None}  # set by dist.OverlappedGradients: receives the decoders' flat gradient as soon as it exists
 
 
-def _stat_sum(t):
+def _stat_sum(t, replicated_k=0):
+    """Sum a statistic slab over the ranks, in place.  replicated_k = K > 0: `t` is a forward slab [K][64 copies][n] accumulated by
+    atomics spread over 64 copies (csrc/gwtf_layout.h GWTF_STAT_REPLICAS): the copies are summed into a contiguous [K][n] exchange
+    buffer first and the result written back as copy 0 (gwtf_stat_compact / gwtf_stat_expand) -- 3 KB instead of 196 KB per
+    collective at f = 37, K = 4.  Costs two small launches per collective (measured on the 1-rank RCCL path: 12.9 -> 14.1 ms per
+    airplane step for the 67 forward collectives), which only a real wire pays back: done when the group has more than one rank,
+    or when GWTF_COMPACT_STAT_COLLECTIVES=1 asks for it (tests run the 1-rank path both ways)."""
+    import os
     import torch.distributed as dist
     COLLECTIVES['n'] += 1
+    if replicated_k and (dist.get_world_size() > 1 or os.environ.get('GWTF_COMPACT_STAT_COLLECTIVES') == '1'):
+        L = _lib.lib()
+        n = t.numel() // (replicated_k * _lib.STAT_REPLICAS)
+        xchg = torch.empty(replicated_k, n, device=t.device, dtype=torch.float32)
+        st = _lib._stream(t)
+        _lib.check(L.gwtf_stat_compact(t.data_ptr(), xchg.data_ptr(), replicated_k, n, st))
+        dist.all_reduce(xchg, op=dist.ReduceOp.SUM)
+        _lib.check(L.gwtf_stat_expand(t.data_ptr(), xchg.data_ptr(), replicated_k, n, st))
+        return
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
@@ -568,14 +584,14 @@ class TrainMixtureFn(torch.autograd.Function):
             else:
                 mom, ys = bufs['moments'], bufs['ystats']
                 _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_INIT, 0))
-                _stat_sum(mom[0, 0])
+                _stat_sum(mom[0, 0], 1)                        # the shared input clouds' moments: one record
                 for step in range(C):
                     c = step if mode == 'direct' else C - 1 - step
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_A, step))
-                    _stat_sum(ys[c])
+                    _stat_sum(ys[c], K)
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_B, step))
                     if step + 1 < C:
-                        _stat_sum(mom[step + 1])
+                        _stat_sum(mom[step + 1], K)
         out = bufs['xbuf'][L.gwtf_mtrain_final_forward_half(C)].clone()
         ctx.save_for_backward(p, raw, lists[0], pw, pb, bufs['film_rec'], film_raw, bufs['moments'], bufs['ystats'])
         ctx.meta = (int(K), int(C), int(f), int(G), int(FP), int(pattern0), float(eps), mode, float(n_total), bool(sharded))

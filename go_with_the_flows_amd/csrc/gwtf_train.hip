@@ -841,6 +841,37 @@ extern "C" int gwtf_gather_table(const unsigned long long* table, float* dst, in
   return (int)hipGetLastError();
 }
 
+// ---- statistic slabs on the wire (data-parallel runs) ---------------------------------------------------------------------------------
+// The forward statistics are accumulated by atomics spread over GWTF_STAT_REPLICAS = 64 copies (moments [K][64][16], ystats
+// [K][64][2 FP 2]).  All-reducing a slab as it stands sends 64 x the information (196 KB instead of 3 KB per collective at f = 37,
+// K = 4: no longer a latency-only message on xGMI).  gwtf_stat_compact sums the copies into a contiguous exchange buffer
+// xchg [K][n]; after the all-reduce gwtf_stat_expand writes the global sums back as copy 0 and zeroes the others, so every consumer
+// (the fold kernels sum the copies) reads the global statistic without knowing.
+namespace {
+__global__ __launch_bounds__(256) void stat_compact_kernel(const float* __restrict__ slab, float* __restrict__ xchg, int R, int n) {
+  const float* s = slab + (size_t)blockIdx.x * R * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r) acc += s[(size_t)r * n + i];       // fixed order: the same sum on every run
+    xchg[(size_t)blockIdx.x * n + i] = acc;
+  }
+}
+__global__ __launch_bounds__(256) void stat_expand_kernel(float* __restrict__ slab, const float* __restrict__ xchg, int R, int n) {
+  float* s = slab + (size_t)blockIdx.x * R * n;
+  for (int t = threadIdx.x; t < R * n; t += blockDim.x) s[t] = t < n ? xchg[(size_t)blockIdx.x * n + t] : 0.f;
+}
+}  // namespace
+extern "C" int gwtf_stat_compact(const float* slab, float* xchg, int K, int n, void* stream) {
+  if (!slab || !xchg || K <= 0 || n <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(stat_compact_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, slab, xchg, GWTF_STAT_REPLICAS, n);
+  return (int)hipGetLastError();
+}
+extern "C" int gwtf_stat_expand(float* slab, const float* xchg, int K, int n, void* stream) {
+  if (!slab || !xchg || K <= 0 || n <= 0) return GWTF_E_BADARG;
+  hipLaunchKernelGGL(stat_expand_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, slab, xchg, GWTF_STAT_REPLICAS, n);
+  return (int)hipGetLastError();
+}
+
 // which half of xbuf / g_bufs holds the final coordinates / dL/dp of component k: base + half * K*B*3*N + k * B*3*N
 extern "C" int gwtf_mtrain_final_forward_half(int C) { return (C - 1) & 1; }
 extern "C" int gwtf_mtrain_final_backward_half(int C, int mode) { return (mode == GWTF_MODE_INVERSE ? C - 1 : 0) & 1; }

@@ -262,6 +262,11 @@ int gwtf_bn_running_update(const unsigned long long* table, const float* src, co
 /* dst[offset_i .. + numel_i) = src_i for n small tensors in one launch: table [n][3] = {src device pointer, offset, numel}
  * (floats).  Builds a stack's raw arena from its parameter / buffer tensors (the host mirror's torch.cat, one launch). */
 int gwtf_gather_table(const unsigned long long* table, float* dst, int n, void* stream);
+/* A replicated forward-statistic slab [K][64 copies][n] (moments: n = 16; ystats: n = 2*FP*2) <-> a contiguous exchange buffer
+ * xchg [K][n] holding the sum over the copies: what a data-parallel run all-reduces between two phases (64 x less on the wire).
+ * gwtf_stat_expand writes xchg back as copy 0 and zeroes the other copies. */
+int gwtf_stat_compact(const float* slab, float* xchg, int K, int n, void* stream);
+int gwtf_stat_expand(float* slab, const float* xchg, int K, int n, void* stream);
 size_t gwtf_mtrain_dw1_floats(int f, int B, int N);
 int gwtf_mtrain_phase(const GwtfTrainCtx* ctx, int phase, int step);
 int gwtf_mtrain_forward(const GwtfTrainCtx* ctx);
