@@ -24,6 +24,7 @@ constexpr int kKC = 64, kPitch = kKC + 1, kMaxM = 128, kMaxN = 256, kMT = kMaxM 
 
 typedef const __attribute__((address_space(1))) float* gptr_c;   // global address space spelled out: a NOINLINE device
 typedef __attribute__((address_space(1))) float* gptr;           // function's plain pointers are generic (flat_load, slow)
+typedef __attribute__((address_space(3))) float* lptr;           // LDS, for the same reason
 
 // Not inlined on purpose: the kernels call it 4 - 10 times per flow, and inlined copies (64 accumulator + 32 staging
 // registers each, scheduled together) spilled several hundred registers.  LDS buffers are function-local statics (one
@@ -304,6 +305,156 @@ __device__ __forceinline__ void gemm_direct(int M, int N, int K, const float* __
   if (avec && bvec) gemm_direct_t<true, true>(M, N, K, (gptr_c)A, sai, sak, (gptr_c)Bm, sbj, sbk, (gptr)C, ldc, accumulate);
   else if (avec) gemm_direct_t<true, false>(M, N, K, (gptr_c)A, sai, sak, (gptr_c)Bm, sbj, sbk, (gptr)C, ldc, accumulate);
   else gemm_direct_t<false, false>(M, N, K, (gptr_c)A, sai, sak, (gptr_c)Bm, sbj, sbk, (gptr)C, ldc, accumulate);
+}
+
+// ---- split-K product for LONG contractions, NARROW output blocks ----------------------------------------------------------------------
+// The exact fp32 MFMA (v_mfma_f32_16x16x4_f32, 32 cycles) makes even these small products THROUGHPUT-bound when a workgroup owns 64
+// output columns: 64 x 64 x 512 is 2048 MFMAs = 16 k cycles on the four SIMDs of ONE compute unit (7 us) while 248 others idle
+// (measured: 12-24 us per head-layer launch).  So the head kernels give a workgroup only 16 * NJ columns (NJ = 1: 32 workgroups for a
+// 512-wide layer), and within it the EIGHT WAVES CUT K: wave w contracts the slice [w S, (w + 1) S) (S = K / 8 rounded up to 16) for
+// the four row tiles of a 64-row block -- its loads go out in one or two rounds instead of K / 64 dependent passes -- writes its
+// partial block to its own LDS slab, and all threads add the slabs in wave order (deterministic: no float atomics) into C [+]=.
+// slab: 8 * 64 * 16 NJ floats of LDS.  Operand description as gemm_direct.  Not inlined.
+template <bool AVEC, bool BVEC, int NJ>
+static __device__ __attribute__((noinline)) void gemm_splitk_t(int M, int N, int K, gptr_c Ag, long sai, long sak, gptr_c Bg, long sbj,
+                                                               long sbk, gptr Cg, long ldc, bool accumulate, lptr slab) {
+  constexpr int NC = 16 * NJ, kSlab = 64 * NC;
+  const float* A = (const float*)Ag;
+  const float* Bm = (const float*)Bg;
+  float* C = (float*)Cg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r16 = lane & 15, q = lane >> 4;
+  const int MT = (M + 15) / 16;
+  const int S = ((K + 7) / 8 + 15) / 16 * 16;
+  const int nw = (K + S - 1) / S;                                // waves with a non-empty slice
+  const int k_lo = wave * S, k_hi = min(K, k_lo + S);
+  const float* brow[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) brow[j] = Bm + (long)min(16 * j + r16, N - 1) * sbj;
+  lptr mine = slab + wave * kSlab;
+#pragma unroll 1
+  for (int mh = 0; mh < MT; mh += 4) {                           // 64 rows at a time: 4 NJ accumulators per wave
+    if (wave < nw) {
+      f32x4 acc[4][NJ];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* arow[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) arow[u] = A + (long)min(16 * (mh + u) + r16, M - 1) * sai;
+#pragma unroll 1
+      for (int k0 = k_lo; k0 < k_hi; k0 += 64) {                 // four 16-k steps per round
+        const bool tail = k0 + 64 > K;                           // wave-uniform
+        f32x4 a[4][4], b[4][NJ];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (k0 + 16 * s >= k_hi) break;                        // wave-uniform: a slice may end inside a round
+          const int ks = k0 + 16 * s + 4 * q;
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) b[s][j] = tail ? load_k4_tail(brow[j], sbk, ks, K) : load_k4_full<BVEC>(brow[j], sbk, ks);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) a[s][u] = tail ? load_k4_tail(arow[u], sak, ks, K) : load_k4_full<AVEC>(arow[u], sak, ks);
+        }
+        if (tail) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              if (k0 + 16 * s < k_hi) b[s][j] = zero_tail(b[s][j], k0 + 16 * s + 4 * q, K);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          if (k0 + 16 * s < k_hi) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                  acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][u][t], b[s][j][t], acc[u][j], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mine[(16 * u + 4 * q + r) * NC + 16 * j + r16] = acc[u][j][r];
+    }
+    __syncthreads();
+    for (int t = tid; t < kSlab; t += kThreads) {
+      const int m = 16 * mh + t / NC, n = t % NC;
+      if (m < M && n < N) {
+        float v = 0.f;
+        for (int w = 0; w < nw; ++w) v += slab[w * kSlab + t];
+        const long o = (long)m * ldc + n;
+        C[o] = accumulate ? C[o] + v : v;
+      }
+    }
+    __syncthreads();
+  }
+}
+template <int NJ>
+__device__ __forceinline__ void gemm_splitk(int M, int N, int K, const float* __restrict__ A, long sai, long sak,
+                                            const float* __restrict__ Bm, long sbj, long sbk, float* __restrict__ C, long ldc,
+                                            bool accumulate, float* slab) {
+  const bool avec = sak == 1 && (sai & 3) == 0 && (reinterpret_cast<size_t>(A) & 15) == 0;
+  const bool bvec = sbk == 1 && (sbj & 3) == 0 && (reinterpret_cast<size_t>(Bm) & 15) == 0;
+  if (avec && bvec) gemm_splitk_t<true, true, NJ>(M, N, K, (gptr_c)A, sai, sak, (gptr_c)Bm, sbj, sbk, (gptr)C, ldc, accumulate, (lptr)slab);
+  else if (avec) gemm_splitk_t<true, false, NJ>(M, N, K, (gptr_c)A, sai, sak, (gptr_c)Bm, sbj, sbk, (gptr)C, ldc, accumulate, (lptr)slab);
+  else gemm_splitk_t<false, false, NJ>(M, N, K, (gptr_c)A, sai, sak, (gptr_c)Bm, sbj, sbk, (gptr)C, ldc, accumulate, (lptr)slab);
+}
+
+// ---- C (M <= 16 MU x N) = A^T-in-LDS . B for a SHORT contraction and a WIDE output (the weight gradient of a head layer: M = the
+// workgroup's output columns of the layer, K = the batch rows (<= 128), N = Din) -- the waves cut N: wave w owns column tiles w, w + 8,
+// ... with all MU row tiles.  A(i, k) = at[k * pitch + i] sits in LDS (the dL/dy block the workgroup has just produced: rows k >= K must be finite,
+// they meet zeros); B(j, k) = Bm[j + k * sbk] (j contiguous: coalesced over the 16 lanes of a row group).
+template <int MU>
+static __device__ __attribute__((noinline)) void gemm_nsplit_lds(int M, int N, int K, lptr at, int pitch, gptr_c Bg, long sbk, gptr Cg,
+                                                                 long ldc) {
+  const float* Bm = (const float*)Bg;
+  float* C = (float*)Cg;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), r16 = lane & 15, q = lane >> 4;
+  const int NT = (N + 15) / 16;
+#pragma unroll 1
+  for (int nt = wave; nt < NT; nt += 8) {
+    f32x4 acc[MU];
+#pragma unroll
+    for (int u = 0; u < MU; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* bcol = Bm + min(16 * nt + r16, N - 1);
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      f32x4 b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b[s] = load_k4_tail(bcol, sbk, k0 + 16 * s + 4 * q, K);     // clamped: always a valid address
+      if (k0 + 64 > K) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) b[s] = zero_tail(b[s], k0 + 16 * s + 4 * q, K);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        if (k0 + 16 * s < K) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int k = k0 + 16 * s + 4 * q + t;
+#pragma unroll
+            for (int u = 0; u < MU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(at[k * pitch + 16 * u + r16], b[s][t], acc[u], 0, 0, 0);
+          }
+        }
+      }
+    }
+    const int n = 16 * nt + r16;
+    if (n < N) {
+#pragma unroll
+      for (int u = 0; u < MU; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = 16 * u + 4 * q + r;
+          if (m < M) C[(long)m * ldc + n] = acc[u][r];
+        }
+    }
+  }
 }
 
 }  // namespace gwtf_gemm

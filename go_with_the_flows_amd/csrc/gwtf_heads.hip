@@ -7,11 +7,11 @@
 //
 // ONE LAYER per launch, forward and backward:
 //   forward : y = x W^T (+ bias) -> [BatchNorm over the B rows: batch statistics, running statistics updated `bn_updates` times,
-//             or running statistics] -> [Swish | log-softmax].  A workgroup owns 64 output COLUMNS and all rows: everything
-//             BatchNorm needs (column statistics) is local to it -- no grid-wide barrier; Dout / 64 workgroups.
-//   backward: pass 1 (per block of 64 output columns): dL/dy through the activation and the BatchNorm (column sums again local),
-//             dW = dy^T x, dbias, dgamma, dbeta;   pass 2 (per block of 64 INPUT columns): dL/dx = dy W.
-// GEMMs: exact fp32 MFMA with operands straight from L2 (gemm_direct below); column sums: gwtf_gemm.h.  In a data-parallel run the caller gathers the rows of all
+//             or running statistics] -> [Swish | log-softmax].  A workgroup owns 16 output COLUMNS and all rows: everything
+//             BatchNorm needs (column statistics) is local to it -- no grid-wide barrier; Dout / 16 workgroups (the exact-fp32 MFMA makes wider blocks throughput-bound on one CU).
+//   backward: pass 1 (per block of 16 output columns): dL/dy through the activation and the BatchNorm (column sums again local),
+//             dW = dy^T x, dbias, dgamma, dbeta;   pass 2 (per block of 16 INPUT columns): dL/dx = dy W.
+// GEMMs: exact fp32 MFMA with operands straight from L2 (gwtf_gemm.h: split-K over the waves for long contractions); column sums: gwtf_gemm.h.  In a data-parallel run the caller gathers the rows of all
 // ranks first (dist.gather_rows): the kernels always see the whole batch -- SyncBatchNorm semantics without a collective inside.
 #include <hip/hip_runtime.h>
 #include "gwtf_layout.h"
@@ -21,7 +21,18 @@
 namespace {
 
 using namespace gwtf_gemm;
-constexpr int kCols = 64;            // output (pass 1) / input (pass 2) columns per workgroup
+constexpr int kNJ = 1, kCols = 16 * kNJ;   // output (pass 1) / input (pass 2) columns per workgroup: narrow, so that a 512-wide layer is 32 workgroups
+constexpr int kSplitK = 128;         // contractions at least this long are cut over the eight waves (gemm_splitk)
+constexpr int kGyPitch = kCols + 1;  // the dL/dy block in LDS for the weight gradient: [128 rows][17]
+constexpr int kWorkFloats = 8 * 64 * kCols;      // split-K slabs (32 KB); the dL/dy block (8.5 KB) reuses them
+static_assert(kWorkFloats >= kMaxM * kGyPitch, "the dL/dy block must fit the work area");
+
+// C block = A . B^T: the long contractions split over the waves, the short ones one tile per wave
+__device__ __forceinline__ void head_gemm(int M, int N, int K, const float* A, long sai, long sak, const float* Bm, long sbj, long sbk,
+                                          float* C, long ldc, bool accumulate, float* work) {
+  if (K >= kSplitK) gemm_splitk<kNJ>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate, work);
+  else gemm_direct(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate);
+}
 
 struct HeadDims { int B, Din, Dout; };
 
@@ -32,7 +43,7 @@ __device__ __forceinline__ float bn_apply(float y, float mean, float rstd, float
 // ypre [B][Dout]: the Linear's output (the BatchNorm input; kept for the backward), stats [3][Dout] = mean, biased var, rstd actually
 // used, out [B][Dout].  bn_mode 0: no BatchNorm; 1: batch statistics (+ running update, momentum form, unbiased variance, applied
 // bn_updates times: the reference evaluates p_prior once per mixture component on the same batch, models.py:169-193 inside
-// flow_mixture.py:163-166); 2: running statistics.  act 0: none, 1: swish, 2: log-softmax over the Dout (<= 64) columns.
+// flow_mixture.py:163-166); 2: running statistics.  act 0: none, 1: swish, 2: log-softmax over the Dout (<= 16) columns.
 __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const float* __restrict__ x, const float* __restrict__ W,
                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
                                                             const float* __restrict__ beta, float* __restrict__ rmean,
@@ -41,9 +52,10 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
                                                             float* __restrict__ ypre, float* __restrict__ stats,
                                                             float* __restrict__ out) {
   __shared__ float red[kThreads];
+  __shared__ float work[kWorkFloats];
   const int B = d.B, Din = d.Din, Dout = d.Dout;
   const int c0 = blockIdx.x * kCols, nc = min(kCols, Dout - c0);
-  gemm_direct(B, nc, Din, x, Din, 1, W + (size_t)c0 * Din, Din, 1, ypre + c0, Dout, false);
+  head_gemm(B, nc, Din, x, Din, 1, W + (size_t)c0 * Din, Din, 1, ypre + c0, Dout, false, work);
   phase_sync();
   const ColMap cm = col_map(kCols);
   const int col = c0 + cm.col;
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
   }
   if (bn_mode == 1 && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += bn_updates;
   if (act == 2) {
-    // log-softmax over the columns of a row (all in this workgroup: Dout <= 64): thread t < B owns row t
+    // log-softmax over the columns of a row (all in this workgroup: Dout <= kCols): thread t < B owns row t
     for (int b = threadIdx.x; b < B; b += kThreads) {
       float mx = -3.0e38f;
       for (int c = 0; c < nc; ++c) mx = fmaxf(mx, yat(b, c));
@@ -95,7 +107,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
   }
 }
 
-// ---- backward, pass 1: per block of 64 output columns ---------------------------------------------------------------------------
+// ---- backward, pass 1: per block of 16 output columns ---------------------------------------------------------------------------
 // g_out [B][Dout] = dL/d out;  writes g_y [B][Dout] = dL/d(x W^T) (scratch for pass 2), g_W [Dout][Din], g_bias / g_gamma / g_beta
 // [Dout] (each may be null).
 __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const float* __restrict__ x, const float* __restrict__ bias,
@@ -140,6 +152,10 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
     const float sg = 1.0f / (1.0f + expf(-s));
     return g * sg * (1.0f + s * (1.0f - sg));                 // d swish / ds
   };
+  __shared__ float work[kWorkFloats];
+  lptr gyt = (lptr)work;                                      // dL/dy block [row][col], pitch 17, zero beyond the batch rows
+  for (int t = threadIdx.x; t < kMaxM * kGyPitch; t += kThreads) gyt[t] = 0.f;
+  __syncthreads();
   float sum_ds = 0.f, sum_dsx = 0.f;
   if (bn_mode != 0 || g_bias) {
     sum_ds = col_sum(cm, kCols, B, [&](int b, int c) { return ds_at(b, c, mean, rstd, ga, be, bi); }, red);
@@ -166,20 +182,20 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
         gy = ga * rstd * gy;
       }
       g_y[o] = gy;
+      gyt[b * kGyPitch + cm.col] = gy;
     }
   }
-  phase_sync();
-  // dW[c0 .. c0 + nc)[:] = g_y[:, block]^T x : M = nc, K = B, N = Din in chunks of 64
-  if (g_W)
-    for (int n0 = 0; n0 < Din; n0 += kCols)
-      gemm_direct(nc, min(kCols, Din - n0), B, g_y + c0, 1, Dout, x + n0, 1, Din, g_W + (size_t)c0 * Din + n0, Din, false);
+  __syncthreads();
+  // dW[c0 .. c0 + nc)[:] = g_y[:, block]^T x : M = nc, K = B, N = Din; the dL/dy operand from LDS, the waves cut Din
+  if (g_W) gemm_nsplit_lds<kNJ>(nc, Din, B, gyt, kGyPitch, (gptr_c)x, Din, (gptr)(g_W + (size_t)c0 * Din), Din);
 }
 
-// ---- backward, pass 2: per block of 64 input columns: g_x[:, block] (+)= g_y W[:, block] ------------------------------------------
+// ---- backward, pass 2: per block of 16 input columns: g_x[:, block] (+)= g_y W[:, block] ------------------------------------------
 __global__ __launch_bounds__(kThreads) void head_bwd2_kernel(HeadDims d, const float* __restrict__ W, const float* __restrict__ g_y,
                                                              float* __restrict__ g_x, int accumulate) {
   const int c0 = blockIdx.x * kCols, nc = min(kCols, d.Din - c0);
-  gemm_direct(d.B, nc, d.Dout, g_y, d.Dout, 1, W + c0, 1, d.Din, g_x + c0, d.Din, accumulate != 0);
+  __shared__ float work[kWorkFloats];
+  head_gemm(d.B, nc, d.Dout, g_y, d.Dout, 1, W + c0, 1, d.Din, g_x + c0, d.Din, accumulate != 0, work);
 }
 
 bool dims_ok(int B, int Din, int Dout) { return B >= 1 && B <= kMaxM && Din >= 1 && Dout >= 1 && Din <= 4096 && Dout <= 4096; }

@@ -470,12 +470,12 @@ class FeatureEncoder(nn.Module):
         return layers
 
     _head_act = 0          # activation code of the mu head in csrc/gwtf_heads.hip (WeightsEncoder: 2 = log_softmax)
-    # Widest trunk layer the HIP layer kernels take by default.  Measured on the MI355X, forward + backward inside a hipGraph
-    # (tools/diag/heads_time.py, B = 64): p_prior (128 wide) 104 us against 111 for the library modules, the mixture-weight
-    # encoder (3 x 128) 155 against 190 -- but g_posterior (512 wide) 255 against 148: a product with K = 512 is eight dependent
-    # memory round trips per workgroup here where hipBLASLt splits K over many.  Set to 4096 to run every head on the HIP kernels
-    # (tests do); a split-K mapping (K over the 8 wavefronts of a workgroup + an LDS reduction) is the known fix.
-    hip_max_width = 256
+    # Widest layer the HIP layer kernels take (a knob for A/B timing against the library modules: set it to 0 to get those).
+    # Measured on the MI355X, forward + backward inside a hipGraph (tools/diag/heads_time.py, B = 64), HIP against library:
+    # g_posterior (512 wide) 114 / 148 us, p_prior 80 / 110 (G = 128) and 102 / 116 (G = 512), the mixture-weight encoder
+    # (3 trunk layers) 100 / 189 and 133 / 200.  (The first mapping -- 64 output columns per workgroup, K walked in dependent
+    # passes -- lost at 512: 255 us; csrc/gwtf_gemm.h gemm_splitk_t has the reason and the fix.)
+    hip_max_width = 4096
 
     def _hidden(self, input, bn_updates=1):
         """The shared trunk: Linear -> BatchNorm -> Swish per layer.  In a synchronised data-parallel run (SyncBatchNorm modules,

@@ -462,11 +462,11 @@ int gwtf_prior_backward(const float* g, const float* raw, const float* gs, const
 /* Per-shape MLP heads: FeatureEncoder / WeightsEncoder (lib/networks/encoders.py:31-89) = n_layers x [Linear(no bias) ->
  * BatchNorm1d -> Swish], then Linear(bias) heads (mu, logvar), the mixture-weight head ending in log_softmax (:87-91) -- the
  * modules g_posterior, p_prior and mixture_weights_encoder of the model (models.py:51-59, flow_mixture.py:28-32).  ONE LAYER per
- * call, forward and backward; a workgroup owns 64 output columns and all B <= 128 rows, so BatchNorm's column statistics are local.
+ * call, forward and backward; a workgroup owns 16 output columns and all B <= 128 rows, so BatchNorm's column statistics are local.
  *   x [B][Din], W [Dout][Din], bias / gamma / beta [Dout] (each may be NULL), out [B][Dout]
  *   bn_mode  0: no BatchNorm   1: batch statistics; running_mean / running_var (may be NULL) get the momentum update with the
  *            unbiased batch variance applied `bn_updates` times, *num_batches_tracked += bn_updates   2: running statistics
- *   act      0: none   1: swish   2: log_softmax over the columns (Dout <= 64)
+ *   act      0: none   1: swish   2: log_softmax over the columns (Dout <= 16)
  *   ypre [B][Dout] = x W^T (the backward's input), stats [3][Dout] = mean, biased variance, 1/sqrt(var + bn_eps) used
  * backward: g_out [B][Dout] -> g_y [B][Dout] (scratch: dL/d(x W^T)), g_x [B][Din] (NULL: not wanted; accumulate_g_x != 0: added
  *   to what is there -- two heads on one trunk), g_W [Dout][Din], g_bias / g_gamma / g_beta [Dout] (each may be NULL).

@@ -35,7 +35,7 @@ def rel(a, b):
 def test_heads_match_the_reference_outputs_gradients_and_buffers(tag, training):
     D = golden('g20_heads')
     m = build(tag, D).to(DEV).train(training)
-    m.hip_max_width = 4096                                     # every head on the HIP kernels (the default leaves trunks beyond 256 wide to the library)
+    m.hip_max_width = 4096                                     # (the default) every head on the HIP kernels
     t = 'train' if training else 'eval'
     x = torch.from_numpy(D[f'{tag}_x']).to(DEV).requires_grad_(True)
     assert m._hip_layers(x) is not None                        # this call is served by the HIP kernels, not by library modules
@@ -63,7 +63,7 @@ def test_heads_match_the_reference_outputs_gradients_and_buffers(tag, training):
 
 @pytest.mark.parametrize('B,din,dout,layers', [(2, 37, 5, 2), (128, 130, 70, 1), (17, 512, 128, 1), (64, 64, 64, 3)])
 def test_heads_odd_sizes_against_the_library_modules_in_fp64(B, din, dout, layers):
-    """Row counts 2 .. 128, widths around the 64-column workgroup blocks and the 256-column GEMM chunks, no-BatchNorm trunks, the
+    """Row counts 2 .. 128, widths around the 16-column workgroup blocks and the split-K threshold, no-BatchNorm trunks, the
     closed-form replay of `bn_updates` running-statistic updates: HIP path == the same module evaluated by torch on the CPU in fp64."""
     for batch_norm in (True, False):
         torch.manual_seed(B + din)

@@ -4,12 +4,15 @@ sys.path.insert(0, '.')
 from go_with_the_flows_amd import encoders
 for name, cls, ctor, kw in (('g_posterior', encoders.FeatureEncoder, (1, 512, 128), dict(deterministic=False)),
                             ('p_prior', encoders.FeatureEncoder, (1, 128, 3), dict(deterministic=False)),
+                            ('p_prior512', encoders.FeatureEncoder, (1, 512, 3), dict(deterministic=False)),
+                            ('weights512', encoders.WeightsEncoder, (3, 512, 4), dict(deterministic=True)),
                             ('weights', encoders.WeightsEncoder, (3, 128, 4), dict(deterministic=True))):
     for B in (8, 64):
         res = {}
         for hip in (True, False):
             torch.manual_seed(0)
             m = cls(*ctor, **kw).cuda().train()
+            m.hip_max_width = 4096
             if not hip:
                 m._hip_layers = lambda x: None
                 m._head = lambda seq, h, act=0: (torch.nn.functional.log_softmax(seq(h), dim=1) if act == 2 else seq(h))
