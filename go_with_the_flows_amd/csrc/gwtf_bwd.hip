@@ -23,6 +23,7 @@
 // O(B N f) is written to HBM any more (it was 100-150 MB per coupling).
 #include "gwtf_device.h"
 #include "gwtf_dw1.h"
+#include <algorithm>
 
 namespace {
 
@@ -108,13 +109,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
   const int tiles_per_shape = (N + 64 * NB - 1) / (64 * NB);
-  const int b = blockIdx.x / tiles_per_shape;
-  const int tile = blockIdx.x - b * tiles_per_shape;
-  const int n_wave0 = (tile * 4 + wave) * 16 * NB;
+  // LIGHT: a workgroup walks `tpw` consecutive tiles of ONE shape -- the weights and the shape's FiLM record are staged once, and
+  // the per-shape sums leave the workgroup once (1 / tpw of the global atomics).  Every other variant: one tile (tpw = 1).
+  const int tpw = LIGHT && ks_.tpw > 1 ? ks_.tpw : 1;
+  const int groups = (tiles_per_shape + tpw - 1) / tpw;
+  const int b = blockIdx.x / groups;
+  const int tile0 = (blockIdx.x - b * groups) * tpw;
   const int own_nb = q & (NB - 1);
-  const int n_own = n_wave0 + 16 * own_nb + i16;
-  const bool own_valid = n_own < N && q < NB;
-  const bool own_inrange = n_own < N;
 
   // stage: forward record | FiLM record of this shape | backward record
   {
@@ -141,6 +142,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   const bool keep2 = pat < 3;
   const int nw = keep2 ? 1 : 2;
 
+  for (int it = 0; it < tpw; ++it) {
+  const int tile = tile0 + it;
+  if (tile >= tiles_per_shape) break;
+  const int n_wave0 = (tile * 4 + wave) * 16 * NB;
+  const int n_own = n_wave0 + 16 * own_nb + i16;
+  const bool own_valid = n_own < N && q < NB;
+  const bool own_inrange = n_own < N;
   // own point: input coordinates and upstream gradients (zero beyond N: every derived gradient is then zero)
   float xo[3], go[3], gl[3];
 #pragma unroll
@@ -479,6 +487,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 #pragma unroll
     for (int d = 0; d < 3; ++d) g_in[((size_t)b * 3 + d) * N + n_own] = gin[d];
   }
+  }   // tiles of this workgroup
   __syncthreads();
   // flush the workgroup's partial sums: FiLM-record grads are per shape (few workgroups per address); sd0 / bias
   // grads are global, spread over GWTF_STAT_REPLICAS copies
@@ -579,8 +588,13 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
     if (gwtf_abs_form(f)) {
       const bool small_tile_mg = (ks.tune & GWTF_TUNE_SMALL_LIGHT_TILE) != 0;   // per-call diagnostic (tools/diag/light_tile_check.py)
       if (VAR == BW_LIGHT && nb == 2 && (long)B * N * K >= 256L * 1024 && !small_tile_mg) {
-        const dim3 grid4((unsigned)(B * ((N + 255) / 256)), (unsigned)K);
-        hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+        // 256-point tiles, and as many of a shape's tiles per workgroup as still leave one full round of 512 resident workgroups
+        const int tps = (N + 255) / 256;
+        GwtfKS k4 = ks;
+        k4.tpw = (int)std::max(1L, std::min((long)tps, (long)B * tps * K / 512));
+        if (ks.tune & GWTF_TUNE_SINGLE_TILE) k4.tpw = 1;
+        const dim3 grid4((unsigned)(B * ((tps + k4.tpw - 1) / k4.tpw)), (unsigned)K);
+        hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c);
       } else if (nb == 1) {
         hipLaunchKernelGGL((bwd_kernel<MB, 1, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
       } else {

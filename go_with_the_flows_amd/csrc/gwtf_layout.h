@@ -205,6 +205,7 @@ struct GwtfKS {
   size_t raw, pw, pb, x, pts, mom, ys, bn, gsd0, gbias, gstats, gmom, dw1;
   int Cper, Ctot;
   int tune;      // the call's GWTF_TUNE_* word (include/gwtf.h), carried to every launcher of the pipeline
+  int tpw;       // tiles of one shape a workgroup walks in the light backward pass (set by its launcher; 0 / 1 = one)
 };
 
 // warp pattern of coupling c in direct order (reference flows.py:129-148, decoders.py:49-52):

@@ -33,7 +33,7 @@ for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for fn in glob.glob(f"{out}/{d}/*counter_collection.csv"):
         for r in csv.DictReader(open(fn)):
             k = r["Kernel_Name"]
-            key = next((n for n in ("bwd_kernel<3, 2, 3>", "bwd_kernel<3, 2, 2>", "bwd_kernel<3, 4, 2>", "stats_kernel", "stack_kernel", "bwd_tail1_kernel", "bwd_tail2_kernel", "fold1_bwd_kernel") if n in k), None)
+            key = next((n for n in ("bwd_kernel<3, 2, 3", "bwd_kernel<3, 2, 2", "bwd_kernel<3, 4, 2", "stats_kernel", "stack_kernel", "bwd_tail1_kernel", "bwd_tail2_kernel", "fold1_bwd_kernel") if n in k), None)
             if key is None: continue
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[key] = {m: r[m] for m in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
