@@ -10,7 +10,8 @@ layer-at-a-time HIP pipeline of csrc/gwtf_encoder_train.hip, forward and backwar
 plain library GEMMs and batch-norms on the HIP device (torch.matmul -> rocBLAS, F.batch_norm -> MIOpen, differentiated by
 autograd): eval mode with a gradient required, ``forward`` (the full (B,C,N) feature map) in train mode, width lists
 without kernels, an input that itself requires a gradient.  CPU tensors raise: there is no CPU path.  The per-shape heads
-are (B x in) x (in x out) library GEMMs.
+(FeatureEncoder, WeightsEncoder) run one HIP launch per layer, forward and backward (csrc/gwtf_heads.hip, ``_HeadLayerFn``), up to
+128 rows; beyond that (e.g. the gathered rows of a large data-parallel batch) they are library GEMMs and batch-norms.
 """
 from collections import OrderedDict
 
