@@ -21,6 +21,7 @@
 //   global -> LDS by LDS-DMA (global_load_lds_dwordx4) into a double buffer while the previous coupling
 //   computes; one barrier per coupling.
 #include "gwtf_device.h"
+#include <algorithm>
 
 namespace {
 
@@ -478,6 +479,7 @@ struct Extras {
   const float* logdet_in;        // [B][3][N] or null (component k: + k * out_stride_k)
   float* moments_out;            // [GWTF_STAT_REPLICAS][16], 9 used {Sx0,Sx1,Sx2,Sx0x0,Sx0x1,Sx0x2,Sx1x1,Sx1x2,Sx2x2}, or null
   size_t moments_stride_k;       // component k accumulates into moments_out + k * moments_stride_k
+  int tpw;                       // one-coupling launches: consecutive tiles of ONE shape a workgroup walks (0 / 1 = one tile)
 };
 
 struct Jobs {
@@ -518,14 +520,15 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
   const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
   const int tiles_per_shape = (n_end - n_begin + 64 * NB - 1) / (64 * NB);
+  // One-coupling launches of the train pipeline (ex.tpw > 1): a workgroup walks tpw consecutive tiles of ONE shape, so the
+  // coupling's weights and the shape's FiLM record are staged once per workgroup instead of once per tile -- such a launch is
+  // 45 % prologue (31 us against a 14 us serial-sum floor, docs/LOG.md).  Whole-stack launches: one tile per workgroup.
+  const int tpw = ex.tpw > 1 ? ex.tpw : 1;
+  const int groups = (tiles_per_shape + tpw - 1) / tpw;
   const int local = bid - jobs.tiles_cum[comp];
-  const int b = local / tiles_per_shape;
-  const int tile = local - b * tiles_per_shape;
-  const int n_wave0 = n_begin + (tile * 4 + wave) * 16 * NB;
+  const int b = local / groups;
+  const int tile0 = (local - b * groups) * tpw;
   const int own_nb = q & (NB - 1);
-  const int n_own = n_wave0 + 16 * own_nb + i16;
-  const bool own_valid = n_own < n_end && q < NB;  // q >= NB holds duplicates of quarter q & (NB-1)
-  const bool own_inrange = n_own < n_end;
   p += comp * p_stride_k;
   out += comp * out_stride_k;
   logdet += comp * out_stride_k;
@@ -558,6 +561,17 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
                                        (lds_void*)&lds[buf][LY::FILM + wave * 256], 16, 0, 0);
   };
 
+  const int n_steps = ex.c_count > 0 ? ex.c_count : C;
+  const int c_start = ex.c_count > 0 ? ex.c_first : (MODE == GWTF_MODE_INVERSE ? C - 1 : 0);
+  stage(0, c_start);
+  const float s_keep = sqrtf(eps + 1.0f);  // scale applied to un-warped coordinates (reference quirk)
+  for (int it = 0; it < tpw; ++it) {       // tpw > 1 only with n_steps == 1: nothing is staged inside the loop
+  const int tile = tile0 + it;
+  if (tile >= tiles_per_shape) break;
+  const int n_wave0 = n_begin + (tile * 4 + wave) * 16 * NB;
+  const int n_own = n_wave0 + 16 * own_nb + i16;
+  const bool own_valid = n_own < n_end && q < NB;  // q >= NB holds duplicates of quarter q & (NB-1)
+  const bool own_inrange = n_own < n_end;
   // this lane's own point (one per lane) and the per-quarter copies used to build the MFMA B operand
   float xo[3], ld[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -565,16 +579,12 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     xo[d] = own_inrange ? p[((size_t)b * 3 + d) * N + n_own] : 0.f;
     if (ex.logdet_in && own_inrange) ld[d] = ex.logdet_in[comp * out_stride_k + ((size_t)b * 3 + d) * N + n_own];
   }
-  const int n_steps = ex.c_count > 0 ? ex.c_count : C;
-  const int c_start = ex.c_count > 0 ? ex.c_first : (MODE == GWTF_MODE_INVERSE ? C - 1 : 0);
   float x[NB][3];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int d = 0; d < 3; ++d) x[nb][d] = __shfl(xo[d], 16 * nb + i16);
 
-  stage(0, c_start);
-  const float s_keep = sqrtf(eps + 1.0f);  // scale applied to un-warped coordinates (reference quirk)
   // largest |coordinate| this lane's point had at the input of any coupling: beyond GWTF_X_LIMIT the f16 image of sd0's
   // activations can overflow (gwtf_layout.h, range scaling) and the ReLU's v_max would turn the resulting NaN accumulators
   // into zeros -- such a point is flagged instead (NaN result below).  v_max ignores NaN operands: a NaN coordinate is
@@ -685,6 +695,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
       atomicAdd(&ex.moments_out[comp * ex.moments_stride_k + (blockIdx.x % GWTF_STAT_REPLICAS) * 16 + threadIdx.x],
                 s_mom[0][threadIdx.x] + s_mom[1][threadIdx.x] + s_mom[2][threadIdx.x] + s_mom[3][threadIdx.x]);
   }
+  }   // tiles of this workgroup (s_mom is rewritten only behind the next tile's barriers)
 }
 
 template <int MB, int NB>
@@ -698,7 +709,8 @@ int launch(const float* p, const float* pw, const float* film, float* out, float
     jobs.begin[k] = segs ? segs[2 * k] : 0;
     jobs.end[k] = segs ? segs[2 * k + 1] : N;
     const int cnt = jobs.end[k] - jobs.begin[k];
-    jobs.tiles_cum[k + 1] = jobs.tiles_cum[k] + B * ((cnt + 64 * NB - 1) / (64 * NB));
+    const int tpw = ex.tpw > 1 ? ex.tpw : 1;
+    jobs.tiles_cum[k + 1] = jobs.tiles_cum[k] + B * (((cnt + 64 * NB - 1) / (64 * NB) + tpw - 1) / tpw);
   }
   if (jobs.tiles_cum[K] == 0) return 0;
   const dim3 grid((unsigned)jobs.tiles_cum[K]), block(256);
@@ -813,14 +825,14 @@ extern "C" int gwtf_stack_plan(const int* segments, int K, int B, int N, int f, 
 
 static int stack_dispatch(const float* p, const float* packed_w, const float* film, float* out, float* logdet, float* ps,
                           float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,
-                          int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, const Extras& ex,
+                          int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, const Extras& ex_in,
                           int tune, void* stream) {
   if (B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || K <= 0 || K > GWTF_MAX_COMPONENTS || !p ||
       !packed_w || !film || !out || !logdet)
     return GWTF_E_BADARG;
   if (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) return GWTF_E_BADARG;
   if (pattern0 < 0 || pattern0 > 5) return GWTF_E_BADARG;
-  if (ex.c_count < 0 || (ex.c_count > 0 && (ex.c_first < 0 || ex.c_first >= C))) return GWTF_E_BADARG;
+  if (ex_in.c_count < 0 || (ex_in.c_count > 0 && (ex_in.c_first < 0 || ex_in.c_first >= C))) return GWTF_E_BADARG;
   const bool any = ps || mus || logvars, all = ps && mus && logvars, ps_only = ps && !mus && !logvars;
   if (any && !all && !ps_only) return GWTF_E_BADARG;     // the three lists, none, or the coordinates alone (train pipeline)
   long pts = 0;
@@ -835,11 +847,21 @@ static int stack_dispatch(const float* p, const float* packed_w, const float* fi
   // of the 1024 SIMDs two waves.
   int nb;
   const int forced = (tune & 0xffff) / 16;
-  if (ex.c_count == 0 || forced == 1 || forced == 2 || forced == 4) {
+  if (ex_in.c_count == 0 || forced == 1 || forced == 2 || forced == 4) {
     nb = choose_nb(segments, K, B, N, f, tune);
   } else {
     nb = pts >= 2048L * 64 ? 4 : (pts >= 2048L * 32 ? 2 : 1);
     if (f > 64 && nb > 2) nb = 2;
+  }
+  Extras ex = ex_in;
+  ex.tpw = 1;
+  if (ex.c_count == 1 && !segments && !(tune & GWTF_TUNE_SINGLE_TILE)) {
+    // one-coupling launch on a grid of several rounds: as many tiles of a shape per workgroup as still leave every resident slot
+    // a workgroup (the staging of the coupling is then paid once per slot, not once per tile)
+    const int MBi = gwtf_padded_width(f) / 16;
+    const TileCost tc = tile_cost(MBi, nb == 4 ? 2 : nb - 1);
+    const long tps = (N + 64 * nb - 1) / (64 * nb), total = (long)K * B * tps;
+    ex.tpw = (int)std::max(1L, std::min(tps, total / (256L * tc.slots)));
   }
   const bool pipe = !(tune & GWTF_TUNE_GENERIC_BODY);
   const int kk_steps = (f + 3) / 4;
