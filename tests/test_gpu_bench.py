@@ -27,6 +27,11 @@ def test_single_gpu_line_has_roofline_and_m1():
     r = line['roofline']
     assert r['bound'] == 'mfma' and 0 < r['frac'] < 1 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
     assert line['also']['m1']['value'] > 0 and 0 < line['also']['m1']['roofline']['frac'] < 1
+    # roofline.traffic of the headline kernel is measured by the run itself (two rocprofv3 --pmc child passes): HBM-side bytes per
+    # launch between the algorithmic 18.9 MB (36 B x 524 288 point passes) and a few times that
+    assert 'measured by this run' in r['traffic_source'], r['traffic_source']
+    assert 18.0e6 < r['traffic'] < 80.0e6, r['traffic']
+    assert 'static' in line['also']['m1']['roofline']['traffic_source']          # secondary shapes: the committed profile set
     ts = line['also']['train_step']                      # the whole training step, timed in a child process
     assert 'error' not in ts and 5 < ts['ms_per_step'] < 60, ts
     # ... and the data-parallel code path on a 1-rank RCCL group: every collective inside the graph, at most 15 % slower

@@ -2,7 +2,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for w in ${@:-m1 airplane}; do
   rm -rf gpurun_out/ks_$w
-  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$w -o $w -- python3 bench.py --workload $w --no-cpu-baseline --steps 50 > gpurun_out/ks_$w.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$w -o $w -- python3 bench.py --workload $w --no-cpu-baseline --no-live-traffic --steps 50 > gpurun_out/ks_$w.log 2>&1
   python3 - <<PY
 import csv, json
 for r in csv.DictReader(open("gpurun_out/ks_$w/${w}_kernel_stats.csv")):
