@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: point-flow forward + log-det throughput on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload airplane|m1|ae|k16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload airplane|m1|ae|svr|k16|k16_b1]
 
 One "step" = one pass of the hot path over one batch of synthetic clouds that are already resident in
 HBM: for every mixture component, the FiLM kernel + the fused coupling-stack kernel (inverse direction,
@@ -14,8 +14,10 @@ torch.distributed.run ... bench.py --gpus N` or, when no launcher environment is
 (`python bench.py --gpus N` spawns the N ranks before touching the GPU, like the reference's mp.spawn in train_ae.py:183-193).
 
 Prints ONE JSON line on rank 0: the BASELINE metric on configs[1] (`value`), `roofline` of the dominant kernel against
-the unit that executes it, `also.m1` = the metric's own B=32 x 2048 shape timed by the same protocol in the same run,
-and `cpu_baseline`.
+the unit that executes it (kernel duration from HIP events around the launch; `traffic` = HBM-side bytes per launch measured by two
+`rocprofv3 --pmc` child passes of this script, N = 1 only), `also` = the other BASELINE shapes (m1, ae, svr, k16, k16_b1) timed by
+the same protocol in the same run plus the whole training step (`train_step`: children of this process, one per rank), and
+`cpu_baseline`.
 """
 import argparse
 import json
