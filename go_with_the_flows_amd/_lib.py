@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgwtf_hip.so')
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 MODE_DIRECT, MODE_INVERSE = 0, 1
 STAT_REPLICAS = 64   # GWTF_STAT_REPLICAS in csrc/gwtf_layout.h
@@ -96,8 +96,6 @@ _SIGNATURES = {
     'gwtf_bn_running_update': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_gather_table': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_mtrain_dw1_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
-    'gwtf_stat_compact': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_stat_expand': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_mtrain_phase': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'gwtf_mtrain_forward': (ctypes.c_int, [ctypes.c_void_p]),
     'gwtf_mtrain_backward': (ctypes.c_int, [ctypes.c_void_p]),
@@ -118,7 +116,7 @@ class TrainCtx(ctypes.Structure):
     _fields_ = ([(n, ctypes.c_int) for n in ('K', 'B', 'N', 'C', 'f', 'G', 'pattern0', 'mode', 'tune')] +
                 [('eps', ctypes.c_float), ('n_total', ctypes.c_double)] +
                 [(n, ctypes.c_void_p) for n in (
-                    'p', 'raw', 'packed_w', 'packed_b', 'film_raw', 'film_rec', 'moments', 'ystats', 'bn_batch', 'xbuf',
+                    'p', 'raw', 'packed_w', 'packed_b', 'film_raw', 'film_rec', 'moments', 'ystats', 'mom_c', 'ys_c', 'bn_batch', 'xbuf',
                     'logdet', 'ps', 'mus', 'logvars', 'g_out', 'g_ld', 'g_ps', 'g_lvs', 'g_bufs', 'g_xa', 'g_xb', 'dw1_ws', 'g_film', 'g_sd0',
                     'g_bias', 'g_stats', 'g_mom', 'g_film_raw', 'g_raw', 'stream')])
 EXPORTS = tuple(_SIGNATURES)

@@ -518,25 +518,13 @@ COLLECTIVES = {'n': 0}        # statistic all-reduces issued by TrainMixtureFn (
 GRAD_SINK = {'reducer': None}  # set by dist.OverlappedGradients: receives the decoders' flat gradient as soon as it exists
 
 
-def _stat_sum(t, replicated_k=0):
-    """Sum a statistic slab over the ranks, in place.  replicated_k = K > 0: `t` is a forward slab [K][64 copies][n] accumulated by
-    atomics spread over 64 copies (csrc/gwtf_layout.h GWTF_STAT_REPLICAS): the copies are summed into a contiguous [K][n] exchange
-    buffer first and the result written back as copy 0 (gwtf_stat_compact / gwtf_stat_expand) -- 3 KB instead of 196 KB per
-    collective at f = 37, K = 4.  Costs two small launches per collective (measured on the 1-rank RCCL path: 12.9 -> 14.1 ms per
-    airplane step for the 67 forward collectives), which only a real wire pays back: done when the group has more than one rank,
-    or when GWTF_COMPACT_STAT_COLLECTIVES=1 asks for it (tests run the 1-rank path both ways)."""
-    import os
+def _stat_sum(t):
+    """Sum a COMPACT statistic record over the ranks, in place.  In a data-parallel run every forward phase of the pipeline ends
+    with one small launch that adds up the 64 copies its atomics were spread over into a contiguous [K][n] record (csrc/gwtf_train.hip
+    stat_compact_kernel): that record goes on the wire (3 KB at f = 37, K = 4, where the copies are 196 KB) and every consumer --
+    the folds, the backward pass -- reads it in place of the copies: no write-back, no second launch."""
     import torch.distributed as dist
     COLLECTIVES['n'] += 1
-    if replicated_k and (dist.get_world_size() > 1 or os.environ.get('GWTF_COMPACT_STAT_COLLECTIVES') == '1'):
-        L = _lib.lib()
-        n = t.numel() // (replicated_k * _lib.STAT_REPLICAS)
-        xchg = torch.empty(replicated_k, n, device=t.device, dtype=torch.float32)
-        st = _lib._stream(t)
-        _lib.check(L.gwtf_stat_compact(t.data_ptr(), xchg.data_ptr(), replicated_k, n, st))
-        dist.all_reduce(xchg, op=dist.ReduceOp.SUM)
-        _lib.check(L.gwtf_stat_expand(t.data_ptr(), xchg.data_ptr(), replicated_k, n, st))
-        return
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
@@ -567,13 +555,15 @@ class TrainMixtureFn(torch.autograd.Function):
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
         t.eps, t.n_total, t.tune = float(eps), float(n_total), _lib.tune_word()
         bufs = dict(moments=zeros(C + 1, K, R * 16), ystats=zeros(C, K, R * 2 * FP * 2), bn_batch=zeros(K, C, 2, 4, 2, f),
+                    # data parallel: the compact statistic records that are all-reduced and that every consumer then reads
+                    mom_c=new(C + 1, K, 16) if sharded else None, ys_c=new(C, K, 2 * FP * 2) if sharded else None,
                     film_rec=new(B, K * C, FS), xbuf=new(2, K, B, 3, N), logdet=new(K, B, 3, N),
                     # the per-coupling inputs (ps) are what the backward recomputes from; mus / logvars only when the caller
                     # wants the reference's lists (36 B per point, coupling and component less to write otherwise)
                     lists=new(3 if want_lists else 1, K, C, B, 3, N))
         t.p, t.raw, t.packed_w, t.packed_b, t.film_raw = p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr(), film_raw.data_ptr()
-        for name in ('moments', 'ystats', 'bn_batch', 'film_rec', 'xbuf', 'logdet'):
-            setattr(t, name, bufs[name].data_ptr())
+        for name in ('moments', 'ystats', 'mom_c', 'ys_c', 'bn_batch', 'film_rec', 'xbuf', 'logdet'):
+            setattr(t, name, bufs[name].data_ptr() if bufs[name] is not None else None)
         lists = bufs['lists']
         t.ps = lists[0].data_ptr()
         t.mus, t.logvars = (lists[1].data_ptr(), lists[2].data_ptr()) if want_lists else (None, None)
@@ -582,18 +572,20 @@ class TrainMixtureFn(torch.autograd.Function):
             if not sharded:
                 _lib.check(L.gwtf_mtrain_forward(ctypes.addressof(t)))
             else:
-                mom, ys = bufs['moments'], bufs['ystats']
+                mom, ys = bufs['mom_c'], bufs['ys_c']
                 _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_INIT, 0))
-                _stat_sum(mom[0, 0], 1)                        # the shared input clouds' moments: one record
+                _stat_sum(mom[0, 0])                           # the shared input clouds' moments: one record
                 for step in range(C):
                     c = step if mode == 'direct' else C - 1 - step
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_A, step))
-                    _stat_sum(ys[c], K)
+                    _stat_sum(ys[c])
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_B, step))
                     if step + 1 < C:
-                        _stat_sum(mom[step + 1], K)
+                        _stat_sum(mom[step + 1])
         out = bufs['xbuf'][L.gwtf_mtrain_final_forward_half(C)].clone()
-        ctx.save_for_backward(p, raw, lists[0], pw, pb, bufs['film_rec'], film_raw, bufs['moments'], bufs['ystats'])
+        # the backward reads the forward statistics again: the compact (all-reduced) records when data parallel, the copies otherwise
+        ctx.save_for_backward(p, raw, lists[0], pw, pb, bufs['film_rec'], film_raw,
+                              bufs['mom_c' if sharded else 'moments'], bufs['ys_c' if sharded else 'ystats'])
         ctx.meta = (int(K), int(C), int(f), int(G), int(FP), int(pattern0), float(eps), mode, float(n_total), bool(sharded))
         ctx.mark_non_differentiable(bufs['bn_batch'])
         ctx.set_materialize_grads(False)
@@ -623,13 +615,17 @@ class TrainMixtureFn(torch.autograd.Function):
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
         t.eps, t.n_total, t.tune = eps, n_total, _lib.tune_word()
         scratch = new(K, B, 3, N)
-        bufs = dict(g_bufs=new(2, K, B, 3, N), g_xa=new(K, B, 3, N),
+        bufs = dict(g_bufs=new(2, K, B, 3, N),
                     dw1_ws=new(K * L.gwtf_mtrain_dw1_floats(f, B, N)), g_film=zeros(B, K * C, 2, 3, FP),
                     g_sd0=zeros(C, K, R * 2 * 3 * FP), g_bias=zeros(C, K, R * 4), g_stats=new(C, K, 2 * 2 * FP),
-                    g_mom=torch.zeros(C, K, 48, device=dev, dtype=torch.float64), g_film_raw=torch.zeros_like(film_raw),
+                    g_mom=zeros(C, K, 16), g_film_raw=torch.zeros_like(film_raw),
                     g_raw=torch.zeros_like(raw))
         t.p, t.raw, t.packed_w, t.packed_b = p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr()
-        t.film_raw, t.film_rec, t.moments, t.ystats = film_raw.data_ptr(), film_rec.data_ptr(), mom.data_ptr(), ystats.data_ptr()
+        t.film_raw, t.film_rec = film_raw.data_ptr(), film_rec.data_ptr()
+        if sharded:
+            t.mom_c, t.ys_c = mom.data_ptr(), ystats.data_ptr()
+        else:
+            t.moments, t.ystats = mom.data_ptr(), ystats.data_ptr()
         t.bn_batch, t.xbuf, t.logdet = bufs['g_stats'].data_ptr(), bufs['g_bufs'].data_ptr(), scratch.data_ptr()   # forward-only fields
         t.ps, t.mus, t.logvars = ps_saved.data_ptr(), ps_saved.data_ptr(), ps_saved.data_ptr()
         t.g_out, t.g_ld = g_out.data_ptr(), g_ld.data_ptr()
@@ -639,7 +635,6 @@ class TrainMixtureFn(torch.autograd.Function):
         t.g_lvs = g_lvs.data_ptr() if g_lvs is not None else None
         for name, buf in bufs.items():
             setattr(t, name, buf.data_ptr())
-        t.g_xb = t.g_xa                    # not written since the merged backward pass (one gradient buffer per level)
         t.stream = _lib._stream(p)
         with torch.cuda.device(dev):
             if not sharded:

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
                                                   float* __restrict__ g_sd0, float* __restrict__ g_bias,
                                                   const float* __restrict__ g_stats, int B, int N, int C, int c, int pat,
                                                   float eps, int kk_steps, int f, int mode, const GwtfKS ks_,
-                                                  const float* __restrict__ g_ps_c, const float* __restrict__ g_lvs_c) {
+                                                  const float* __restrict__ g_ps_c, const float* __restrict__ g_lvs_c,
+                                                  const GwtfCombine cmb) {
   using K = Cfg<MB>;
   using KB = BCfg<MB>;
   constexpr int FP = K::FP;
@@ -108,6 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
+  const bool combine = (LIGHT || MERGED) && cmb.gm != nullptr;   // on-the-fly gradient combine of the level processed before this one
   const int tiles_per_shape = (N + 64 * NB - 1) / (64 * NB);
   // LIGHT: a workgroup walks `tpw` consecutive tiles of ONE shape -- the weights and the shape's FiLM record are staged once, and
   // the per-shape sums leave the workgroup once (1 / tpw of the global atomics).  Every other variant: one tile (tpw = 1).
@@ -209,38 +211,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   // ---- tail forward + backward on the own point ------------------------------------------------------------
   float dt[2][2] = {{0.f, 0.f}, {0.f, 0.f}};   // [branch][warped slot] = dL/d o
   float xw[2] = {0.f, 0.f}, gow[2] = {0.f, 0.f}, glw[2] = {0.f, 0.f}, gx[2] = {0.f, 0.f};
+  const float keep_scale = mode == GWTF_MODE_INVERSE ? 1.0f / s_keep : s_keep;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    if (d == w0) { xw[0] = xo[d]; gow[0] = go[d]; glw[0] = gl[d]; }
-    if (!keep2 && d == w1) { xw[1] = xo[d]; gow[1] = go[d]; glw[1] = gl[d]; }
+    if (d == w0) { xw[0] = xo[d]; glw[0] = gl[d]; }
+    if (!keep2 && d == w1) { xw[1] = xo[d]; glw[1] = gl[d]; }
   }
+  // forward quantities of the tail (hardware rcp / sqrt / exp2 like the forward kernel, gwtf_stack.hip)
+  float t_rden[2] = {0.f, 0.f}, t_e[2] = {0.f, 0.f}, t_sc[2] = {1.f, 1.f}, t_rsc[2] = {1.f, 1.f}, t_out[2] = {0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     if (!STATS && s < nw) {
       const float t = res[0][s] + bias[s];
       const float den = 1.0f + fabsf(t);
-      const float rden = __builtin_amdgcn_rcpf(den);   // hardware rcp / sqrt / exp2 like the forward tail (gwtf_stack.hip)
-      const float lv = t * rden;
+      t_rden[s] = __builtin_amdgcn_rcpf(den);
+      const float lv = t * t_rden[s];
       const float mu = res[1][s] + bias[2 + s];
-      const float e = __expf(lv);
-      const float sc = __builtin_amdgcn_sqrtf(eps + e);
-      const float rsc = __builtin_amdgcn_rcpf(sc);
+      t_e[s] = __expf(lv);
+      t_sc[s] = __builtin_amdgcn_sqrtf(eps + t_e[s]);
+      t_rsc[s] = __builtin_amdgcn_rcpf(t_sc[s]);
+      t_out[s] = mode == GWTF_MODE_INVERSE ? (xw[s] - mu) * t_rsc[s] : fmaf(t_sc[s], xw[s], mu);   // this coupling's output
+    }
+  }
+  if ((LIGHT || MERGED) && combine) {
+    // g_out += gM + Q x_out of the level processed before (x_out = this coupling's output = that level's input)
+    float xout[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) xout[d] = d == w0 ? t_out[0] : ((!keep2 && d == w1) ? t_out[1] : xo[d] * keep_scale);
+    const float* gmv = cmb.gm + (size_t)blockIdx.y * cmb.gm_sk;    // wave-uniform address: scalar loads, no long-lived registers
+    const float q00 = 2.f * gmv[3], q01 = gmv[4], q02 = gmv[5], q11 = 2.f * gmv[6], q12 = gmv[7], q22 = 2.f * gmv[8];
+    if (own_inrange) {
+      go[0] += gmv[0] + q00 * xout[0] + q01 * xout[1] + q02 * xout[2];
+      go[1] += gmv[1] + q01 * xout[0] + q11 * xout[1] + q12 * xout[2];
+      go[2] += gmv[2] + q02 * xout[0] + q12 * xout[1] + q22 * xout[2];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    if (d == w0) gow[0] = go[d];
+    if (!keep2 && d == w1) gow[1] = go[d];
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    if (!STATS && s < nw) {
       float dsc;
       if (mode == GWTF_MODE_INVERSE) {       // out = (x - mu)/s
-        const float outw = (xw[s] - mu) * rsc;
-        gx[s] = gow[s] * rsc;
-        dsc = -gow[s] * outw * rsc;
+        gx[s] = gow[s] * t_rsc[s];
+        dsc = -gow[s] * t_out[s] * t_rsc[s];
         dt[1][s] = -gx[s];
       } else {                                // out = s*x + mu
-        gx[s] = gow[s] * sc;
+        gx[s] = gow[s] * t_sc[s];
         dsc = gow[s] * xw[s];
         dt[1][s] = gow[s];
       }
-      const float dlv = glw[s] + dsc * e * (0.5f * rsc);
-      dt[0][s] = dlv * (rden * rden);
+      const float dlv = glw[s] + dsc * t_e[s] * (0.5f * t_rsc[s]);
+      dt[0][s] = dlv * (t_rden[s] * t_rden[s]);
     }
   }
-  const float keep_scale = mode == GWTF_MODE_INVERSE ? 1.0f / s_keep : s_keep;
   float gin[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) gin[d] = STATS ? 0.f : (d == w0 ? gx[0] : ((!keep2 && d == w1) ? gx[1] : go[d] * keep_scale));
@@ -580,7 +607,7 @@ template <int MB, int VAR>
 int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld, const float* pw_c, const float* pb_c,
                const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0, float* g_bias,
                const float* g_stats, int B, int N, int C, int c, int pat, float eps, int kk_steps, int f, int mode, int K,
-               const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, hipStream_t st) {
+               const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, const GwtfCombine& cmb, hipStream_t st) {
   const int pts_wg = 64 * nb;
   const dim3 grid((unsigned)(B * ((N + pts_wg - 1) / pts_wg)), (unsigned)K), block(256);
   if constexpr (MB == 3 && (VAR == BW_LIGHT || VAR == BW_MERGED)) {
@@ -594,11 +621,11 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
         k4.tpw = (int)std::max(1L, std::min((long)tps, (long)B * tps * K / 512));
         if (ks.tune & GWTF_TUNE_SINGLE_TILE) k4.tpw = 1;
         const dim3 grid4((unsigned)(B * ((tps + k4.tpw - 1) / k4.tpw)), (unsigned)K);
-        hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c);
+        hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c, cmb);
       } else if (nb == 1) {
-        hipLaunchKernelGGL((bwd_kernel<MB, 1, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+        hipLaunchKernelGGL((bwd_kernel<MB, 1, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
       } else {
-        hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+        hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
       }
       return (int)hipGetLastError();
     }
@@ -607,11 +634,11 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
     const bool small_tile = (ks.tune & GWTF_TUNE_SMALL_LIGHT_TILE) != 0;      // per-call diagnostic (tools/diag/light_tile_check.py)
     if (nb == 2 && (long)B * N * K >= 256L * 1024 && !small_tile) {
       const dim3 grid4((unsigned)(B * ((N + 255) / 256)), (unsigned)K);
-      hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c);
+      hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
       return (int)hipGetLastError();
     }
   }
-#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, VAR>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c)
+#define GWTF_B(NB_) hipLaunchKernelGGL((bwd_kernel<MB, NB_, VAR>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb)
   if (nb == 1) GWTF_B(1); else GWTF_B(2);
 #undef GWTF_B
   return (int)hipGetLastError();
@@ -647,11 +674,11 @@ static int bwd_grid(int B, int N) {
 static int bwd_dispatch(int var, const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                         const float* packed_b_c, const float* film, float* g_in, float* dw1_ws, float* g_film, float* g_sd0,
                         float* g_bias, const float* g_stats, int c, int B, int N, int C, int f, int pat, float eps, int mode,
-                        int K, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
+                        int K, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, const GwtfCombine& cmb, void* stream) {
   const int kk_steps = (f + 3) / 4;
   const int nb = bwd_points_per_wg(B, N) / 64;
   hipStream_t st = (hipStream_t)stream;
-#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, K, ks, g_ps_c, g_lvs_c, st
+#define GWTF_A x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, K, ks, g_ps_c, g_lvs_c, cmb, st
 #define GWTF_V(MB_)                                                                                     \
   switch (var) {                                                                                        \
     case BW_DIRECT: return launch_bwd<MB_, BW_DIRECT>(nb, GWTF_A);                                      \
@@ -692,7 +719,7 @@ extern "C" int gwtf_coupling_backward_lists(const float* x_in, const float* g_ou
   GwtfKS ks = {};
   ks.Cper = ks.Ctot = C;
   return bwd_dispatch(BW_DIRECT, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
-                      B, N, C, f, (pattern0 + c) % 6, eps, mode, 1, ks, g_ps_c, g_lvs_c, stream);
+                      B, N, C, f, (pattern0 + c) % 6, eps, mode, 1, ks, g_ps_c, g_lvs_c, GwtfCombine{}, stream);
 }
 
 // K-batched variants (train pipeline, gwtf_train.hip): component k adds k * stride (GwtfKS) to every base pointer
@@ -701,31 +728,33 @@ int gwtf_internal_coupling_backward_k(const float* x_in, const float* g_out, con
                                       float* g_sd0, float* g_bias, int c, int K, int B, int N, int f, int pattern0, float eps,
                                       int mode, const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
   return bwd_dispatch(BW_DIRECT, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, nullptr, c,
-                      B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c, g_lvs_c, stream);
+                      B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c, g_lvs_c, GwtfCombine{}, stream);
 }
 // The train pipeline's two passes (BW_LIGHT / BW_MERGED above).  light: only g_film and g_bias are written; merged: g_in, the dW1
 // partials and g_sd0, with the statistics path's upstream g_stats [K][2][2][FP] added to dacc.
 int gwtf_internal_light_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                    const float* film, float* g_film, float* g_bias, int c, int K, int B, int N, int f,
                                    int pattern0, float eps, int mode, const GwtfKS& ks, const float* g_ps_c,
-                                   const float* g_lvs_c, void* stream) {
+                                   const float* g_lvs_c, const GwtfCombine& cmb, void* stream) {
   return bwd_dispatch(BW_LIGHT, x_in, g_out, g_ld, packed_w_c, packed_w_c /*unused*/, film, g_film /*unused*/, g_film /*unused*/,
                       g_film, g_film /*unused*/, g_bias, nullptr, c, B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c,
-                      g_lvs_c, stream);
+                      g_lvs_c, cmb, stream);
 }
 int gwtf_internal_merged_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                     const float* packed_b_c, const float* film, const float* g_stats, float* g_in, float* dw1_ws,
                                     float* g_sd0, int c, int K, int B, int N, int f, int pattern0, float eps, int mode,
-                                    const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream) {
+                                    const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, const GwtfCombine& cmb,
+                                    void* stream) {
   return bwd_dispatch(BW_MERGED, x_in, g_out, g_ld, packed_w_c, packed_b_c, film, g_in, dw1_ws, g_sd0 /*unused*/, g_sd0,
-                      g_sd0 /*unused*/, g_stats, c, B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c, g_lvs_c, stream);
+                      g_sd0 /*unused*/, g_stats, c, B, N, ks.Ctot, f, (pattern0 + c) % 6, eps, mode, K, ks, g_ps_c, g_lvs_c, cmb,
+                      stream);
 }
 int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, const float* packed_w_c, const float* packed_b_c,
                                    float* g_in, float* dw1_ws, float* g_sd0, int K, int B, int N, int f, int pattern,
                                    const GwtfKS& ks, void* stream) {
   return bwd_dispatch(BW_STATS, x_in, nullptr, nullptr, packed_w_c, packed_b_c, packed_w_c /*unused*/, g_in, dw1_ws,
                       g_sd0 /*unused*/, g_sd0, g_sd0 /*unused*/, g_stats, 0, B, N, 1, f, pattern, 0.f, GWTF_MODE_INVERSE, K, ks,
-                      nullptr, nullptr, stream);
+                      nullptr, nullptr, GwtfCombine{}, stream);
 }
 
 extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, const float* packed_w_c,

@@ -145,6 +145,47 @@ __device__ __forceinline__ float wave_max(float v) {
   return fmaxf(u, w);
 }
 
+// ---- moment path of the train-mode backward ---------------------------------------------------------------------------------------
+// sd0_bn's batch statistics are analytic in the 9 first / second moments of a level's input coordinates (fold0), so the level's
+// input gradient carries  gM_a + sum_b Q_ab x_b  per point, Q_aa = 2 gM_aa, Q_ab = gM_ab: the nine moment gradients gM come from the
+// five sums {gE0, gE1, gC00, gC01, gC11} of the sd0 fold's backward (r5) and the kept coordinates' moments.
+__device__ __forceinline__ int mom2_index(int a, int b) {  // index of S x_a x_b inside the 9-vector, a <= b
+  return a == 0 ? 3 + b : (a == 1 ? 5 + b : 8);
+}
+struct KeptMoments { double e0, e1, c00, c01, c11; };
+__device__ inline KeptMoments kept_moments(const float (&mom)[9], int k0, int k1, double n_total) {
+  auto M = [&](int i) { float v = 0.f;
+#pragma unroll
+    for (int u = 0; u < 9; ++u) v = u == i ? mom[u] : v;
+    return v; };
+  KeptMoments r;
+  r.e0 = M(k0) / n_total;
+  r.e1 = k1 >= 0 ? M(k1) / n_total : 0.0;
+  r.c00 = M(mom2_index(k0, k0)) / n_total - r.e0 * r.e0;
+  r.c11 = k1 >= 0 ? M(mom2_index(k1, k1)) / n_total - r.e1 * r.e1 : 0.0;
+  r.c01 = k1 >= 0 ? M(mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)) / n_total - r.e0 * r.e1 : 0.0;
+  return r;
+}
+// One fold block's share of the nine moment gradients gm[0..8] (the rest of gm[16] zero), LINEAR in its five sums r5: the blocks
+// (and, data parallel, the ranks) add their shares up -- float atomics / an all-reduce of 16 floats -- and every consumer reads gM.
+__device__ inline void moment_grad_terms(const KeptMoments& km, const double (&r5)[5], int pat, double n_total, float* gm) {
+  int k0, k1, w0d, w1d;
+  gwtf_pattern_dims(pat, &k0, &k1, &w0d, &w1d);
+  const double gC00 = r5[2], gC01 = r5[3], gC11 = r5[4];
+  const double gE0 = r5[0] - 2.0 * km.e0 * gC00 - km.e1 * gC01;
+  const double gE1 = r5[1] - 2.0 * km.e1 * gC11 - km.e0 * gC01;
+  const double inv_n = 1.0 / n_total;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gm[i] = 0.f;
+  gm[k0] = (float)(gE0 * inv_n);
+  gm[mom2_index(k0, k0)] = (float)(gC00 * inv_n);
+  if (k1 >= 0) {
+    gm[k1] = (float)(gE1 * inv_n);
+    gm[mom2_index(k1, k1)] = (float)(gC11 * inv_n);
+    gm[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] = (float)(gC01 * inv_n);
+  }
+}
+
 // sd0 (+ folded sd0_bn) + ReLU + f16 split in the lane that owns each MFMA k-slot, then the f x f contraction
 // acc[m][nb] = cinit[m] + W1'[16m.., :] . h0[:, points of block nb] on v_mfma_f32_16x16x32_f16 (3 products).
 // MG: 1 = the caller knows at compile time that the last k-step is the merged abs-form one (f = 33..40: the whole contraction is

@@ -208,6 +208,17 @@ struct GwtfKS {
   int tpw;       // tiles of one shape a workgroup walks in the light backward pass (set by its launcher; 0 / 1 = one)
 };
 
+// The gradient combine of the backward level processed BEFORE this one, applied on the fly by this level's passes (train pipeline).
+// A level's input gradient is  g_in = g_a + d(moments)/dx = g_a + gM + Q x  (Q_aa = 2 gM_aa, Q_ab = gM_ab) with x that level's INPUT
+// = this level's OUTPUT, which the backward kernels recompute anyway: they read the previous level's raw g_a and add the moment path
+// themselves instead of a separate pass over the points per level (3 x 12 B per point read + written, one launch on the chain).
+// gm: the nine moment gradients of that level [K][16] (written by its sd0 fold's backward; all-reduced when data parallel);
+// null: nothing to add (first backward level, eval mode).
+struct GwtfCombine {
+  const float* gm;
+  size_t gm_sk;         // component stride (floats)
+};
+
 // warp pattern of coupling c in direct order (reference flows.py:129-148, decoders.py:49-52):
 // index (pattern0 + c) % 6 -> 0:[0] 1:[1] 2:[2] 3:[0,1] 4:[0,2] 5:[1,2]
 GWTF_HD int gwtf_pattern_kept(int pat) { return pat < 3 ? 2 : 1; }

@@ -13,8 +13,11 @@
 // Everything here is O(f) or O(B*f) work: latency, not throughput.
 #include <hip/hip_runtime.h>
 #include "gwtf_layout.h"
+#include "gwtf_device.h"
 #include "gwtf_dw1.h"
 #include "../../include/gwtf.h"
+
+using namespace gwtf_dev;   // arrival ticket, moment-gradient helpers
 
 namespace {
 
@@ -40,11 +43,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const float* __restrict__ 
   }
 }
 
-__device__ __forceinline__ int mom2_index(int a, int b) {  // index of S x_a x_b inside the 9-vector, a <= b
-  return a == 0 ? 3 + b : (a == 1 ? 5 + b : 8);
-}
-
 // One workgroup, thread = (branch, feature).  bn_batch[branch][kind 0][2][f] <- {mean, unbiased var}.
+template <int NR /* copies of the moment record to add: 1 = the compact record */>
 __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
                              float* __restrict__ pw_c, float* __restrict__ pb_c, float* __restrict__ bn_batch, int f, int G,
                              int FP, const GwtfKS ks) {
@@ -57,7 +57,8 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
   __shared__ float mom[9];
   if (t < 9) {
     float sacc = 0.f;
-    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) sacc += mom_rep[r * 16 + t];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) sacc += mom_rep[r * 16 + t];
     mom[t] = sacc;
   }
   __syncthreads();
@@ -135,6 +136,7 @@ __global__ void fold0_kernel(const float* __restrict__ raw_c, const float* __res
 }
 
 // grid = B workgroups, thread = (branch, feature).  Workgroup 0 also emits the running-stat update of sd1_bn.
+template <int NR /* copies of ystats to add: 1 = the compact record */>
 __global__ void fold1_kernel(const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total,
                              const float* __restrict__ film_raw, float* __restrict__ film_rec,
                              float* __restrict__ bn_batch, int c, int C, int f, int G, int FP, const GwtfKS ks) {
@@ -155,7 +157,8 @@ __global__ void fold1_kernel(const float* __restrict__ raw_c, const float* __res
   }
   const float* rb = raw_c + (size_t)br * R.branch_size();
   float ys = 0.f, yq = 0.f;
-  for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
     ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
     yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
   }
@@ -202,11 +205,12 @@ int gwtf_internal_stats_backward_k(const float* x_in, const float* g_stats, cons
 int gwtf_internal_light_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                    const float* film, float* g_film, float* g_bias, int c, int K, int B, int N, int f,
                                    int pattern0, float eps, int mode, const GwtfKS& ks, const float* g_ps_c,
-                                   const float* g_lvs_c, void* stream);
+                                   const float* g_lvs_c, const GwtfCombine& cmb, void* stream);
 int gwtf_internal_merged_backward_k(const float* x_in, const float* g_out, const float* g_ld, const float* packed_w_c,
                                     const float* packed_b_c, const float* film, const float* g_stats, float* g_in, float* dw1_ws,
                                     float* g_sd0, int c, int K, int B, int N, int f, int pattern0, float eps, int mode,
-                                    const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, void* stream);
+                                    const GwtfKS& ks, const float* g_ps_c, const float* g_lvs_c, const GwtfCombine& cmb,
+                                    void* stream);
 int gwtf_internal_dw1_reduce_k(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N, int K,
                                size_t ws_sk, size_t out_sk, void* stream);
 
@@ -223,8 +227,8 @@ extern "C" int gwtf_train_fold0(const float* raw_c, const float* moments, double
   if (!raw_c || !moments || !packed_w_c || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP_TRAIN || G <= 0 || pattern < 0 ||
       pattern > 5 || n_total < 1.0)
     return GWTF_E_BADARG;
-  hipLaunchKernelGGL(fold0_kernel, dim3(1), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, moments, n_total, pattern,
-                     packed_w_c, packed_b_c, bn_batch_c, f, G, gwtf_padded_width(f), single_ks(1));
+  hipLaunchKernelGGL(fold0_kernel<GWTF_STAT_REPLICAS>, dim3(1), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, moments, n_total,
+                     pattern, packed_w_c, packed_b_c, bn_batch_c, f, G, gwtf_padded_width(f), single_ks(1));
   return (int)hipGetLastError();
 }
 
@@ -233,8 +237,8 @@ extern "C" int gwtf_train_fold1(const float* raw_c, const float* ystats, double 
   if (!raw_c || !ystats || !film_raw || !film_rec || !bn_batch_c || f <= 0 || f > GWTF_MAX_FP_TRAIN || G <= 0 || B <= 0 ||
       c < 0 || c >= C || n_total < 1.0)
     return GWTF_E_BADARG;
-  hipLaunchKernelGGL(fold1_kernel, dim3(B), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, ystats, n_total, film_raw,
-                     film_rec, bn_batch_c, c, C, f, G, gwtf_padded_width(f), single_ks(C));
+  hipLaunchKernelGGL(fold1_kernel<GWTF_STAT_REPLICAS>, dim3(B), dim3(2 * GWTF_MAX_FP), 0, (hipStream_t)stream, raw_c, ystats, n_total,
+                     film_raw, film_rec, bn_batch_c, c, C, f, G, gwtf_padded_width(f), single_ks(C));
   return (int)hipGetLastError();
 }
 
@@ -269,7 +273,8 @@ constexpr int kF1Slices = 16;
 __global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
     const float* __restrict__ raw_c, const float* __restrict__ ystats, double n_total, const float* __restrict__ film_raw,
     const float* __restrict__ g_film, const float* __restrict__ g_bias, float* __restrict__ g_film_raw,
-    float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G, int FP, const GwtfKS ks) {
+    float* __restrict__ g_raw_c, float* __restrict__ g_stats, int c, int B, int C, int f, int G, int FP, const GwtfKS ks,
+    int NR /* copies of ystats to add: 1 = the compact record */) {
   raw_c += blockIdx.z * ks.raw;      // blockIdx.z = mixture component
   ystats += blockIdx.z * ks.ys;
   g_bias += blockIdx.z * ks.gbias;
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
   {
     float ys = 0.f, yq = 0.f;
     if (on)
-      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) {
+      for (int r = sl; r < NR; r += kF1Slices) {
         ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
         yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
       }
@@ -370,35 +375,20 @@ __global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
   }
 }
 
-// moments of the kept coordinates (mean / covariance terms) from the 64 replicas of the 9 raw moments
-struct KeptMoments { double e0, e1, c00, c01, c11; };
-__device__ inline KeptMoments kept_moments(const float (&mom)[9], int k0, int k1, double n_total) {
-  auto M = [&](int i) { float v = 0.f;
-#pragma unroll
-    for (int u = 0; u < 9; ++u) v = u == i ? mom[u] : v;
-    return v; };
-  KeptMoments r;
-  r.e0 = M(k0) / n_total;
-  r.e1 = k1 >= 0 ? M(k1) / n_total : 0.0;
-  r.c00 = M(mom2_index(k0, k0)) / n_total - r.e0 * r.e0;
-  r.c11 = k1 >= 0 ? M(mom2_index(k1, k1)) / n_total - r.e1 * r.e1 : 0.0;
-  r.c01 = k1 >= 0 ? M(mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)) / n_total - r.e0 * r.e1 : 0.0;
-  return r;
-}
-
 // g_sd0 replicas -> dW0, dgamma0, dbeta0, and this workgroup's share of the five sums the moment gradients need.
 // Every (branch, feature) is independent up to those sums: grid = (branch, tile of 16 features), block = 16 slices (over
-// the replicas) x 16 features; the partial sums go to `part` [2][FP/16][5] doubles and combine_kernel finishes the job.
+// the replicas) x 16 features.  Each block turns its five sums into its SHARE of the nine moment gradients gM (linear in them) and
+// adds it to gm [16] with float atomics (gm zero before the level's launch): 2 * FP/16 adds per value, no finishing kernel.
 // block (bx = branch, by = tile of 16 features of n_by, bz = mixture component)
 __device__ __forceinline__ void fold0_bwd_block(
     const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
-    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP,
-    const GwtfKS& ks, int bx, int by, int bz, int n_by) {
+    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, float* __restrict__ gm, int f, int G, int FP,
+    const GwtfKS& ks, int bx, int by, int bz, int n_by, int NR /* copies of the moment record */) {
   raw_c += bz * ks.raw;
   mom_rep += bz * ks.mom;
   g_sd0 += bz * ks.gsd0;
   g_raw_c += bz * ks.raw;
-  part += bz * (ks.gmom / 2);   // ks.gmom counts floats, part is double
+  gm += bz * ks.gmom;
   const int t = threadIdx.x % 16, sl = threadIdx.x / 16;
   const int br = bx, j = by * 16 + t;
   __shared__ float mom_part[kF1Slices][9];
@@ -407,7 +397,7 @@ __device__ __forceinline__ void fold0_bwd_block(
   const bool on = j < f;
   if (t < 9) {
     float sacc = 0.f;
-    for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) sacc += mom_rep[r * 16 + t];
+    for (int r = sl; r < NR; r += kF1Slices) sacc += mom_rep[r * 16 + t];
     mom_part[sl][t] = sacc;
   }
   {
@@ -472,124 +462,121 @@ __device__ __forceinline__ void fold0_bwd_block(
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  if (t < 5) {
-    double acc = 0.0;
+  if (t == 0) {
+    double r5[5];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc += red[u][t];
-    part[((size_t)br * n_by + by) * 5 + t] = acc;
+    for (int i = 0; i < 5; ++i) {
+      double acc = 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc += red[u][i];
+      r5[i] = acc;
+    }
+    float share[16];
+    moment_grad_terms(km, r5, pat, n_total, share);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) atomicAdd(&gm[i], share[i]);
   }
 }
 
 __global__ __launch_bounds__(kF1Slices * 16) void fold0_bwd_kernel(
     const float* __restrict__ raw_c, const float* __restrict__ mom_rep, double n_total, int pat,
-    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP,
-    const GwtfKS ks) {
-  fold0_bwd_block(raw_c, mom_rep, n_total, pat, g_sd0, g_raw_c, part, f, G, FP, ks, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y);
+    const float* __restrict__ g_sd0, float* __restrict__ g_raw_c, float* __restrict__ gm, int f, int G, int FP,
+    const GwtfKS ks, int NR) {
+  fold0_bwd_block(raw_c, mom_rep, n_total, pat, g_sd0, g_raw_c, gm, f, G, FP, ks, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, NR);
 }
 
-// g_in = g_a [+ g_b: a second pass's share, null when one merged pass wrote g_a] + d(moments)/dx:  gM_a + sum_b Q_ab x_b,  Q_aa = 2 gM_aa, Q_ab = gM_ab.  The nine moment gradients gM
-// are finished here from fold0_bwd_kernel's partial sums (every workgroup redoes the ~100 loads: cheaper than one more
-// single-workgroup kernel in the dependency chain).
-// block (bx of n_bx = slice of the points, by = shape, bz = mixture component)
+// g_in = g_a [+ g_b: a second pass's share, null when one merged pass wrote g_a] + d(moments)/dx:  gM_a + sum_b Q_ab x_b,
+// Q_aa = 2 gM_aa, Q_ab = gM_ab, with the level's nine moment gradients gM (fold0_bwd_block).  The train pipeline applies this on the
+// fly inside the next level's passes (GwtfCombine); as a pass of its own it is left for the LAST level (dL/dp) and the per-coupling
+// entry point.   block (bx of n_bx = slice of the points, by = shape, bz = mixture component)
 __device__ __forceinline__ void combine_block(const float* __restrict__ x, const float* __restrict__ ga,
-                                              const float* __restrict__ gb, const float* __restrict__ mom_rep,
-                                              const double* __restrict__ part, int n_part, double n_total, int pat,
+                                              const float* __restrict__ gb, const float* __restrict__ gm_k,
                                               float* __restrict__ g_in, int B, int N, const GwtfKS& ks, int bx, int by, int bz,
                                               int n_bx) {
   x += bz * ks.x;
   ga += bz * ks.pts;
   if (gb) gb += bz * ks.pts;
   g_in += bz * ks.pts;
-  mom_rep += bz * ks.mom;
-  part += bz * (ks.gmom / 2);
-  __shared__ float s_mom[9];
-  __shared__ double s_r5[5];
-  __shared__ float s_gm[16];
-  if (threadIdx.x < 9) {
-    float sacc = 0.f;
-    for (int r = 0; r < GWTF_STAT_REPLICAS; ++r) sacc += mom_rep[r * 16 + threadIdx.x];
-    s_mom[threadIdx.x] = sacc;
-  } else if (threadIdx.x >= 64 && threadIdx.x < 69) {
-    double acc = 0.0;
-    for (int u = 0; u < n_part; ++u) acc += part[(size_t)u * 5 + (threadIdx.x - 64)];
-    s_r5[threadIdx.x - 64] = acc;
-  }
-  if (threadIdx.x < 16) s_gm[threadIdx.x] = 0.f;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float mom[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) mom[i] = s_mom[i];
-    int k0, k1, w0d, w1d;
-    gwtf_pattern_dims(pat, &k0, &k1, &w0d, &w1d);
-    const KeptMoments km = kept_moments(mom, k0, k1, n_total);
-    const double gC00 = s_r5[2], gC01 = s_r5[3], gC11 = s_r5[4];
-    const double gE0 = s_r5[0] - 2.0 * km.e0 * gC00 - km.e1 * gC01;
-    const double gE1 = s_r5[1] - 2.0 * km.e1 * gC11 - km.e0 * gC01;
-    s_gm[k0] = (float)(gE0 / n_total);
-    s_gm[mom2_index(k0, k0)] = (float)(gC00 / n_total);
-    if (k1 >= 0) {
-      s_gm[k1] = (float)(gE1 / n_total);
-      s_gm[mom2_index(k1, k1)] = (float)(gC11 / n_total);
-      s_gm[mom2_index(k0 < k1 ? k0 : k1, k0 < k1 ? k1 : k0)] = (float)(gC01 / n_total);
-    }
-  }
-  __syncthreads();
-  const float* gm = s_gm;
+  const float* gm = gm_k + bz * ks.gmom;
   const int b = by;
+  const float g0 = gm[0], g1 = gm[1], g2 = gm[2];
   const float q00 = 2.f * gm[3], q01 = gm[4], q02 = gm[5], q11 = 2.f * gm[6], q12 = gm[7], q22 = 2.f * gm[8];
   for (int n = bx * blockDim.x + threadIdx.x; n < N; n += n_bx * blockDim.x) {
     const size_t o0 = ((size_t)b * 3 + 0) * N + n, o1 = o0 + N, o2 = o1 + N;
     const float x0 = x[o0], x1 = x[o1], x2 = x[o2];
     const float a0 = gb ? ga[o0] + gb[o0] : ga[o0], a1 = gb ? ga[o1] + gb[o1] : ga[o1], a2 = gb ? ga[o2] + gb[o2] : ga[o2];
-    g_in[o0] = a0 + gm[0] + q00 * x0 + q01 * x1 + q02 * x2;
-    g_in[o1] = a1 + gm[1] + q01 * x0 + q11 * x1 + q12 * x2;
-    g_in[o2] = a2 + gm[2] + q02 * x0 + q12 * x1 + q22 * x2;
+    g_in[o0] = a0 + g0 + q00 * x0 + q01 * x1 + q02 * x2;
+    g_in[o1] = a1 + g1 + q01 * x0 + q11 * x1 + q12 * x2;
+    g_in[o2] = a2 + g2 + q02 * x0 + q12 * x1 + q22 * x2;
   }
 }
 
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ x, const float* __restrict__ ga,
-                                                      const float* __restrict__ gb, const float* __restrict__ mom_rep,
-                                                      const double* __restrict__ part, int n_part, double n_total, int pat,
+                                                      const float* __restrict__ gb, const float* __restrict__ gm,
                                                       float* __restrict__ g_in, int B, int N, const GwtfKS ks) {
-  combine_block(x, ga, gb, mom_rep, part, n_part, n_total, pat, g_in, B, N, ks, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+  combine_block(x, ga, gb, gm, g_in, B, N, ks, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
 }
 
-// The tail of a backward level is four small kernels in a row -- sd0 fold, gradient combine, the two stages of the dW1 partial
-// reduction -- of which only the combine feeds the next level.  Two launches instead of four: the sd0 fold runs beside stage 1 of
-// the reduction (they are independent), the combine beside stage 2.  Blocks [0, n_role0) take the first role.
-__global__ __launch_bounds__(256) void bwd_tail1_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom_rep,
+// The tail of a backward level: the sd0 fold's backward (its share of the moment gradients gM feeds the NEXT level's passes, which
+// apply the gradient combine on the fly: gwtf_layout.h GwtfCombine), beside it stage 1 of this level's dW1 partial reduction and
+// stage 2 of the PREVIOUS level's (nothing on the dependency chain waits for either) -- one launch.  Blocks [0, n_role0) fold, the
+// next n_role1 run stage 1, the rest stage 2 (mid_prev == null: none).
+__global__ __launch_bounds__(256) void bwd_tail1_kernel(const float* __restrict__ raw_c, const float* __restrict__ mom,
                                                         double n_total, int pat, const float* __restrict__ g_sd0,
-                                                        float* __restrict__ g_raw_c, double* __restrict__ part, int f, int G, int FP,
-                                                        const GwtfKS ks, int K, const float* __restrict__ ws, int n_partials,
-                                                        float* __restrict__ mid, int rec) {
-  const int n_by = FP / 16, n_role0 = 2 * n_by * K;
+                                                        float* __restrict__ g_raw_c, float* __restrict__ gm, int f, int G, int FP,
+                                                        const GwtfKS ks, int K, int NR, const float* __restrict__ ws, int n_partials,
+                                                        float* __restrict__ mid, int rec, const float* __restrict__ mid_prev,
+                                                        float* __restrict__ dW1_prev, size_t branch_stride) {
+  __shared__ float red[4][64];
+  const int n_by = FP / 16, n_role0 = 2 * n_by * K, gx = (rec + 255) / 256, n_role1 = gx * gwtf_dw1::kStage * K;
   if ((int)blockIdx.x < n_role0) {
     const int b = blockIdx.x;
-    fold0_bwd_block(raw_c, mom_rep, n_total, pat, g_sd0, g_raw_c, part, f, G, FP, ks, b % 2, (b / 2) % n_by, b / (2 * n_by), n_by);
+    fold0_bwd_block(raw_c, mom, n_total, pat, g_sd0, g_raw_c, gm, f, G, FP, ks, b % 2, (b / 2) % n_by, b / (2 * n_by), n_by, NR);
     return;
   }
-  const int b = blockIdx.x - n_role0, gx = (rec + 255) / 256;
-  const int bx = b % gx, by = (b / gx) % gwtf_dw1::kStage, bz = b / (gx * gwtf_dw1::kStage);
-  gwtf_dw1::fold_block(ws + bz * ks.dw1, n_partials, mid + bz * ks.dw1, rec, bx, by, threadIdx.x);
+  if ((int)blockIdx.x < n_role0 + n_role1) {
+    const int b = blockIdx.x - n_role0;
+    const int bx = b % gx, by = (b / gx) % gwtf_dw1::kStage, bz = b / (gx * gwtf_dw1::kStage);
+    gwtf_dw1::fold_block(ws + bz * ks.dw1, n_partials, mid + bz * ks.dw1, rec, bx, by, threadIdx.x);
+    return;
+  }
+  const int b = blockIdx.x - n_role0 - n_role1, g2 = (2 * f * f + 63) / 64;
+  gwtf_dw1::reduce_block(mid_prev + (b / g2) * ks.dw1, dW1_prev + (b / g2) * ks.raw, f, branch_stride, b % g2, threadIdx.x, red);
 }
 
+// After the LAST backward level: the one gradient combine no later pass applies (dL/dp of the input clouds) beside stage 2 of that
+// level's dW1 reduction.
 __global__ __launch_bounds__(256) void bwd_tail2_kernel(const float* __restrict__ x, const float* __restrict__ ga,
-                                                        const float* __restrict__ gb, const float* __restrict__ mom_rep,
-                                                        const double* __restrict__ part, int n_part, double n_total, int pat,
-                                                        float* __restrict__ g_in, int B, int N, const GwtfKS ks, int K, int n_bx,
-                                                        const float* __restrict__ mid, float* __restrict__ dW1, int f,
-                                                        size_t branch_stride) {
+                                                        const float* __restrict__ gm, float* __restrict__ g_in, int B, int N,
+                                                        const GwtfKS ks, int K, int n_bx, const float* __restrict__ mid,
+                                                        float* __restrict__ dW1, int f, size_t branch_stride) {
   __shared__ float red[4][64];
   const int n_role0 = n_bx * B * K;
   if ((int)blockIdx.x < n_role0) {
     const int b = blockIdx.x;
-    combine_block(x, ga, gb, mom_rep, part, n_part, n_total, pat, g_in, B, N, ks, b % n_bx, (b / n_bx) % B, b / (n_bx * B), n_bx);
+    combine_block(x, ga, nullptr, gm, g_in, B, N, ks, b % n_bx, (b / n_bx) % B, b / (n_bx * B), n_bx);
     return;
   }
   const int b = blockIdx.x - n_role0, gx = (2 * f * f + 63) / 64;
   const int bx = b % gx, bz = b / gx;
   gwtf_dw1::reduce_block(mid + bz * ks.dw1, dW1 + bz * ks.raw, f, branch_stride, bx, threadIdx.x, red);
+}
+
+// sum of the R copies of a replicated statistic slab [K][R][n] -> the contiguous record [K][n] a data-parallel run all-reduces and
+// its consumers then read (fixed order: the same sum on every run)
+__global__ __launch_bounds__(256) void stat_compact_kernel(const float* __restrict__ slab, float* __restrict__ out, int R, int n,
+                                                           size_t slab_sk) {
+  const float* s = slab + (size_t)blockIdx.x * slab_sk;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int r = 0; r < R; r += 4) {
+      a0 += s[(size_t)r * n + i];
+      a1 += s[(size_t)(r + 1) * n + i];
+      a2 += s[(size_t)(r + 2) * n + i];
+      a3 += s[(size_t)(r + 3) * n + i];
+    }
+    out[(size_t)blockIdx.x * n + i] = (a0 + a1) + (a2 + a3);
+  }
 }
 
 }  // namespace
@@ -608,23 +595,32 @@ extern "C" int gwtf_pack_w1t(const float* raw, float* packed_b, int C, int f, in
 // (SyncBatchNorm semantics, reference train_ae.py:152):
 //
 //   forward, per depth level (coupling c = step or C-1-step):
-//     GWTF_PHASE_FWD_INIT           moments of the input clouds                      -> all-reduce moments[0]      (1 x 64*16)
-//     GWTF_PHASE_FWD_A   fold0 (K workgroups) + statistics pass (K x tiles)          -> all-reduce ystats[c]       (K x 64*2*FP*2)
-//     GWTF_PHASE_FWD_B   fold1 (B x K) + apply pass (K x tiles, moments of the output) -> all-reduce moments[step+1] (K x 64*16)
+//     GWTF_PHASE_FWD_INIT           moments of the input clouds                        -> all-reduce mom_c[0][0]    (16)
+//     GWTF_PHASE_FWD_A   fold0 (K workgroups) + statistics pass (K x tiles)            -> all-reduce ys_c[c]        (K x 2*FP*2)
+//     GWTF_PHASE_FWD_B   fold1 (B x K) + apply pass (K x tiles, moments of the output) -> all-reduce mom_c[step+1]  (K x 16)
 //   backward, per depth level in reverse:
 //     GWTF_PHASE_BWD_A   light pass (FiLM-record / bias sums of the coupling path) + fold1 backward -> all-reduce g_stats[c] (K x 2*2*FP)
-//     GWTF_PHASE_BWD_B   merged backward (coupling + statistics path) + fold0 backward  -> all-reduce g_mom[c]     (K x 48 doubles)
-//     GWTF_PHASE_BWD_C   combine (moments path) + dW1 reduction
+//     GWTF_PHASE_BWD_B   merged backward (coupling + statistics path) + tail (fold0 backward | dW1 stage 1 | the previous level's
+//                        dW1 stage 2)                                                  -> all-reduce g_mom[c]       (K x 16)
+//     GWTF_PHASE_BWD_C   nothing, except after the LAST level: the final gradient combine (dL/dp) + that level's dW1 stage 2
+//   The gradient combine of a level (moment path: g += gM + Q x) is applied on the fly by the NEXT level's light and merged passes
+//   (gwtf_layout.h GwtfCombine), which recompute that level's input coordinates anyway.
+//
+// Statistics are accumulated by atomics spread over 64 copies.  One rank: the folds add the copies up themselves.  Data parallel
+// (ctx.mom_c / ys_c given): each forward phase ends with ONE small launch that sums the copies into a compact [K][n] record -- what
+// goes on the wire (3 KB per collective at f = 37, K = 4) and what every consumer then reads.  (Letting the last workgroup of the
+// pass do that sum -- an arrival ticket -- was built and measured: every workgroup then waits for its own atomics and a returning
+// ticket add before it can retire, statistics pass 23.0 -> 32.0 us, apply pass 29.0 -> 31.1; docs/LOG.md round 4.)
 //
 // i.e. TWO small collectives per depth level and direction for all K x 2 branches (66 per forward of the 33-coupling
-// configs; the reference's SyncBatchNorm issues 1056), 4 + 7 launches per level instead of 4K + 10K.  A single rank runs
+// configs; the reference's SyncBatchNorm issues 1056), 4 + 4 launches per level instead of 4K + 10K.  A single rank runs
 // all phases back to back from one C call (gwtf_mtrain_forward / gwtf_mtrain_backward).  Buffer layouts: GwtfTrainCtx in
-// include/gwtf.h; per-level slabs are contiguous over K so that one collective covers a level.
+// include/gwtf.h; per-level records are contiguous over K so that one collective covers a level.
 // =====================================================================================================================
 namespace {
 struct Dims {
   int FP;
-  size_t RC, PW, PB, MS, YS, BS, XS, GS0, GB, GST, GM, FS;
+  size_t RC, PW, PB, MS, YS, YC, BS, XS, GS0, GB, GST, GM, FS;
 };
 Dims dims_of(const GwtfTrainCtx* t) {
   Dims d;
@@ -633,18 +629,31 @@ Dims dims_of(const GwtfTrainCtx* t) {
   d.PW = gwtf_packed_w_coupling_floats(t->f);
   d.PB = gwtf_packed_b_coupling_floats(t->f);
   d.MS = (size_t)GWTF_STAT_REPLICAS * 16;
-  d.YS = (size_t)GWTF_STAT_REPLICAS * 2 * d.FP * 2;
+  d.YC = (size_t)2 * d.FP * 2;
+  d.YS = (size_t)GWTF_STAT_REPLICAS * d.YC;
   d.BS = (size_t)2 * 4 * 2 * t->f;
   d.XS = (size_t)t->B * 3 * t->N;
   d.GS0 = (size_t)GWTF_STAT_REPLICAS * 2 * 3 * d.FP;
   d.GB = (size_t)GWTF_STAT_REPLICAS * 4;
   d.GST = (size_t)2 * 2 * d.FP;
-  d.GM = 96;
+  d.GM = 16;
   d.FS = gwtf_film_out_size(d.FP);
   return d;
 }
-size_t dw1_region(const GwtfTrainCtx* t) {   // one component's dW1 workspace: the merged pass's partials + reduction scratch
-  return gwtf_dw1_workspace_floats(t->f, t->B, t->N) + gwtf_dw1_reduce_scratch_floats(t->f);
+// one component's dW1 workspace: the merged pass's partials + TWO stage-1 scratch records (stage 2 of a level runs beside stage 1 of
+// the next)
+size_t dw1_region(int f, int B, int N) {
+  return gwtf_dw1_workspace_floats(f, B, N) + 2 * gwtf_dw1_reduce_scratch_floats(f);
+}
+// Where the consumers of a forward statistic read it: the pass's 64 copies (one rank), or the compact record (data parallel)
+struct StatView { const float* p; size_t sk; int nr; };
+StatView moments_of(const GwtfTrainCtx* t, const Dims& d, int level) {
+  if (t->mom_c) return {t->mom_c + (size_t)level * t->K * 16, level == 0 ? (size_t)0 : (size_t)16, 1};
+  return {t->moments + (size_t)level * t->K * d.MS, level == 0 ? (size_t)0 : d.MS, GWTF_STAT_REPLICAS};   // level 0: the shared input clouds
+}
+StatView ystats_of(const GwtfTrainCtx* t, const Dims& d, int c) {
+  if (t->ys_c) return {t->ys_c + (size_t)c * t->K * d.YC, d.YC, 1};
+  return {t->ystats + (size_t)c * t->K * d.YS, d.YS, GWTF_STAT_REPLICAS};
 }
 GwtfKS strides_of(const GwtfTrainCtx* t, const Dims& d, bool first_level) {
   GwtfKS ks = {};
@@ -653,14 +662,14 @@ GwtfKS strides_of(const GwtfTrainCtx* t, const Dims& d, bool first_level) {
   ks.pb = (size_t)t->C * d.PB;
   ks.x = first_level ? 0 : d.XS;       // the first level reads the shared input clouds
   ks.pts = d.XS;
-  ks.mom = first_level ? 0 : d.MS;     // ... and their (single) moment record
-  ks.ys = d.YS;
+  ks.mom = first_level ? 0 : (t->mom_c ? 16 : d.MS);     // ... and their (single) moment record
+  ks.ys = t->ys_c ? d.YC : d.YS;
   ks.bn = (size_t)t->C * d.BS;
   ks.gsd0 = d.GS0;
   ks.gbias = d.GB;
   ks.gstats = d.GST;
   ks.gmom = d.GM;
-  ks.dw1 = dw1_region(t);
+  ks.dw1 = dw1_region(t->f, t->B, t->N);
   ks.Cper = t->C;
   ks.Ctot = t->K * t->C;
   ks.tune = t->tune;
@@ -671,21 +680,24 @@ bool ctx_ok(const GwtfTrainCtx* t, bool backward) {
       t->G <= 0 || t->pattern0 < 0 || t->pattern0 > 5 || t->n_total < 1.0)
     return false;
   if (t->mode != GWTF_MODE_DIRECT && t->mode != GWTF_MODE_INVERSE) return false;
-  if (!t->p || !t->raw || !t->packed_w || !t->film_raw || !t->film_rec || !t->moments || !t->ystats || !t->bn_batch || !t->xbuf ||
-      !t->logdet)
-    return false;
+  if (!t->p || !t->raw || !t->packed_w || !t->film_raw || !t->film_rec || !t->bn_batch || !t->xbuf || !t->logdet) return false;
+  if ((t->mom_c == nullptr) != (t->ys_c == nullptr)) return false;          // both compact records, or neither
+  const bool copies = t->moments && t->ystats;
+  if (!backward && !copies) return false;                                   // the passes' atomics always land in the copies
+  if (backward && !copies && !t->mom_c) return false;
   const bool any = t->ps || t->mus || t->logvars, all = t->ps && t->mus && t->logvars, ps_only = t->ps && !t->mus && !t->logvars;
   if (any && !all && !ps_only) return false;
-  if (backward && (!t->ps || !t->packed_b || !t->g_out || !t->g_ld || !t->g_bufs || !t->g_xa || !t->g_xb || !t->dw1_ws ||
+  if (backward && (!t->ps || !t->packed_b || !t->g_out || !t->g_ld || !t->g_bufs || !t->dw1_ws ||
                    !t->g_film || !t->g_sd0 || !t->g_bias || !t->g_stats || !t->g_mom || !t->g_film_raw || !t->g_raw))
     return false;
   return true;
 }
+void compact(const float* slab, size_t slab_sk, float* out, int K, int n, hipStream_t st) {
+  hipLaunchKernelGGL(stat_compact_kernel, dim3(K), dim3(256), 0, st, slab, out, GWTF_STAT_REPLICAS, n, slab_sk);
+}
 }  // namespace
 
-extern "C" size_t gwtf_mtrain_dw1_floats(int f, int B, int N) {
-  return gwtf_dw1_workspace_floats(f, B, N) + gwtf_dw1_reduce_scratch_floats(f);
-}
+extern "C" size_t gwtf_mtrain_dw1_floats(int f, int B, int N) { return dw1_region(f, B, N); }
 
 extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   const bool bwd = phase == GWTF_PHASE_BWD_A || phase == GWTF_PHASE_BWD_B || phase == GWTF_PHASE_BWD_C;
@@ -693,28 +705,45 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   const Dims d = dims_of(t);
   const int K = t->K, C = t->C, B = t->B, N = t->N, f = t->f, G = t->G, FP = d.FP;
   hipStream_t st = (hipStream_t)t->stream;
-  if (phase == GWTF_PHASE_FWD_INIT) return gwtf_train_moments(t->p, t->moments, B, N, t->stream);
+  if (phase == GWTF_PHASE_FWD_INIT) {
+    int rc = gwtf_train_moments(t->p, t->moments, B, N, t->stream);
+    if (!rc && t->mom_c) compact(t->moments, 0, t->mom_c, 1, 16, st);
+    return rc ? rc : (int)hipGetLastError();
+  }
 
   if (!bwd) {
     const int c = t->mode == GWTF_MODE_DIRECT ? step : C - 1 - step;
     const int pat = (t->pattern0 + c) % 6;
     const GwtfKS ks = strides_of(t, d, step == 0);
     const float* cur = step == 0 ? t->p : t->xbuf + (size_t)((step - 1) & 1) * K * d.XS;
-    float* mom = t->moments + (size_t)step * K * d.MS;
-    float* ys = t->ystats + (size_t)c * K * d.YS;
+    const StatView mom = moments_of(t, d, step), ys = ystats_of(t, d, c);
+    float* ys_copies = t->ystats + (size_t)c * K * d.YS;
     if (phase == GWTF_PHASE_FWD_A) {
-      hipLaunchKernelGGL(fold0_kernel, dim3(K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, mom, t->n_total, pat,
-                         t->packed_w + (size_t)c * d.PW, t->packed_b ? t->packed_b + (size_t)c * d.PB : nullptr,
-                         t->bn_batch + (size_t)c * d.BS, f, G, FP, ks);
-      return gwtf_internal_stats_k(cur, t->packed_w + (size_t)c * d.PW, ys, K, B, N, f, pat, ks.x, ks.pw, ks.ys, t->tune, t->stream);
+      float* pb_c = t->packed_b ? t->packed_b + (size_t)c * d.PB : nullptr;
+      if (mom.nr == 1)
+        hipLaunchKernelGGL(fold0_kernel<1>, dim3(K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, mom.p, t->n_total, pat,
+                           t->packed_w + (size_t)c * d.PW, pb_c, t->bn_batch + (size_t)c * d.BS, f, G, FP, ks);
+      else
+        hipLaunchKernelGGL(fold0_kernel<GWTF_STAT_REPLICAS>, dim3(K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, mom.p,
+                           t->n_total, pat, t->packed_w + (size_t)c * d.PW, pb_c, t->bn_batch + (size_t)c * d.BS, f, G, FP, ks);
+      int rc = gwtf_internal_stats_k(cur, t->packed_w + (size_t)c * d.PW, ys_copies, K, B, N, f, pat, ks.x, ks.pw, d.YS, t->tune, t->stream);
+      if (!rc && t->ys_c) compact(ys_copies, d.YS, t->ys_c + (size_t)c * K * d.YC, K, (int)d.YC, st);
+      return rc ? rc : (int)hipGetLastError();
     }
     if (phase == GWTF_PHASE_FWD_B) {
-      hipLaunchKernelGGL(fold1_kernel, dim3(B, K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, ys, t->n_total,
-                         t->film_raw, t->film_rec, t->bn_batch + (size_t)c * d.BS, c, C, f, G, FP, ks);
+      if (ys.nr == 1)
+        hipLaunchKernelGGL(fold1_kernel<1>, dim3(B, K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, ys.p, t->n_total,
+                           t->film_raw, t->film_rec, t->bn_batch + (size_t)c * d.BS, c, C, f, G, FP, ks);
+      else
+        hipLaunchKernelGGL(fold1_kernel<GWTF_STAT_REPLICAS>, dim3(B, K), dim3(2 * GWTF_MAX_FP), 0, st, t->raw + (size_t)c * d.RC, ys.p,
+                           t->n_total, t->film_raw, t->film_rec, t->bn_batch + (size_t)c * d.BS, c, C, f, G, FP, ks);
       float* nxt = t->xbuf + (size_t)(step & 1) * K * d.XS;
-      return gwtf_internal_apply_k(cur, t->packed_w, t->film_rec, nxt, step > 0 ? t->logdet : nullptr, t->logdet, t->ps, t->mus,
-                                   t->logvars, step + 1 < C ? t->moments + (size_t)(step + 1) * K * d.MS : nullptr, d.MS, c, K, B,
-                                   N, C, f, t->pattern0, t->eps, t->mode, ks.x, d.XS, t->tune, t->stream);
+      float* mom_next = step + 1 < C ? t->moments + (size_t)(step + 1) * K * d.MS : nullptr;
+      int rc = gwtf_internal_apply_k(cur, t->packed_w, t->film_rec, nxt, step > 0 ? t->logdet : nullptr, t->logdet, t->ps, t->mus,
+                                     t->logvars, mom_next, d.MS, c, K, B, N, C, f, t->pattern0, t->eps, t->mode, ks.x, d.XS, t->tune,
+                                     t->stream);
+      if (!rc && mom_next && t->mom_c) compact(mom_next, d.MS, t->mom_c + (size_t)(step + 1) * K * 16, K, 16, st);
+      return rc ? rc : (int)hipGetLastError();
     }
     return GWTF_E_BADARG;
   }
@@ -729,10 +758,9 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   const float* x_in = from_p ? t->p : t->ps + (size_t)(inverse ? c + 1 : c - 1) * d.XS;
   if (!from_p) ks.x = (size_t)C * d.XS;                 // lists are [K][C][B][3][N]
   const int c_prev = inverse ? c - 1 : c + 1;           // the coupling handled by the previous backward step
-  const float* cur = step == 0 ? t->g_out : t->g_bufs + (size_t)(c_prev & 1) * K * d.XS;
+  const float* cur = step == 0 ? t->g_out : t->g_bufs + (size_t)(c_prev & 1) * K * d.XS;   // that step's RAW gradient (its combine: below)
   float* nxt = t->g_bufs + (size_t)(c & 1) * K * d.XS;
-  const float* mom = t->moments + (size_t)fstep * K * d.MS;
-  const float* ys = t->ystats + (size_t)c * K * d.YS;
+  const StatView mom = moments_of(t, d, fstep), ys = ystats_of(t, d, c);
   float* g_sd0 = t->g_sd0 + (size_t)c * K * d.GS0;
   float* g_bias = t->g_bias + (size_t)c * K * d.GB;
   float* g_stats = t->g_stats + (size_t)c * K * d.GST;
@@ -742,34 +770,42 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   float* g_raw_c = t->g_raw + (size_t)c * d.RC;
   const float* g_ps_c = t->g_ps ? t->g_ps + (size_t)c * d.XS : nullptr;
   const float* g_lvs_c = t->g_lvs ? t->g_lvs + (size_t)c * d.XS : nullptr;
+  const GwtfRaw R(f, G);
+  const int rec = 2 * f * f, n_partials = gwtf_dw1_partials(B, N);
+  const size_t scratch = gwtf_dw1_reduce_scratch_floats(f);
+  float* mid = t->dw1_ws + (size_t)n_partials * rec + (size_t)(c & 1) * scratch;
+  // the previous step's gradient combine, applied on the fly by this step's passes: its input was this coupling's output
+  GwtfCombine cmb = {};
+  if (step > 0) {
+    cmb.gm = t->g_mom + (size_t)c_prev * K * d.GM;
+    cmb.gm_sk = d.GM;
+  }
   if (phase == GWTF_PHASE_BWD_A) {
     int rc = gwtf_internal_light_backward_k(x_in, cur, t->g_ld, pw_c, t->film_rec, t->g_film, g_bias, c, K, B, N, f, t->pattern0,
-                                            t->eps, t->mode, ks, g_ps_c, g_lvs_c, t->stream);
+                                            t->eps, t->mode, ks, g_ps_c, g_lvs_c, cmb, t->stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, K), dim3(kF1Slices * 16), 0, st, t->raw + (size_t)c * d.RC, ys,
-                       t->n_total, t->film_raw, t->g_film, g_bias, t->g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks);
+    hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, K), dim3(kF1Slices * 16), 0, st, t->raw + (size_t)c * d.RC, ys.p,
+                       t->n_total, t->film_raw, t->g_film, g_bias, t->g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks, ys.nr);
     return (int)hipGetLastError();
   }
   if (phase == GWTF_PHASE_BWD_B) {
-    int rc = gwtf_internal_merged_backward_k(x_in, cur, t->g_ld, pw_c, pb_c, t->film_rec, g_stats, t->g_xa, t->dw1_ws, g_sd0, c, K, B,
-                                             N, f, t->pattern0, t->eps, t->mode, ks, g_ps_c, g_lvs_c, t->stream);
+    int rc = gwtf_internal_merged_backward_k(x_in, cur, t->g_ld, pw_c, pb_c, t->film_rec, g_stats, nxt, t->dw1_ws, g_sd0, c, K, B,
+                                             N, f, t->pattern0, t->eps, t->mode, ks, g_ps_c, g_lvs_c, cmb, t->stream);
     if (rc) return rc;
-    // sd0 fold + stage 1 of the dW1 reduction in one launch
-    const int rec = 2 * f * f, n_partials = gwtf_dw1_partials(B, N);
-    float* mid = t->dw1_ws + (size_t)n_partials * rec;
-    const unsigned blocks = 2u * (FP / 16) * K + (unsigned)((rec + 255) / 256) * gwtf_dw1::kStage * K;
-    hipLaunchKernelGGL(bwd_tail1_kernel, dim3(blocks), dim3(256), 0, st, t->raw + (size_t)c * d.RC, mom, t->n_total, pat, g_sd0, g_raw_c,
-                       reinterpret_cast<double*>(g_mom), f, G, FP, ks, K, t->dw1_ws, n_partials, mid, rec);
+    // sd0 fold's backward | stage 1 of this level's dW1 reduction | stage 2 of the previous level's: one launch
+    const float* mid_prev = step > 0 ? t->dw1_ws + (size_t)n_partials * rec + (size_t)(c_prev & 1) * scratch : nullptr;
+    float* dW1_prev = step > 0 ? t->g_raw + (size_t)c_prev * d.RC + R.sd1_w() : nullptr;
+    const unsigned blocks = 2u * (FP / 16) * K + (unsigned)((rec + 255) / 256) * gwtf_dw1::kStage * K +
+                            (step > 0 ? (unsigned)((rec + 63) / 64) * K : 0u);
+    hipLaunchKernelGGL(bwd_tail1_kernel, dim3(blocks), dim3(256), 0, st, t->raw + (size_t)c * d.RC, mom.p, t->n_total, pat, g_sd0,
+                       g_raw_c, g_mom, f, G, FP, ks, K, mom.nr, t->dw1_ws, n_partials, mid, rec, mid_prev, dW1_prev, R.branch_size());
     return (int)hipGetLastError();
   }
-  // GWTF_PHASE_BWD_C: gradient combine + stage 2 of the dW1 reduction in one launch
+  // GWTF_PHASE_BWD_C: only after the last level -- its gradient combine (dL/dp, in place) + stage 2 of its dW1 reduction
+  if (step + 1 < C) return 0;
   const int bxn = (N + 255) / 256, n_bx = bxn < 64 ? bxn : 64;
-  const GwtfRaw R(f, G);
-  const int rec = 2 * f * f, n_partials = gwtf_dw1_partials(B, N);
-  const float* mid = t->dw1_ws + (size_t)n_partials * rec;
-  const unsigned blocks = (unsigned)n_bx * B * K + (unsigned)((2 * f * f + 63) / 64) * K;
-  hipLaunchKernelGGL(bwd_tail2_kernel, dim3(blocks), dim3(256), 0, st, x_in, t->g_xa, static_cast<const float*>(nullptr), mom,
-                     reinterpret_cast<const double*>(g_mom), 2 * (FP / 16), t->n_total, pat, nxt, B, N, ks, K, n_bx, mid,
+  const unsigned blocks = (unsigned)n_bx * B * K + (unsigned)((rec + 63) / 64) * K;
+  hipLaunchKernelGGL(bwd_tail2_kernel, dim3(blocks), dim3(256), 0, st, x_in, nxt, g_mom, nxt, B, N, ks, K, n_bx, mid,
                      g_raw_c + R.sd1_w(), f, R.branch_size());
   return (int)hipGetLastError();
 }
@@ -841,37 +877,6 @@ extern "C" int gwtf_gather_table(const unsigned long long* table, float* dst, in
   return (int)hipGetLastError();
 }
 
-// ---- statistic slabs on the wire (data-parallel runs) ---------------------------------------------------------------------------------
-// The forward statistics are accumulated by atomics spread over GWTF_STAT_REPLICAS = 64 copies (moments [K][64][16], ystats
-// [K][64][2 FP 2]).  All-reducing a slab as it stands sends 64 x the information (196 KB instead of 3 KB per collective at f = 37,
-// K = 4: no longer a latency-only message on xGMI).  gwtf_stat_compact sums the copies into a contiguous exchange buffer
-// xchg [K][n]; after the all-reduce gwtf_stat_expand writes the global sums back as copy 0 and zeroes the others, so every consumer
-// (the fold kernels sum the copies) reads the global statistic without knowing.
-namespace {
-__global__ __launch_bounds__(256) void stat_compact_kernel(const float* __restrict__ slab, float* __restrict__ xchg, int R, int n) {
-  const float* s = slab + (size_t)blockIdx.x * R * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    float acc = 0.f;
-    for (int r = 0; r < R; ++r) acc += s[(size_t)r * n + i];       // fixed order: the same sum on every run
-    xchg[(size_t)blockIdx.x * n + i] = acc;
-  }
-}
-__global__ __launch_bounds__(256) void stat_expand_kernel(float* __restrict__ slab, const float* __restrict__ xchg, int R, int n) {
-  float* s = slab + (size_t)blockIdx.x * R * n;
-  for (int t = threadIdx.x; t < R * n; t += blockDim.x) s[t] = t < n ? xchg[(size_t)blockIdx.x * n + t] : 0.f;
-}
-}  // namespace
-extern "C" int gwtf_stat_compact(const float* slab, float* xchg, int K, int n, void* stream) {
-  if (!slab || !xchg || K <= 0 || n <= 0) return GWTF_E_BADARG;
-  hipLaunchKernelGGL(stat_compact_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, slab, xchg, GWTF_STAT_REPLICAS, n);
-  return (int)hipGetLastError();
-}
-extern "C" int gwtf_stat_expand(float* slab, const float* xchg, int K, int n, void* stream) {
-  if (!slab || !xchg || K <= 0 || n <= 0) return GWTF_E_BADARG;
-  hipLaunchKernelGGL(stat_expand_kernel, dim3(K), dim3(256), 0, (hipStream_t)stream, slab, xchg, GWTF_STAT_REPLICAS, n);
-  return (int)hipGetLastError();
-}
-
 // which half of xbuf / g_bufs holds the final coordinates / dL/dp of component k: base + half * K*B*3*N + k * B*3*N
 extern "C" int gwtf_mtrain_final_forward_half(int C) { return (C - 1) & 1; }
 extern "C" int gwtf_mtrain_final_backward_half(int C, int mode) { return (mode == GWTF_MODE_INVERSE ? C - 1 : 0) & 1; }
@@ -934,19 +939,20 @@ extern "C" int gwtf_train_coupling_backward(const float* x_in, const float* g_ou
       (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE))
     return GWTF_E_BADARG;
   int rc = gwtf_internal_light_backward_k(x_in, g_out, g_ld, packed_w_c, film_rec, g_film, g_bias, c, 1, B, N, f, pattern0, eps,
-                                          mode, ks, nullptr, nullptr, stream);
+                                          mode, ks, nullptr, nullptr, GwtfCombine{}, stream);
   if (rc) return rc;
   hipLaunchKernelGGL(fold1_bwd_kernel, dim3(2, FP / 16, 1), dim3(kF1Slices * 16), 0, st, raw_c, ystats_c, n_total, film_raw, g_film,
-                     g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks);
+                     g_bias, g_film_raw, g_raw_c, g_stats, c, B, C, f, G, FP, ks, GWTF_STAT_REPLICAS);
   rc = gwtf_internal_merged_backward_k(x_in, g_out, g_ld, packed_w_c, packed_b_c, film_rec, g_stats, g_xa, dw1_ws, g_sd0, c, 1, B,
-                                       N, f, pattern0, eps, mode, ks, nullptr, nullptr, stream);
+                                       N, f, pattern0, eps, mode, ks, nullptr, nullptr, GwtfCombine{}, stream);
   if (rc) return rc;
-  double* part = reinterpret_cast<double*>(g_mom);          // [2][FP/16][5] doubles of scratch (<= 80 floats)
+  hipError_t me = hipMemsetAsync(g_mom, 0, 16 * sizeof(float), st);   // the nine moment gradients gM, accumulated by the fold's blocks
+  if (me != hipSuccess) return (int)me;
   hipLaunchKernelGGL(fold0_bwd_kernel, dim3(2, FP / 16, 1), dim3(kF1Slices * 16), 0, st, raw_c, moments_c, n_total, pat, g_sd0,
-                     g_raw_c, part, f, G, FP, ks);
+                     g_raw_c, g_mom, f, G, FP, ks, GWTF_STAT_REPLICAS);
   const int bx = (N + 255) / 256;
   hipLaunchKernelGGL(combine_kernel, dim3(bx < 64 ? bx : 64, B, 1), dim3(256), 0, st, x_in, g_xa, static_cast<const float*>(nullptr),
-                     moments_c, part, 2 * (FP / 16), n_total, pat, g_in, B, N, ks);
+                     g_mom, g_in, B, N, ks);
   const GwtfRaw R(f, G);
   return gwtf_dw1_reduce(dw1_ws, 1, g_raw_c + R.sd1_w(), R.branch_size(), f, B, N, stream);
 }

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWTF_ABI_VERSION 2
+#define GWTF_ABI_VERSION 3
 #define GWTF_E_BADARG 10001   /* shape / mode / width outside what the kernels support */
 #define GWTF_E_UNSUPPORTED 10002   /* a layer-width list no kernel instantiation was built for */
 #define GWTF_MODE_DIRECT 0    /* sampling direction  base -> data (reference models.py:202) */
@@ -195,15 +195,15 @@ int gwtf_train_coupling_backward(const float* x_in, const float* g_out, const fl
                                  int c, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
                                  void* stream);
 
-/* Backward of the whole single-rank train-mode stack: gwtf_train_coupling_backward for every coupling in reverse order
- * (host loop in the library: one call per decoder instead of C).  Array layouts at the definition (csrc/gwtf_train.hip);
- * *final_buf = which half of g_bufs [2][B][3][N] holds dL/dp. */
+/* Backward of the whole single-rank train-mode stack (the K = 1 case of gwtf_mtrain_backward: host loop in the library, one call
+ * per decoder).  Array layouts at GwtfTrainCtx; *final_buf = which half of g_bufs [2][B][3][N] holds dL/dp.  g_xa / g_xb are no
+ * longer written (the gradient combine is applied on the fly by the next level's passes); the arguments stay. */
 int gwtf_train_backward(const float* p, const float* ps, const float* g_out, const float* g_ld, const float* raw,
                         const float* packed_w, const float* packed_b, const float* film_rec, const float* film_raw,
-                        const float* moments, const float* ystats, float* g_bufs, float* g_xa, float* g_xb, float* dw1_ws,
-                        float* g_film, float* g_sd0, float* g_bias, float* g_stats, float* g_mom, float* g_film_raw,
-                        float* g_raw, int* final_buf, int B, int N, int C, int f, int G, int pattern0, float eps, int mode,
-                        void* stream);
+                        const float* moments, const float* ystats, float* g_bufs, float* g_xa, float* g_xb,
+                        float* dw1_ws /*gwtf_mtrain_dw1_floats(f, B, N)*/, float* g_film, float* g_sd0, float* g_bias, float* g_stats,
+                        float* g_mom /*[C][16] zero*/, float* g_film_raw, float* g_raw, int* final_buf, int B, int N, int C, int f, int G,
+                        int pattern0, float eps, int mode, void* stream);
 
 /* ---- K-batched, phase-split train pipeline (round 2) -------------------------------------------------------------------
  * All K components of a flow mixture (reference flow_mixture.py:163-166: a Python loop over self.pc_decoder) run through
@@ -232,8 +232,13 @@ typedef struct GwtfTrainCtx {
   float* packed_b;           /* [K][C][packed_b]     from gwtf_pack_w1t; fold0 fills the sd0 sections; NULL: no backward */
   const float* film_raw;     /* [B][K*C][2][2][FP]   raw FiLM {a, b} per shape (batch-statistic FiLM BatchNorm applied) */
   float* film_rec;           /* [B][K*C][gwtf_film_out_floats]  written by fold1, read by apply and the backward */
-  float* moments;            /* [C+1][K][R*16]       zero */
+  float* moments;            /* [C+1][K][R*16]       zero: the R = 64 copies the passes' statistic atomics are spread over */
   float* ystats;             /* [C][K][R*2*FP*2]     zero */
+  float* mom_c;              /* [C+1][K][16] or NULL COMPACT moments (9 used) of every level's input: data-parallel runs -- each forward
+                              *                       phase then ends with one launch that sums the copies into it, the caller all-reduces
+                              *                       it, and every consumer (folds, backward) reads it instead of the copies.
+                              *                       Level 0 (the shared input clouds): record [0][0] only */
+  float* ys_c;               /* [C][K][2*FP*2] or NULL (both or neither): COMPACT {sum y, sum y^2} per branch and feature, likewise */
   float* bn_batch;           /* [K][C][2][4][2][f]   batch {mean, unbiased var} of sd0_bn (kind 0) and sd1_bn (kind 1) */
   float* xbuf;               /* [2][K][B][3][N]      ping-pong coordinates; result in half gwtf_mtrain_final_forward_half(C) */
   float* logdet;             /* [K][B][3][N] */
@@ -244,13 +249,13 @@ typedef struct GwtfTrainCtx {
   const float* g_ps;         /* [K][C][B][3][N] or NULL: dL/d ps[c], gradients entering through the per-coupling list slots */
   const float* g_lvs;        /* [K][C][B][3][N] or NULL: dL/d logvars[c] */
   float* g_bufs;             /* [2][K][B][3][N]  dL/dp per component ends in half gwtf_mtrain_final_backward_half(C, mode) */
-  float* g_xa; float* g_xb;  /* [K][B][3][N] scratch (g_xb: unused since the merged backward pass, kept for layout stability) */
+  float* g_xa; float* g_xb;  /* unused (the gradient combine runs inside the next level's passes); kept for layout stability, may be NULL */
   float* dw1_ws;             /* [K][gwtf_mtrain_dw1_floats(f, B, N)] scratch */
   float* g_film;             /* [B][K*C][2][3][FP]   zero */
   float* g_sd0;              /* [C][K][R*2*3*FP]     zero */
   float* g_bias;             /* [C][K][R*4]          zero */
   float* g_stats;            /* [C][K][2*2*FP] */
-  float* g_mom;              /* [C][K][96]  (8-byte aligned; 48 doubles per component and level) */
+  float* g_mom;              /* [C][K][16]  zero: the nine moment gradients gM of every level (summed by atomics; all-reduced when data parallel) */
   float* g_film_raw;         /* [B][K*C][2][2][FP]   dL/d film_raw */
   float* g_raw;              /* [K][C][raw record]   zero; receives dW0, dgamma0, dbeta0, dW1, dW2, db2 */
   void* stream;
@@ -262,11 +267,6 @@ int gwtf_bn_running_update(const unsigned long long* table, const float* src, co
 /* dst[offset_i .. + numel_i) = src_i for n small tensors in one launch: table [n][3] = {src device pointer, offset, numel}
  * (floats).  Builds a stack's raw arena from its parameter / buffer tensors (the host mirror's torch.cat, one launch). */
 int gwtf_gather_table(const unsigned long long* table, float* dst, int n, void* stream);
-/* A replicated forward-statistic slab [K][64 copies][n] (moments: n = 16; ystats: n = 2*FP*2) <-> a contiguous exchange buffer
- * xchg [K][n] holding the sum over the copies: what a data-parallel run all-reduces between two phases (64 x less on the wire).
- * gwtf_stat_expand writes xchg back as copy 0 and zeroes the other copies. */
-int gwtf_stat_compact(const float* slab, float* xchg, int K, int n, void* stream);
-int gwtf_stat_expand(float* slab, const float* xchg, int K, int n, void* stream);
 size_t gwtf_mtrain_dw1_floats(int f, int B, int N);
 int gwtf_mtrain_phase(const GwtfTrainCtx* ctx, int phase, int step);
 int gwtf_mtrain_forward(const GwtfTrainCtx* ctx);

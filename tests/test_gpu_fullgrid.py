@@ -133,3 +133,4 @@ def test_train_mode_forward_at_airplane_grid_every_shape_every_component():
     z64, ld64, z32, ld32 = (np.stack(t) for t in (z64, ld64, z32, ld32))
     _bounds(f'train_forward:K{K}_f{f}_{B}x{N}_inverse', hz, hld, z64, ld64, z32, ld32, 3 * L, extra={'running_stats_rel': rv_err})
     assert rv_err < 1e-4, rv_err
+
