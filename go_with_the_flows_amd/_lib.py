@@ -96,6 +96,9 @@ _SIGNATURES = {
     'gwtf_bn_running_update': (ctypes.c_int, [_c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_gather_table': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_mtrain_dw1_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
+    'gwtf_film_heads_slices': (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    'gwtf_film_heads_forward': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
+    'gwtf_film_heads_backward': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_int, _c_fp]),
     'gwtf_mtrain_phase': (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]),
     'gwtf_mtrain_forward': (ctypes.c_int, [ctypes.c_void_p]),
     'gwtf_mtrain_backward': (ctypes.c_int, [ctypes.c_void_p]),
@@ -204,10 +207,17 @@ def padded_width(f):
     return lib().gwtf_padded_width(f)
 
 
-def pack_weights(raw, C, f, G, training, pattern0=0, K=1):
-    """Packed stack / FiLM weights of K concatenated stacks of C couplings each (raw: K*C coupling records)."""
+def pack_weights(raw, C, f, G, training, pattern0=0, K=1, stack_only=False):
+    """Packed stack / FiLM weights of K concatenated stacks of C couplings each (raw: K*C coupling records).  stack_only (train
+    pipeline): the stack weights alone -- its FiLM heads read the raw arena in place; returns (pw, None)."""
     L = lib()
     pw = torch.empty(K * C * L.gwtf_packed_w_coupling_floats(f), device=raw.device, dtype=torch.float32)
+    if stack_only:
+        if raw.numel() != K * C * L.gwtf_raw_coupling_floats(f, G):
+            raise GwtfError(f'raw arena has {raw.numel()} floats, expected {K * C * L.gwtf_raw_coupling_floats(f, G)}')
+        with torch.cuda.device(raw.device):
+            check(L.gwtf_pack_weights_k(_ptr(raw, 'raw'), _ptr(pw, 'packed_w'), None, K, C, f, G, int(pattern0), 2, _stream(raw)))
+        return pw, None
     pf = torch.empty(K * C * L.gwtf_packed_film_coupling_floats(f, G), device=raw.device, dtype=torch.float32)
     if raw.numel() != K * C * L.gwtf_raw_coupling_floats(f, G):
         raise GwtfError(f'raw arena has {raw.numel()} floats, expected {K * C * L.gwtf_raw_coupling_floats(f, G)}')

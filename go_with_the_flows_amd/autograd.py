@@ -405,6 +405,55 @@ def _film_train(P, g, eps):
     return a, o[:, :, :, 1], mean.detach(), (var * (Bn / max(Bn - 1.0, 1.0))).detach()
 
 
+class FilmHeadsFn(torch.autograd.Function):
+    """The FiLM heads of KC couplings (all K stacks of a mixture at once) in HIP, forward and backward (csrc/gwtf_film_train.hip;
+    reference flows.py:33-45, 68-80, 100-106).  raw: the (stacked) raw arena holding KC coupling records; g_all (B_all, G): the latent
+    rows BatchNorm sees (all ranks' rows when data parallel); rows [row0, row0 + B) are this rank's shapes.
+    -> film_raw (B, KC, 2, 2, FP) = {a = eps + exp(scale head), b = shift head} per branch, zero beyond the f valid columns (the
+    train pipeline's record); batch mean / biased variance of the heads' BatchNorm (KC, 2, 2, f) (training) or its running ones."""
+
+    @staticmethod
+    def forward(ctx, raw, g_all, KC, f, G, row0, B, eps, training):
+        L = _lib.lib()
+        raw, g_all = raw.contiguous(), g_all.contiguous().float()
+        dev = raw.device
+        Ball, H, FP = g_all.shape[0], 4 * KC, L.gwtf_padded_width(f)
+        if Ball > 128 or raw.numel() != KC * L.gwtf_raw_coupling_floats(f, G):
+            raise _lib.GwtfError(f'FilmHeadsFn: {Ball} latent rows (limit 128) / arena of {raw.numel()} floats for {KC} couplings')
+        poison = branch_poison(raw, KC).contiguous()
+        hraw = torch.empty(Ball, H, f, device=dev, dtype=torch.float32)
+        hn = torch.empty_like(hraw)
+        stats = torch.empty(3, H, f, device=dev, dtype=torch.float32)
+        film_raw = torch.zeros(B, KC, 2, 2, FP, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.gwtf_film_heads_forward(raw.data_ptr(), g_all.data_ptr(), poison.data_ptr(), hraw.data_ptr(), hn.data_ptr(),
+                                                 stats.data_ptr(), film_raw.data_ptr(), KC, f, G, Ball, row0, B, float(eps),
+                                                 1 if training else 0, _lib._stream(raw)))
+        ctx.save_for_backward(raw, g_all, hraw, hn, stats, film_raw)
+        ctx.meta = (KC, f, G, row0, B, float(eps), bool(training))
+        mean, var = stats[0].view(KC, 2, 2, f), stats[1].view(KC, 2, 2, f)
+        ctx.mark_non_differentiable(mean, var)
+        return film_raw, mean, var
+
+    @staticmethod
+    def backward(ctx, g_film_raw, _gm, _gv):
+        raw, g_all, hraw, hn, stats, film_raw = ctx.saved_tensors
+        KC, f, G, row0, B, eps, training = ctx.meta
+        L = _lib.lib()
+        dev = raw.device
+        Ball = g_all.shape[0]
+        g_film_raw = g_film_raw.contiguous().float()
+        g_raw = torch.zeros_like(raw)
+        dhraw = torch.empty_like(hraw)
+        dg_part = torch.empty(L.gwtf_film_heads_slices(KC, G), Ball, G, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(L.gwtf_film_heads_backward(raw.data_ptr(), g_all.data_ptr(), hraw.data_ptr(), hn.data_ptr(), stats.data_ptr(),
+                                                  film_raw.data_ptr(), g_film_raw.data_ptr(), g_raw.data_ptr(), dhraw.data_ptr(),
+                                                  dg_part.data_ptr(), KC, f, G, Ball, row0, B, eps, 1 if training else 0,
+                                                  _lib._stream(raw)))
+        return g_raw, dg_part.sum(0), None, None, None, None, None, None, None
+
+
 class _AllReduceSum(torch.autograd.Function):
     """Sum over the ranks of the data-parallel group, in both directions: forward all-reduces the statistic,
     backward all-reduces its gradient (every rank's loss depends on every rank's points through the batch
@@ -530,11 +579,12 @@ def _stat_sum(t):
 
 class TrainMixtureFn(torch.autograd.Function):
     """out, logdet (K,B,3,N), lists (3,K,C,B,3,N), bn_batch (K,C,2,4,2,f) of K stacks with batch-statistic BatchNorm.
-    raw (K, C*R): the stacks' raw arenas; a, bsh (B, K*C, 2, f): raw FiLM scale / shift of this rank's shapes.
-    n_total: number of points the statistics cover over all ranks; sharded: statistics are all-reduced between phases."""
+    raw (K, C*R): the stacks' raw arenas; film_raw (B, K*C, 2, 2, FP): raw FiLM {scale a, shift b} of this rank's shapes, zero
+    beyond the f valid columns (FilmHeadsFn).  n_total: number of points the statistics cover over all ranks; sharded: statistics
+    are all-reduced between phases."""
 
     @staticmethod
-    def forward(ctx, p, raw, a, bsh, K, C, f, G, pattern0, eps, mode, n_total, sharded, want_lists=True):
+    def forward(ctx, p, raw, film_raw, K, C, f, G, pattern0, eps, mode, n_total, sharded, want_lists=True):
         L = _lib.lib()
         p, raw = p.contiguous(), raw.contiguous()
         B, _, N = p.shape
@@ -544,11 +594,10 @@ class TrainMixtureFn(torch.autograd.Function):
         R = _lib.STAT_REPLICAS
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
         zeros = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
-        film_raw = zeros(B, K * C, 2, 2, FP)
-        film_raw[:, :, :, 0, :f] = a
-        film_raw[:, :, :, 1, :f] = bsh
+        film_raw = film_raw.contiguous()
+        assert film_raw.shape == (B, K * C, 2, 2, FP), film_raw.shape
         with torch.cuda.device(dev):
-            pw, _pf = _lib.pack_weights(raw.view(-1), C, f, G, True, pattern0, K=K)
+            pw, _ = _lib.pack_weights(raw.view(-1), C, f, G, True, pattern0, K=K, stack_only=True)
             pb = zeros(K * C * PB)
             _lib.check(L.gwtf_pack_w1t(raw.data_ptr(), pb.data_ptr(), K * C, f, G, _lib._stream(p)))
         t = _lib.TrainCtx()
@@ -649,8 +698,7 @@ class TrainMixtureFn(torch.autograd.Function):
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_BWD_C, step))
         dp = bufs['g_bufs'][L.gwtf_mtrain_final_backward_half(C, _lib._MODES[mode])]
         dp = dp[0] if K == 1 else dp.sum(0)                    # the K components read the same clouds
-        gfr = bufs['g_film_raw']
-        return (dp, bufs["g_raw"], gfr[:, :, :, 0, :f], gfr[:, :, :, 1, :f]) + (None,) * 10
+        return (dp, bufs["g_raw"], bufs['g_film_raw']) + (None,) * 10
 
 
 def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False, want_lists=True):
@@ -674,9 +722,12 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
         raise ValueError('train-mode BatchNorm needs more than 1 shape per (global) batch (torch raises the same)')
     from .flows import stacked_raw_arena
     raw = stacked_raw_arena(engines)                          # (K, R): one gather launch, one autograd node
-    # the FiLM heads of all K stacks in ONE set of batched products: views of the stacked arena, K*C couplings
-    film_a, film_b, film_mean, film_var = _film_train(_gather_film(raw, K * C, f, G), g_all, eps)
-    a, bsh = film_a[row0:row0 + B], film_b[row0:row0 + B]                # (B, K*C, 2, f)
+    # the FiLM heads of all K stacks (4 K C small MLPs, BatchNorm over the latent rows of ALL ranks): one HIP launch forward, two
+    # backward, parameters read from / gradients written into the stacked arena in place (csrc/gwtf_film_train.hip)
+    if rows_total > 128:
+        raise _lib.GwtfError(f'train-mode FiLM heads: {rows_total} latent rows in the (global) batch, the kernels take up to 128')
+    film_raw, film_mean, film_var = FilmHeadsFn.apply(raw, g_all, K * C, f, G, row0, B, eps, True)
+    film_var = film_var * (rows_total / max(rows_total - 1.0, 1.0))      # unbiased, as BatchNorm's running_var update takes it
     if raw.requires_grad:
         # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
         # the FiLM heads' part, summed by autograd): hand it to the data-parallel reducer (dist.OverlappedGradients, looked up
@@ -687,7 +738,7 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
                 for k, e in enumerate(engines):
                     sink.on_flat_gradient(grad[k], e)
         raw.register_hook(_to_reducer)
-    out, logdet, ps, mus, lvs, bn_batch = TrainMixtureFn.apply(p.float(), raw, a, bsh, K, C, f, G, e0.pattern0, eps, mode,
+    out, logdet, ps, mus, lvs, bn_batch = TrainMixtureFn.apply(p.float(), raw, film_raw, K, C, f, G, e0.pattern0, eps, mode,
                                                                float(rows_total) * N, distributed, want_lists)
     lists = (ps, mus, lvs) if want_lists else None           # (K,C,B,3,N) each; ps / lvs differentiable
     bn_batch = bn_batch.clone()

@@ -111,7 +111,7 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, const float* __rest
       __half2 pk = __floats2half2_rn(0.f, 0.f);
       if (ks < KS && jo < f) {
         const float* ex = pf + ((size_t)c * 2 + br) * PF.branch_size();     // range-scaling exponents (pack_scales_kernel)
-        const int rs = (int)ex[PF.rs() + jo];
+        const int rs = training ? 0 : (int)ex[PF.rs() + jo];       // train packing: no range scaling (batch statistics normalise)
         const float sc = training ? 1.0f : inv_std(rb[R.bn1() + f + jo]);   // train: sd1_bn is applied via fold1
         const GwtfA16Slot sl = gwtf_a16_slot(f, KS, ks, part, jp);   // f = 33..40: merged image of the short k-step
         const bool absf = gwtf_abs_form(f);                          // ... in abs form: every entry halved, columns in the last pair
@@ -119,7 +119,7 @@ __global__ void pack_w_kernel(const float* __restrict__ raw, const float* __rest
         for (int t = 0; t < 2; ++t) {
           const int ji = 32 * ks + 4 * (2 * sl.jsrc + t) + (lane >> 4);  // input feature
           float w = 0.f;
-          if (ji < f && !sl.zero) w = ldexpf(rb[R.sd1_w() + (size_t)jo * f + ji] * sc, (int)ex[PF.cs() + ji] - rs - (absf ? 1 : 0));
+          if (ji < f && !sl.zero) w = ldexpf(rb[R.sd1_w() + (size_t)jo * f + ji] * sc, (training ? 0 : (int)ex[PF.cs() + ji]) - rs - (absf ? 1 : 0));
           const float hi = __half2float(__float2half_rn(w));
           e[t] = sl.lo ? (w - hi) : hi;
         }
@@ -214,19 +214,24 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
 extern "C" int gwtf_pack_weights_k(const float* raw, float* packed_w, float* packed_film, int K, int Cper, int f, int G,
                                    int pattern0, int training, void* stream) {
   const int C = K * Cper;
-  if (K <= 0 || Cper <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_w || !packed_film || pattern0 < 0 || pattern0 > 5)
+  // training == 2: the train pipeline's packing -- the stack weights only (its FiLM heads read the raw arena in place,
+  // csrc/gwtf_film_train.hip; no range-scaling exponents in train mode): packed_film may be NULL
+  const bool stack_only = training == 2;
+  if (K <= 0 || Cper <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_w || (!packed_film && !stack_only) || pattern0 < 0 ||
+      pattern0 > 5)
     return GWTF_E_BADARG;
   const int FP = gwtf_padded_width(f);
   hipStream_t st = (hipStream_t)stream;
   const int threads = 256;
-  hipLaunchKernelGGL(pack_scales_kernel, dim3(2 * C), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training, pattern0, Cper);
+  if (!stack_only)
+    hipLaunchKernelGGL(pack_scales_kernel, dim3(2 * C), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training, pattern0, Cper);
   {
     const size_t total = GwtfPackW(FP).coupling_size() * (size_t)C;
     const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
     hipLaunchKernelGGL(pack_w_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_film, packed_w, C, f, G, FP, training,
                        pattern0, Cper);
   }
-  {
+  if (!stack_only) {
     const size_t total = GwtfPackF(FP, G).coupling_size() * (size_t)C;
     const int blocks = (int)((total + threads - 1) / threads < 2048 ? (total + threads - 1) / threads : 2048);
     hipLaunchKernelGGL(pack_film_kernel, dim3(blocks), dim3(threads), 0, st, raw, packed_film, C, f, G, FP, training);

@@ -135,7 +135,11 @@ class _EncoderTrainFn(torch.autograd.Function):
             check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), 3, n_total, P(gam[3]), P(aff[3]), 0, 0, P(bconst), st))
             s3, q3, r3 = (bconst[i * C[4]:(i + 1) * C[4]] for i in range(3))
             W3 = Ws[3]
-            M = (W3 * q3[:, None]).t() @ W3                                        # (256, 256), symmetric
+            # M = W3^T diag(q3) W3 (256 x 256, symmetric).  As ONE product the library picks a single 256 x 256 macro tile -- one
+            # workgroup on one compute unit, 122 us for 67 MFLOP; cut along the 512-long contraction into 16 batched products it is
+            # 16 workgroups + one small sum (measured inside the train step: ~15 us).
+            W3q = (W3 * q3[:, None]).view(16, C[4] // 16, C[3])
+            M = torch.bmm(W3q.transpose(1, 2), W3.reshape(16, C[4] // 16, C[3])).sum(0)
             k = 8.0 - torch.floor(torch.log2(M.abs().max().clamp_min(1e-37)))      # power-of-two operand scale, on the device
             units_m = torch.empty(L.gwtf_enc_train_units_floats(3) // 2, **f32)
             check(L.gwtf_enc_train_pack_matrix(P((M * torch.exp2(k)).contiguous()), P(units_m), C[3], C[3], st))

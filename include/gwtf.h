@@ -63,7 +63,8 @@ size_t gwtf_film_out_floats(int f);                   /* FiLM output per (shape,
 int gwtf_pack_weights(const float* raw, float* packed_w, float* packed_film,
                       int C, int f, int G, int pattern0, int training, void* stream);
 /* The same for K concatenated stacks of Cper couplings each (the components of a mixture): raw [K][Cper][...], every stack
- * starts again at warp pattern `pattern0`. */
+ * starts again at warp pattern `pattern0`.  training = 2: the train pipeline's packing -- packed_w only (train form), packed_film
+ * may be NULL: its FiLM heads read the raw arena in place (gwtf_film_heads_forward). */
 int gwtf_pack_weights_k(const float* raw, float* packed_w, float* packed_film,
                         int K, int Cper, int f, int G, int pattern0, int training, void* stream);
 
@@ -204,6 +205,26 @@ int gwtf_train_backward(const float* p, const float* ps, const float* g_out, con
                         float* dw1_ws /*gwtf_mtrain_dw1_floats(f, B, N)*/, float* g_film, float* g_sd0, float* g_bias, float* g_stats,
                         float* g_mom /*[C][16] zero*/, float* g_film_raw, float* g_raw, int* final_buf, int B, int N, int C, int f, int G,
                         int pattern0, float eps, int mode, void* stream);
+
+/* ---- FiLM conditioning heads under autograd (csrc/gwtf_film_train.hip) -----------------------------------------------------
+ * Replaces T_*_0_cond_w / T_*_0_cond_b of every coupling (reference lib/networks/flows.py:33-45, 68-80, evaluated at :100-101,
+ * 105-106): Linear(G -> f) -> BatchNorm1d over the latent rows -> Swish -> Linear(f -> f); a = eps + exp(scale head), b = shift head.
+ * H = 4 KC heads (KC couplings in all: K stacks x C), one workgroup per head, parameters read in place from the raw arena
+ * [KC][raw coupling record]; training = 1: batch statistics over the B_all rows (<= 128; all ranks' rows when data parallel),
+ * 0: the arena's running statistics.
+ *   g [B_all][G]; poison [KC][2] (0 or NaN, added to the scale a: diverged weights reach every output) or NULL
+ *   hraw, hn [B_all][H][f] (pre-BatchNorm / post-Swish activations, kept for the backward); stats [3][H][f] = mean, biased var, rstd
+ *   film_raw [B][KC][2][2][FP] (rows row0 .. row0 + B of g): {a, b} per branch, the train pipeline's GwtfTrainCtx.film_raw; only the
+ *   f valid columns are written (zero the buffer first).
+ * Backward: g_film_raw = dL/d film_raw -> g_raw: every FiLM parameter's gradient written (=) at its arena offset (other slots
+ * untouched); dhraw [B_all][H][f] scratch; dg_part [gwtf_film_heads_slices(KC, G)][B_all][G]: partial dL/dg, summed by the caller. */
+int gwtf_film_heads_slices(int KC, int G);
+int gwtf_film_heads_forward(const float* raw, const float* g, const float* poison, float* hraw, float* hn, float* stats,
+                            float* film_raw, int KC, int f, int G, int B_all, int row0, int B, float eps, int training,
+                            void* stream);
+int gwtf_film_heads_backward(const float* raw, const float* g, const float* hraw, const float* hn, const float* stats,
+                             const float* film_raw, const float* g_film_raw, float* g_raw, float* dhraw, float* dg_part,
+                             int KC, int f, int G, int B_all, int row0, int B, float eps, int training, void* stream);
 
 /* ---- K-batched, phase-split train pipeline (round 2) -------------------------------------------------------------------
  * All K components of a flow mixture (reference flow_mixture.py:163-166: a Python loop over self.pc_decoder) run through
