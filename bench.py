@@ -121,12 +121,17 @@ def _run_bench_train(extra_args, env, timeout=200, graph=True, steps=20):
                            cwd=here, env=env, capture_output=True, text=True, timeout=timeout)
     except Exception as e:      # a secondary figure must never cost the headline line
         return {'error': repr(e)[:300]}
-    ms = {l.split(':')[0].strip(): float(l.split(':')[1].split('ms/step')[0]) for l in r.stdout.splitlines() if 'ms/step' in l}
-    for l in r.stdout.splitlines():
-        if l.startswith('statistic all-reduces captured in the graph:'):
-            ms['collectives'] = int(l.split(':')[1])
     if r.returncode != 0:
         return {'error': (r.stderr or r.stdout)[-300:]}
+    try:
+        ms = {l.split(':')[0].strip(): float(l.split(':')[1].split('ms/step')[0]) for l in r.stdout.splitlines() if 'ms/step' in l}
+        for l in r.stdout.splitlines():
+            if l.startswith('statistic all-reduces captured in the graph:'):
+                ms['collectives'] = int(l.split(':')[1])
+            if l.startswith('per-shape modules:'):
+                ms['per_shape_modules'] = l.split(':', 1)[1].strip()
+    except (ValueError, IndexError) as e:
+        return {'error': f'unparsable bench_train output: {e!r}'[:300]}
     ms['rc'] = 0
     return ms
 
@@ -155,7 +160,7 @@ def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backen
         ms = _run_bench_train(['--api', 'both'], base_env, steps=steps)
         if 'hipGraph' not in ms:
             return ms if 'error' in ms else {'error': 'no hipGraph line'}
-        rec = {'ms_per_step': ms['hipGraph'], 'eager_ms_per_step': ms.get('eager'), 'steps': steps,
+        rec = {'ms_per_step': ms['hipGraph'], 'eager_ms_per_step': ms.get('eager'), 'steps': steps, 'per_shape_modules': ms.get('per_shape_modules'),
                'list_api_ms_per_step': ms.get('hipGraph list API'),        # the reference's own call: model(g, p) -> lists -> loss
                'workload': wl + ', B=64'}
         sh = _run_bench_train([], dict(base_env, GWTF_FORCE_SHARDED='1'), steps=steps)
@@ -189,7 +194,7 @@ def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backen
             break
         if rank == 0:
             rec[label] = {'ms_per_step': ms[key], 'eager_ms_per_step': ms.get('eager'), 'per_rank_batch': per_rank,
-                          'statistic_all_reduces_in_graph': ms.get('collectives'), 'graphed': graph,
+                          'statistic_all_reduces_in_graph': ms.get('collectives'), 'graphed': graph, 'per_shape_modules': ms.get('per_shape_modules'),
                           'shapes_per_s': round(per_rank * world / ms[key] * 1e3, 1)}
     return rec
 

@@ -270,6 +270,8 @@ def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segment
         raise GwtfError(f'p must be (B,3,N), got {tuple(p.shape)}')
     if film.shape[0] != B or film.shape[1] != K * C:
         raise GwtfError(f'film is {tuple(film.shape)}, expected ({B},{K * C},...)')
+    if (out is None) != (logdet is None):
+        raise GwtfError('stack_forward_multi: pass out and logdet together (both preallocated) or neither')
     seg = None
     if segments is not None:
         flat = [int(v) for be in segments for v in be]

@@ -724,10 +724,14 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
     raw = stacked_raw_arena(engines)                          # (K, R): one gather launch, one autograd node
     # the FiLM heads of all K stacks (4 K C small MLPs, BatchNorm over the latent rows of ALL ranks): one HIP launch forward, two
     # backward, parameters read from / gradients written into the stacked arena in place (csrc/gwtf_film_train.hip)
-    if rows_total > 128:
-        raise _lib.GwtfError(f'train-mode FiLM heads: {rows_total} latent rows in the (global) batch, the kernels take up to 128')
-    film_raw, film_mean, film_var = FilmHeadsFn.apply(raw, g_all, K * C, f, G, row0, B, eps, True)
-    film_var = film_var * (rows_total / max(rows_total - 1.0, 1.0))      # unbiased, as BatchNorm's running_var update takes it
+    if rows_total <= 128:
+        film_raw, film_mean, film_var = FilmHeadsFn.apply(raw, g_all, K * C, f, G, row0, B, eps, True)
+        film_var = film_var * (rows_total / max(rows_total - 1.0, 1.0))  # unbiased, as BatchNorm's running_var update takes it
+    else:
+        # more than 128 latent rows in the (global) batch: the heads as batched library products on views of the arena
+        film_a, film_b, film_mean, film_var = _film_train(_gather_film(raw, K * C, f, G), g_all, eps)
+        FP = _lib.lib().gwtf_padded_width(f)
+        film_raw = F.pad(torch.stack([film_a[row0:row0 + B], film_b[row0:row0 + B]], dim=3), (0, FP - f))   # (B, K*C, 2, 2, FP)
     if raw.requires_grad:
         # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
         # the FiLM heads' part, summed by autograd): hand it to the data-parallel reducer (dist.OverlappedGradients, looked up

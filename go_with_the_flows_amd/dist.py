@@ -56,7 +56,10 @@ def quiesce_for_capture(device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and torch.cuda.is_available():
         import time
         torch.cuda.synchronize(device)
-        time.sleep(0.35)
+        # An ASSUMPTION about ProcessGroupNCCL's watchdog (its polling period is ~100 ms in this torch build and it retires a finished
+        # work item on the next poll): GWTF_CAPTURE_QUIESCE_S overrides the wait for other builds / loaded hosts.  The primary
+        # protection stays capture_mode() = 'thread_local'; keep no asynchronous Work object alive across the capture.
+        time.sleep(float(os.environ.get('GWTF_CAPTURE_QUIESCE_S', '0.35')))
 
 
 def graph_capture(graph, device=None, **kwargs):
@@ -249,6 +252,45 @@ def all_reduce_gradients(module, average=True, force=False, algorithm='ring'):
     return flat.numel()
 
 
+def sync_module_state(module, src=0, verify_only=False):
+    """Make every rank start from rank `src`'s model: broadcast all parameters and buffers (BatchNorm running statistics,
+    num_batches_tracked, eps).  DistributedDataParallel does this at construction (reference train_ae.py:153) and the reference
+    sets no seed, so without it ranks that built the model themselves -- or where only rank 0 loaded a checkpoint -- would
+    average the gradients of DIFFERENT models, silently.  One flat broadcast per dtype.  verify_only: change nothing, raise if a
+    rank's state differs from `src`'s (a checksum exchange).  No-op without a process group or on one rank.
+    Returns the number of elements broadcast / checked."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return 0
+    tensors = [p.data for p in module.parameters()] + [b for b in module.buffers()]
+    on_cpu = dist.get_backend() != 'nccl'
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    total = 0
+    for dtype in sorted(by_dtype, key=str):                   # the same order on every rank
+        group = by_dtype[dtype]
+        flat = torch.cat([t.detach().reshape(-1) for t in group])
+        wire = flat.cpu() if (on_cpu and flat.is_cuda) else flat.clone()
+        dist.broadcast(wire, src=src)
+        wire = wire.to(flat.device)
+        total += flat.numel()
+        if verify_only:
+            same = torch.equal(wire, flat) or bool(((wire == flat) | (torch.isnan(wire.float()) & torch.isnan(flat.float()))).all())
+            ok = torch.tensor([1 if same else 0], dtype=torch.int64, device=wire.device if not on_cpu else 'cpu')
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok) == 0:
+                raise RuntimeError(f"rank {dist.get_rank()}: the model's {dtype} state differs between the ranks "
+                                   f'(parameters / buffers not synchronised: call dist.sync_module_state(model) first)')
+            continue
+        with torch.no_grad():
+            torch._foreach_copy_(group, [v.view_as(t) for v, t in zip(wire.split_with_sizes([t.numel() for t in group]), group)])
+    if not verify_only:
+        for mod in module.modules():                           # every packed-weight cache is keyed on the tensors just overwritten
+            if hasattr(mod, 'invalidate_packed_weights'):
+                mod.invalidate_packed_weights()
+    return total
+
+
 _REDUCE_STREAMS = {}        # per device: the stream the overlapped gradient all-reduces are ordered on
 
 
@@ -271,10 +313,13 @@ class OverlappedGradients:
     hold a .grad are then reduced with the remainder, as accumulated totals (tests/dist_gpu_worker.py).
     """
 
-    def __init__(self, module, average=True):
+    def __init__(self, module, average=True, sync_state=True):
         self.module, self.average = module, average
         self.pending = []
         self.launched = 0          # asynchronous collectives launched from inside the backward pass (tests read it)
+        # every rank starts from rank 0's parameters AND buffers, as DistributedDataParallel's constructor guarantees
+        # (train_ae.py:153); sync_state=False: the caller has done it (verify with sync_module_state(verify_only=True))
+        self.synced = sync_module_state(module) if sync_state else 0
 
     def __enter__(self):
         from . import autograd

@@ -159,8 +159,6 @@ class GlobalRNVPDecoder(nn.Module):
         if mode not in ('direct', 'inverse'):
             raise ValueError(f"mode must be 'direct' or 'inverse', got {mode!r}")
         training = self.training
-        if training and g.shape[0] < 2:
-            raise ValueError('Expected more than 1 value per channel when training (BatchNorm over the batch)')
         eps = self.flows[0].nvp1._eps_value
         row0, rows = 0, g.shape[0]
         if self._syncs():
@@ -171,6 +169,8 @@ class GlobalRNVPDecoder(nn.Module):
             from .dist import gather_rows
             g, lay = gather_rows(g.contiguous().float())
             row0 = lay.row0
+        if training and g.shape[0] < 2:      # the (GLOBAL) batch BatchNorm sees: one local row is fine when other ranks hold more
+            raise ValueError('Expected more than 1 value per channel when training (BatchNorm over the batch)')
         gs, mus, lvs, stats = _PriorFlowFn.apply(g.contiguous().float(), self._raw_arena(), self.n_flows, self.n_features,
                                                  eps, mode, training)
         if g.shape[0] != rows:

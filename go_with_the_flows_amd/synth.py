@@ -10,8 +10,17 @@ import numpy as np
 import torch
 
 
-def synth_state(template_state, seed):
-    """template_state: mapping key -> tensor/array (only shapes/dtypes are used).  Returns numpy dict."""
+CONDITIONED_GAIN = 0.3   # output_gain of the well-conditioned state: a deep stack then maps 0.3 N(0,1) clouds to |z| of a few units
+
+
+def synth_state(template_state, seed, output_gain=1.0):
+    """template_state: mapping key -> tensor/array (only shapes/dtypes are used).  Returns numpy dict.
+    output_gain scales every coupling's output layer (sd2 weight and bias) AFTER the draw, so the random stream -- and every
+    golden fixture generated with the default -- is unchanged.  The default (1.0) is the bench / fixture state: O(1) log-dets per
+    coupling, which a 33-coupling inverse pass compounds to |z| ~ 5e3 on some points (fp32 evaluation is then ill-conditioned:
+    the stated ABSOLUTE tolerance is below fp32's own noise there).  CONDITIONED_GAIN gives what a trained model does -- clouds
+    mapped to a few units -- and is the state on which the absolute tolerance is asserted without reference to fp32 noise
+    (tests/test_gpu_fullgrid.py)."""
     rng = np.random.default_rng(seed)
     out = {}
     for key in template_state:  # insertion order of the module's state_dict: deterministic
@@ -41,7 +50,7 @@ def synth_state(template_state, seed):
             fan_in = shape[-1]
             v = rng.uniform(-1.0, 1.0, shape) * np.sqrt(3.0 / fan_in)
         elif name.endswith('sd2'):
-            v = rng.normal(0.0, 0.15, shape) if kind == 'weight' else rng.normal(0.0, 0.1, shape)
+            v = (rng.normal(0.0, 0.15, shape) if kind == 'weight' else rng.normal(0.0, 0.1, shape)) * output_gain
         elif name.endswith('film_w0') or name.endswith('film_b0'):
             v = rng.uniform(-1.0, 1.0, shape) / np.sqrt(shape[-1])
         elif name.endswith('film_w1') or name.endswith('film_b1') or name in ('mu_mlp0', 'logvar_mlp0', 'mu_mlp1', 'logvar_mlp1'):
@@ -52,9 +61,9 @@ def synth_state(template_state, seed):
     return out
 
 
-def load_synth_(module, seed):
+def load_synth_(module, seed, output_gain=1.0):
     """Overwrite ``module``'s parameters/buffers in place with ``synth_state``; returns the numpy state."""
-    st = synth_state(module.state_dict(), seed)
+    st = synth_state(module.state_dict(), seed, output_gain)
     module.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
     return st
 

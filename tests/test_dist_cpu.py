@@ -155,3 +155,41 @@ def _rows_worker(rank, world, port):
 def test_row_layout_and_gather_rows(world):
     port = 33500 + os.getpid() % 2000 + world
     mp.spawn(_rows_worker, args=(world, port), nprocs=world, join=True)
+
+
+def _state_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from go_with_the_flows_amd.dist import init_from_env, sync_module_state, OverlappedGradients
+    init_from_env('gloo')
+    torch.manual_seed(100 + rank)                       # the reference sets no seed: every rank builds a DIFFERENT model
+    net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.BatchNorm1d(7), torch.nn.Linear(7, 3))
+    net[1].running_mean.normal_()
+    net[1].num_batches_tracked += 3 + rank
+    mine = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [net[1].running_mean])
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    assert not torch.equal(gathered[0], gathered[1])    # they do start apart
+    try:
+        sync_module_state(net, verify_only=True)
+        raise AssertionError('a model mismatch between the ranks must be reported')
+    except RuntimeError as e:
+        assert 'differs between the ranks' in str(e)
+    red = OverlappedGradients(net)                      # the data-parallel wrapper synchronises at construction, like DDP
+    assert red.synced == sum(p.numel() for p in net.parameters()) + sum(b.numel() for b in net.buffers())
+    mine = torch.cat([p.detach().reshape(-1) for p in net.parameters()] + [net[1].running_mean, net[1].running_var,
+                                                                            net[1].num_batches_tracked.float().reshape(1)])
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    assert all(torch.equal(gathered[0], q) for q in gathered[1:])
+    assert int(net[1].num_batches_tracked) == 3          # rank 0's
+    sync_module_state(net, verify_only=True)            # and the check is silent now
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_data_parallel_wrapper_starts_every_rank_from_rank0_state(world):
+    """DistributedDataParallel broadcasts rank 0's parameters and buffers at construction (train_ae.py:153); the
+    reference sets no seed, so the hand-rolled reducer must do the same or ranks train different models with averaged gradients."""
+    port = 31500 + os.getpid() % 2000 + world
+    mp.spawn(_state_worker, args=(world, port), nprocs=world, join=True)

@@ -41,7 +41,7 @@ def _oracle(p, g, st, L, mode, dtype, training=False):
     return z.numpy(), ld.numpy()
 
 
-def _bounds(tag, hip_z, hip_ld, z64, ld64, z32, ld32, C, extra=None):
+def _bounds(tag, hip_z, hip_ld, z64, ld64, z32, ld32, C, extra=None, absolute=False):
     """Point-wise bar.  The stated tolerance grows with a coordinate's magnitude (conftest.tol_at_depth: rounding error is relative);
     bench.py's synthetic weights send some points of the inverse pass to |x| ~ 5e3, so it is applied PER POINT: error divided by
     max(1, |x|/6) (coordinates) / max(1, |x|/24) (log-det) of that point, against tol(C) = 2e-5 / 1e-5 * max(1, C/12).  Two
@@ -54,8 +54,17 @@ def _bounds(tag, hip_z, hip_ld, z64, ld64, z32, ld32, C, extra=None):
              hip_vs_fp64_coord_abs=float(np.abs(hip_z - z64).max()), fp32_vs_fp64_coord_abs=float(np.abs(z32 - z64).max()),
              xmax=float(mag.max()), **(extra or {}))
     e['tol_coord'], e['tol_logdet'] = tol_at_depth(C, 1.0)
-    record_parity('fullgrid:' + tag, **e)
+    if not absolute:
+        record_parity('fullgrid:' + tag, **e)
     assert np.isfinite(hip_z).all() and np.isfinite(hip_ld).all(), tag
+    if absolute:
+        # the well-conditioned state: the STATED tolerance at this depth and coordinate range, absolute, no reference to fp32 noise
+        ta, tl = tol_at_depth(C, e['xmax'])
+        e['abs_tol_coord'], e['abs_tol_logdet'] = ta, tl
+        e['hip_vs_fp64_logdet_abs'] = float(np.abs(hip_ld - ld64).max())
+        record_parity('fullgrid-conditioned:' + tag, **e)
+        assert e['hip_vs_fp64_coord_abs'] < ta and e['hip_vs_fp64_logdet_abs'] < tl, (tag, e)
+        return e
     assert e['hip_vs_fp64_coord'] < 3 * e['fp32_vs_fp64_coord'] + TOL_COORD / 4, (tag, e)
     assert e['hip_vs_fp64_logdet'] < 3 * e['fp32_vs_fp64_logdet'] + TOL_LOGDET / 4, (tag, e)
     assert e['hip_vs_fp64_coord'] < max(e['tol_coord'], 1.5 * e['fp32_vs_fp64_coord']), (tag, e)
@@ -63,8 +72,15 @@ def _bounds(tag, hip_z, hip_ld, z64, ld64, z32, ld32, C, extra=None):
     return e
 
 
+@pytest.mark.parametrize('state', ['bench', 'conditioned'])
 @pytest.mark.parametrize('name', sorted(bench.WORKLOADS))
-def test_bench_workload_every_shape_every_component_against_fp64_oracle(name):
+def test_bench_workload_every_shape_every_component_against_fp64_oracle(name, state):
+    """state 'bench': the synthetic weights bench.py times (per-point bar relative to the coordinate's magnitude, never further
+    from fp64 than the fp32 evaluation of the same function); 'conditioned': the same draw with the couplings' output layers scaled
+    by synth.CONDITIONED_GAIN, which keeps |z| at a few units as a trained model does -- there the stated ABSOLUTE tolerance
+    (conftest.tol_at_depth) must hold on every point of the full grid."""
+    from go_with_the_flows_amd.synth import CONDITIONED_GAIN
+    gain = 1.0 if state == 'bench' else CONDITIONED_GAIN
     cfg = bench.WORKLOADS[name]
     K, L, f, G, B, N, mode = (cfg[k] for k in ('K', 'L', 'f', 'G', 'B', 'N', 'mode'))
     _cpu_threads()
@@ -72,7 +88,7 @@ def test_bench_workload_every_shape_every_component_against_fp64_oracle(name):
     decs, states = [], []
     for k in range(K):                                           # bench.run_workload's construction, rank 0
         d = gw.LocalCondRNVPDecoder(L, f, G)
-        states.append(load_synth_(d, 2 + k))
+        states.append(load_synth_(d, 2 + k, gain))
         decs.append(d.to(DEV).eval())
     p, g = synth_inputs(B, N, G, 0)
     pd, gd = torch.from_numpy(p).to(DEV), torch.from_numpy(g).to(DEV)
@@ -100,20 +116,22 @@ def test_bench_workload_every_shape_every_component_against_fp64_oracle(name):
         z64, ld64 = (np.stack(t) for t in zip(*[_oracle(p, g, states[k], L, mode, torch.float64) for k in range(K)]))
         z32, ld32 = (np.stack(t) for t in zip(*[_oracle(p, g, states[k], L, mode, torch.float32) for k in range(K)]))
         assert hz.shape == (K, B, 3, N)
-    _bounds(f'{name}:K{K}_f{f}_{B}x{N}_{mode}', hz, hld, z64, ld64, z32, ld32, C)
+    _bounds(f'{name}:K{K}_f{f}_{B}x{N}_{mode}', hz, hld, z64, ld64, z32, ld32, C, absolute=state == 'conditioned')
 
 
-def test_train_mode_forward_at_airplane_grid_every_shape_every_component():
+@pytest.mark.parametrize('state', ['bench', 'conditioned'])
+def test_train_mode_forward_at_airplane_grid_every_shape_every_component(state):
     """model.train() forward (batch-statistic BatchNorm over all 64 x 2048 points; reference flows.py:27,30,62,65) of the airplane
     config's K = 4 decoders through the K-batched pipeline, all shapes and components against the fp64 oracle in train mode, and the
     updated running statistics."""
+    from go_with_the_flows_amd.synth import CONDITIONED_GAIN
     K, L, f, G, B, N = 4, 11, 37, 128, 64, 2048
     _cpu_threads()
     _lib.set_tuning(0)
     decs, states = [], []
     for k in range(K):
         d = gw.LocalCondRNVPDecoder(L, f, G)
-        states.append(load_synth_(d, 2 + k))
+        states.append(load_synth_(d, 2 + k, 1.0 if state == 'bench' else CONDITIONED_GAIN))
         decs.append(d.to(DEV).train())
     p, g = synth_inputs(B, N, G, 0)
     stack = gw.MixtureStack(decs)
@@ -131,6 +149,7 @@ def test_train_mode_forward_at_airplane_grid_every_shape_every_component():
             if 'running_' in key:
                 rv_err = max(rv_err, float((sd[key].cpu().double() - ref).abs().max() / (ref.abs().max() + 1e-12)))
     z64, ld64, z32, ld32 = (np.stack(t) for t in (z64, ld64, z32, ld32))
-    _bounds(f'train_forward:K{K}_f{f}_{B}x{N}_inverse', hz, hld, z64, ld64, z32, ld32, 3 * L, extra={'running_stats_rel': rv_err})
+    _bounds(f'train_forward:K{K}_f{f}_{B}x{N}_inverse', hz, hld, z64, ld64, z32, ld32, 3 * L, extra={'running_stats_rel': rv_err},
+            absolute=state == 'conditioned')
     assert rv_err < 1e-4, rv_err
 

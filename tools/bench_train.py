@@ -141,6 +141,9 @@ del l                       # keep no reference to an autograd graph across iter
 ms = timed(step, a.steps)
 pts = a.batch * a.points * WORLD
 say(f'ranks: {WORLD}  per-rank batch: {a.batch}  sharded path: {sharded()}')
+_rows = a.batch * (WORLD if sharded() else 1)      # rows the per-shape modules see (all ranks' rows when data parallel)
+say(f'per-shape modules: rows={_rows} film_heads={"hip" if _rows <= 128 else "library"} heads={"hip" if _rows <= 128 else "library"} '
+    f'prior_flow={"hip" if _rows <= 128 else "library"}')
 say(f'eager   : {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s (each point through all {CFG["n_components"]} components)')
 if a.graph:
     s = torch.cuda.Stream()
