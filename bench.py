@@ -15,9 +15,10 @@ torch.distributed.run ... bench.py --gpus N` or, when no launcher environment is
 
 Prints ONE JSON line on rank 0: the BASELINE metric on configs[1] (`value`), `roofline` of the dominant kernel against
 the unit that executes it (kernel duration from HIP events around the launch; `traffic` = HBM-side bytes per launch measured by two
-`rocprofv3 --pmc` child passes of this script, N = 1 only), `also` = the other BASELINE shapes (m1, ae, svr, k16, k16_b1) timed by
-the same protocol in the same run plus the whole training step (`train_step`: children of this process, one per rank), and
-`cpu_baseline`.
+`rocprofv3 --pmc` child passes of this script, N = 1 only: headline and `also.m1`, null elsewhere), `also` = the other BASELINE shapes
+(m1, ae, svr, k16, k16_b1) timed by the same protocol in the same run plus the whole training step (`train_step`: children of this
+process, one per rank; N = 1: plain, the reference's list API, the data-parallel code path on a 1-rank RCCL group, and configs[2]'s
+16-shape per-rank shard), and `cpu_baseline`.
 """
 import argparse
 import json
@@ -165,8 +166,19 @@ def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backen
                'workload': wl + ', B=64'}
         sh = _run_bench_train([], dict(base_env, GWTF_FORCE_SHARDED='1'), steps=steps)
         rec['data_parallel_path_1rank'] = ({'ms_per_step': sh.get('hipGraph'), 'statistic_all_reduces_in_graph': sh.get('collectives'),
-                                            'note': 'SyncBatchNorm model, phase-split pipeline, every collective captured in the hipGraph, '
-                                                    'RCCL 1-rank group'} if 'hipGraph' in sh else sh)
+                                            'per_shape_modules': sh.get('per_shape_modules'),
+                                            'note': 'the code path an N > 1 group runs -- SyncBatchNorm model, phase-split pipeline, one compaction launch '
+                                                    'per statistic collective, row gathers, overlapped gradient exchange, every collective captured in the '
+                                                    'hipGraph -- on an RCCL 1-rank group: what that path costs before any link latency'} if 'hipGraph' in sh else sh)
+        # BASELINE configs[2] (autoencoding, global batch 128 over 8 GPUs): ONE rank's share, 16 shapes, G = 512, f = 33, through the same
+        # data-parallel code path (1-rank RCCL group) and plain
+        ae = _run_bench_train(['--config', 'ae', '--batch', '16'], dict(base_env, GWTF_FORCE_SHARDED='1'), steps=steps)
+        ae_plain = _run_bench_train(['--config', 'ae', '--batch', '16'], base_env, steps=steps)
+        rec['ae_shard'] = ({'workload': 'config_autoencoding.yaml per-rank shard of an 8-GPU run: K=4 x 33 couplings, f=33, G=512, 16 shapes x 2048 points, '
+                                        'whole model, forward + backward in one hipGraph + fused AMSGrad',
+                            'data_parallel_path_1rank_ms_per_step': ae.get('hipGraph'), 'plain_ms_per_step': ae_plain.get('hipGraph'),
+                            'statistic_all_reduces_in_graph': ae.get('collectives'), 'per_shape_modules': ae.get('per_shape_modules')}
+                           if 'hipGraph' in ae else ae)
         return rec
     # N > 1: a fresh rendezvous port for the children, agreed on through the parents' group
     import socket
@@ -380,20 +392,13 @@ def roofline_record(name, m, live=False):
     exceed 1 because that unit is not the one doing the work."""
     cfg = m['cfg']
     peak = MFMA_F16_PEAK_TFLOPS / 3
-    # HBM-side bytes per launch: the headline record measures them in this run (live_traffic: two rocprofv3 --pmc child passes); the
-    # secondary shapes, and any run where that fails, read the committed profile set, whose tag is reported beside the figure
+    # HBM-side bytes per launch, measured in this run (live_traffic: two rocprofv3 --pmc child passes) for the headline and the metric's
+    # own shape; null where not measured -- no figure is carried over from an earlier profile
     traffic, traffic_source = None, None
-    note = None
     if live:
         traffic, traffic_source = live_traffic(name)
         if traffic is None:
-            note, traffic_source = traffic_source, None
-    tfile = os.path.join(ROOT, 'profiles', 'traffic.json')
-    if traffic is None and os.path.exists(tfile):
-        tj = json.load(open(tfile))
-        traffic = tj.get(name)
-        if traffic is not None:
-            traffic_source = f"profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, tools/profile.sh, tag {tj.get('_tag', 'r07')}; static, not this run)" + (f' [{note}]' if note else '')
+            traffic_source = 'not measured: ' + str(traffic_source)
     return {'bound': 'mfma', 'achieved': round(m['achieved'], 3), 'peak': round(peak, 1), 'unit': 'TFLOP/s',
             'frac': round(m['achieved'] / peak, 4), 'traffic': traffic, 'traffic_source': traffic_source,
             'peak_basis': 'dense f16 MFMA 2500 TFLOP/s / 3 products per fp32 product (the executing unit)',
@@ -409,7 +414,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=100)
     ap.add_argument('--workload', default='airplane', choices=sorted(WORKLOADS))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-live-traffic', action='store_true', help='roofline.traffic from profiles/traffic.json instead of two rocprofv3 --pmc child passes of this run')
+    ap.add_argument('--no-live-traffic', action='store_true', help='skip the rocprofv3 --pmc child passes that measure roofline.traffic (it is then null)')
     ap.add_argument('--no-also', action='store_true', help='skip the secondary M1 (north-star shape) measurement')
     ap.add_argument('--no-train-step', action='store_true', help='skip the secondary whole-model training-step measurement')
     ap.add_argument('--train-step-steps', type=int, default=20, help='timed steps of the secondary training-step measurement')
@@ -470,7 +475,8 @@ def main():
             a = run_workload(name, args, dev, rank, world, sync_all, reduce_max)
             also[name] = {'value': round(a['value'], 3), 'unit': 'Mpoints/s',
                           'ms_per_step': round(a['elapsed'] / args.steps * 1e3, 4), 'steps': args.steps, 'warmup': args.warmup,
-                          'workload': a['cfg']['name'], 'roofline': roofline_record(name, a)}
+                          'workload': a['cfg']['name'],
+                          'roofline': roofline_record(name, a, live=(name == 'm1' and world == 1 and not args.no_live_traffic and not under_profiler()))}
 
         if not args.no_train_step and 'train_step' in selected:
             ts = train_step_record(world, rank, local_rank, dist, dev, args.backend, args.share_device, args.train_step_steps)      # N > 1: every rank takes part (one child per GPU)

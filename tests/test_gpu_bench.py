@@ -31,12 +31,16 @@ def test_single_gpu_line_has_roofline_and_m1():
     # launch between the algorithmic 18.9 MB (36 B x 524 288 point passes) and a few times that
     assert 'measured by this run' in r['traffic_source'], r['traffic_source']
     assert 18.0e6 < r['traffic'] < 80.0e6, r['traffic']
-    assert 'static' in line['also']['m1']['roofline']['traffic_source']          # secondary shapes: the committed profile set
+    m1r = line['also']['m1']['roofline']                                          # the metric's own shape: measured live as well
+    assert 'measured by this run' in m1r['traffic_source'] and 2.3e6 < m1r['traffic'] < 30.0e6, m1r
+    assert line['also']['ae']['roofline']['traffic'] is None                     # nothing carried over from an earlier profile
     ts = line['also']['train_step']                      # the whole training step, timed in a child process
     assert 'error' not in ts and 5 < ts['ms_per_step'] < 60, ts
     # ... and the data-parallel code path on a 1-rank RCCL group: every collective inside the graph, at most 15 % slower
     dp = ts['data_parallel_path_1rank']
     assert 'error' not in dp and dp['statistic_all_reduces_in_graph'] == 132 and dp['ms_per_step'] < 1.15 * ts['ms_per_step'], ts
+    ae = ts['ae_shard']                                  # configs[2]'s per-rank shard (16 shapes, G = 512) through the same path
+    assert 'error' not in ae and 2 < ae['plain_ms_per_step'] <= ae['data_parallel_path_1rank_ms_per_step'] < 40, ae
 
 
 def test_gpus_2_spawns_itself_and_reports_the_aggregate():
