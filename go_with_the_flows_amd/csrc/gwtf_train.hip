@@ -564,17 +564,17 @@ __global__ __launch_bounds__(256) void bwd_tail2_kernel(const float* __restrict_
 
 // sum of the R copies of a replicated statistic slab [K][R][n] -> the contiguous record [K][n] a data-parallel run all-reduces and
 // its consumers then read (fixed order: the same sum on every run)
-__global__ __launch_bounds__(256) void stat_compact_kernel(const float* __restrict__ slab, float* __restrict__ out, int R, int n,
+__global__ __launch_bounds__(256) void stat_compact_kernel(const float* __restrict__ slab, float* __restrict__ out, int n,
                                                            size_t slab_sk) {
+  constexpr int R = GWTF_STAT_REPLICAS;      // a compile-time trip count: all 64 loads of a value in flight at once
   const float* s = slab + (size_t)blockIdx.x * slab_sk;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    float v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = s[(size_t)r * n + i];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    for (int r = 0; r < R; r += 4) {
-      a0 += s[(size_t)r * n + i];
-      a1 += s[(size_t)(r + 1) * n + i];
-      a2 += s[(size_t)(r + 2) * n + i];
-      a3 += s[(size_t)(r + 3) * n + i];
-    }
+#pragma unroll
+    for (int r = 0; r < R; r += 4) { a0 += v[r]; a1 += v[r + 1]; a2 += v[r + 2]; a3 += v[r + 3]; }
     out[(size_t)blockIdx.x * n + i] = (a0 + a1) + (a2 + a3);
   }
 }
@@ -693,7 +693,7 @@ bool ctx_ok(const GwtfTrainCtx* t, bool backward) {
   return true;
 }
 void compact(const float* slab, size_t slab_sk, float* out, int K, int n, hipStream_t st) {
-  hipLaunchKernelGGL(stat_compact_kernel, dim3(K), dim3(256), 0, st, slab, out, GWTF_STAT_REPLICAS, n, slab_sk);
+  hipLaunchKernelGGL(stat_compact_kernel, dim3(K), dim3(256), 0, st, slab, out, n, slab_sk);
 }
 }  // namespace
 
