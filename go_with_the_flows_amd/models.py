@@ -332,6 +332,52 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
             return x, torch.from_numpy(flows_idx + 1).to(x.device).unsqueeze(0).float()
         return x
 
+    @staticmethod
+    def _padded_partition(labels, K):
+        """labels (S, n) ints in [0, K): every sample's per-point component.  -> counts (K,) = the LARGEST count of each component
+        over the samples, and index tensors: slot (S, n) = where point i of sample s sits in the padded component-major layout
+        (points of component k of every sample occupy [start_k, start_k + counts_k), the sample's own in front)."""
+        S, n = labels.shape
+        per = np.stack([(labels == k).sum(1) for k in range(K)], axis=1)            # (S, K)
+        counts = per.max(0)
+        starts = np.concatenate([[0], np.cumsum(counts)[:-1]])
+        slot = np.empty((S, n), np.int64)
+        for s in range(S):
+            order = np.argsort(labels[s], kind='stable')                                # points of component 0 first, ...
+            rank_in_comp = np.concatenate([np.arange(c) for c in per[s]]) if n else np.zeros(0, np.int64)
+            slot[s, order] = starts[labels[s][order]] + rank_in_comp
+        return counts, slot
+
+    @torch.no_grad()
+    def sample_many(self, g_samples, n_points, return_labels=False):
+        """Generation for S shapes in ONE launch (the reference samples one shape per call, flow_mixture.py:146-177; the decoder
+        launch for a single 2048-point shape is latency-bound at ~36 us -- bench.py k16_b1 -- where a batch runs 22 x that rate).
+        Each sample draws its points' components from its own mixture weights (np.random.choice, sample by sample, as the
+        reference's loop would); the points are laid out component by component with every component's segment padded to its
+        largest count over the batch (a few per cent of padding: multinomial counts concentrate), pushed through their own
+        component by one partitioned launch, and gathered back in the points' original order.
+        -> (S, 3, n_points)[, labels (S, n_points) in 1..K]."""
+        S, K, P = g_samples.shape[0], self.n_components, self.p_latent_space_size
+        logits = self.get_weights(g_samples)
+        labels = np.stack([self._draw_components(logits[s], n_points) for s in range(S)])
+        mu0, lv0 = self._base_gaussian(g_samples)
+        z0 = self.reparameterize(mu0.expand(S, P, n_points), lv0.expand(S, P, n_points))
+        x = self._decode_partitioned_many(z0, g_samples, labels)
+        if return_labels:
+            return x, torch.from_numpy(labels + 1).to(x.device).float()
+        return x
+
+    def _decode_partitioned_many(self, z0, g_samples, labels):
+        """z0 (S, 3, n) base samples, labels (S, n) numpy: point i of sample s through component labels[s, i] -> (S, 3, n)."""
+        S, _, n = z0.shape
+        counts, slot = self._padded_partition(np.asarray(labels), self.n_components)
+        n_pad = int(counts.sum())
+        slot_t = torch.from_numpy(slot).to(z0.device)
+        zp = torch.zeros(S, 3, n_pad, device=z0.device, dtype=torch.float32)
+        zp.scatter_(2, slot_t.unsqueeze(1).expand(S, 3, n), z0.float())
+        xp, _ = self.mixture_stack().forward_partition(zp, g_samples, [int(c) for c in counts], mode='direct')
+        return xp.gather(2, slot_t.unsqueeze(1).expand(S, 3, n))
+
 
 class FlowMixtureNLL(nn.Module):
     """Mixture point NLL on the reference's list outputs (losses.py:88-137), reduced by the fused HIP kernel."""

@@ -149,6 +149,35 @@ def test_sample_fused_equals_per_component_decoding():
             off += cnt
 
 
+def test_sample_many_equals_one_decoder_pass_per_point_group():
+    """sample_many: S shapes in one partitioned launch (padded component-major layout) -- every point must come out as its own
+    component's decoder maps it with ITS shape's latent, in the point's original position; labels are the per-sample draws."""
+    m, cfg = build(util_mode='generating')
+    m.eval()
+    S, n, K = 5, 300, cfg['n_components']
+    g = torch.randn(S, cfg['g_latent_space_size'], device=DEV)
+    rng = np.random.default_rng(4)
+    draws = [rng.integers(0, K, n) for _ in range(S)]
+    draws[1][:] = 0                                           # a sample whose points all fall into ONE component
+    it = iter(draws)
+    m._draw_components = lambda row, k: next(it)
+    base = torch.randn(S, 3, n, device=DEV)
+    m.reparameterize = lambda mu, logvar: base * torch.exp(0.5 * logvar) + mu
+    x, labels = m.sample_many(g, n, return_labels=True)
+    assert x.shape == (S, 3, n) and np.array_equal(host(labels), np.stack(draws) + 1)
+    with torch.no_grad():
+        mu0, lv0 = m._base_gaussian(g)
+        z0 = base * torch.exp(0.5 * lv0.expand(S, 3, n)) + mu0.expand(S, 3, n)
+        for s in range(S):
+            for k in range(K):
+                idx = np.nonzero(draws[s] == k)[0]
+                if len(idx) == 0:
+                    continue
+                it_ = torch.from_numpy(idx).to(DEV)
+                want = m.pc_decoder[k](z0[s:s + 1][:, :, it_].contiguous(), g[s:s + 1], mode='direct')[0][-1]
+                assert maxabs(host(x[s:s + 1][:, :, it_]), host(want)) < TOL_COORD, (s, k)
+
+
 def test_graphed_train_step_equals_eager_steps():
     """Three optimiser steps through GraphedTrainStep == three eager steps (same noise, same batches)."""
     from go_with_the_flows_amd import optim

@@ -26,14 +26,14 @@ ff = glob.glob(f"{out}/full/*kernel_stats.csv")
 if ff:
     fr = [r for r in csv.DictReader(open(ff[0])) if 'copyBuffer' not in r['Name'] and 'FillFunctor' not in r['Name']]
     print(f"  kernel time per eager step (start-up uploads and first-step optimiser state fills excluded): {sum(float(r['TotalDurationNs']) for r in fr)/7/1e6:.2f} ms, kernels per step: {sum(int(r['Calls']) for r in fr)/7:.0f}")
-    for r in fr[:14]:
+    for r in fr[:24]:
         print(f"  {r['Name'][:90]:90s} calls={r['Calls']:>6s} avg_us={float(r['AverageNs'])/1e3:9.2f} pct={r['Percentage']}")
 agg = collections.defaultdict(lambda: collections.defaultdict(list)); meta = {}
 for d in ("pmc1", "pmc2", "pmc3", "pmc4"):
     for fn in glob.glob(f"{out}/{d}/*counter_collection.csv"):
         for r in csv.DictReader(open(fn)):
             k = r["Kernel_Name"]
-            key = next((n for n in ("bwd_kernel<3, 2, 3", "bwd_kernel<3, 2, 2", "bwd_kernel<3, 4, 2", "stats_kernel", "stack_kernel", "bwd_tail1_kernel", "bwd_tail2_kernel", "fold1_bwd_kernel") if n in k), None)
+            key = next((n for n in ("bwd_kernel<3, 2, 3", "bwd_kernel<3, 2, 2", "bwd_kernel<3, 4, 2", "stats_kernel", "stack_kernel", "bwd_tail1_kernel", "fold1_bwd_kernel", "fold0_kernel", "fold1_kernel") if n in k), None)
             if key is None: continue
             agg[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[key] = {m: r[m] for m in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "Scratch_Size")}
