@@ -284,6 +284,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 
   // ---- per branch: dacc, FiLM-record grads, dh = W1p^T dacc, dpre, sd0 grads, dx_kept ----------------------
   float dxa_own = 0.f, dxb_own = 0.f;
+  constexpr bool DEFER_DW = MB <= 4 && !LIGHT;      // one column of dW1 tiles per wave: branch 0's can wait in registers (below)
+  f32x4 dwk[MB];
+#pragma unroll
+  for (int mi = 0; mi < MB; ++mi) dwk[mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int br = 0; br < 2; ++br) {
     float d0[NB], d1[NB];
@@ -493,6 +497,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
         // C layout: lane (col = h feature 16 ni + i16, q) holds rows = dacc features 16 mi + 4 q + r.  The partial is stored
         // COMPACT, [f][f] (the padded rows / columns are zero anyway): 41 % less partial traffic at f = 37 (FP = 48), written here
         // and read back by the reduction
+        if (DEFER_DW && br == 0) {
+          // branch 0's partial stays in registers until branch 1 is through: stored here, the wave would meet its own 12 stores at the
+          // `s_waitcnt vmcnt(0)` that guards branch 1's transposed weights (vmcnt counts stores too) -- an HBM write round trip
+          // on the critical path of every workgroup
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) dwk[mi] = dw[mi] * down;
+          continue;
+        }
         float* out = dw1_ws + ((size_t)blockIdx.x * 2 + br) * f * f;
         const int col = 16 * ni + i16;
 #pragma unroll
@@ -504,6 +516,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           }
       }
     }
+  }
+  if (DEFER_DW && !LIGHT && wave < MB) {
+    float* out = dw1_ws + ((size_t)blockIdx.x * 2 + 0) * f * f;
+    const int col = 16 * wave + i16;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * mi + 4 * q + r;
+        if (row < f && col < f) __builtin_nontemporal_store(dwk[mi][r], &out[row * f + col]);
+      }
   }
 #pragma unroll
   for (int d = 0; d < 3; ++d) {

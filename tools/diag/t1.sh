@@ -1,24 +1,3 @@
-timeout -k 10 300 python -m pytest tests/test_gpu_models.py -x -q -k "sample" 2>&1 | tail -5
-python - <<'PY'
-import sys, time, json, os, torch, numpy as np
-sys.path.insert(0, '.')
-from go_with_the_flows_amd import models
-from go_with_the_flows_amd.synth import load_synth_
-CFG = dict(train_mode='p_rnvp_mc_g_rnvp_vae', util_mode='generating', deterministic=False, pc_enc_init_n_channels=3, pc_enc_init_n_features=64,
-           pc_enc_n_features=[128, 256, 512], g_latent_space_size=128, g_prior_n_flows=7, g_prior_n_features=128, g_posterior_n_layers=1,
-           p_latent_space_size=3, p_prior_n_layers=1, p_decoder_n_flows=21, p_decoder_n_features=64, p_decoder_base_type='free',
-           p_decoder_base_var=-3.9551, n_components=16, params_reduce_mode='depth_and_feature', weights_type='learned_weights',
-           pnll_weight=1.0, gnll_weight=1.0, gent_weight=1.0)
-m = models.Flow_Mixture_Model(**CFG).cuda().eval()
-g = torch.randn(32, 128, device='cuda')
-for S in (1, 8, 32):
-    for _ in range(3): m.sample_many(g[:S], 2048)
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(10): m.sample_many(g[:S], 2048)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 10
-    print(f'sample_many S={S}: {dt*1e3:.2f} ms per call, {dt/S*1e6:.0f} us per sample (host-inclusive, eager)')
-for _ in range(3): m.sample_fused(g[:1], 2048)
-torch.cuda.synchronize(); t = time.perf_counter()
-for _ in range(10): m.sample_fused(g[:1], 2048)
-torch.cuda.synchronize(); print(f'sample_fused (one shape): {(time.perf_counter() - t) / 10 * 1e6:.0f} us per sample (host-inclusive, eager)')
-PY
+for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 2>&1 | grep -E "hipGraph"; done
+bash tools/step_kstats.sh t7 | grep -E "bwd_kernel|kernel time"
+timeout -k 10 900 python -m pytest tests -m gpu -x -q -k "train or graph or fused or sgd or directional or reproducible or backward" 2>&1 | tail -3
