@@ -100,15 +100,21 @@ def fold(engine, g, eps):
     s1 = 1.0 / torch.sqrt(rv1 + BN_EPS)
     W1p = P['W1'] * s1.unsqueeze(-1)
     c1 = -rm1 * s1
-    hg, hb, hrm, hrv = P['hbn']
-    S = hg / torch.sqrt(hrv + BN_EPS)
-    T = hb - hrm * S
-    hraw = torch.einsum('bg,cxhfg->bcxhf', g, P['L0'])
-    hbn = hraw * S + T
-    hn = hbn * torch.sigmoid(hbn)
-    o = torch.einsum('bcxhi,cxhji->bcxhj', hn, P['L1']) + P['b1']
-    a = eps + torch.exp(o[:, :, :, 0])
-    cvec = c1 + o[:, :, :, 1] / a
+    if g.is_cuda and g.shape[0] <= 128:
+        # the FiLM heads (Linear -> BatchNorm with running statistics -> Swish -> Linear -> exp) in HIP, forward and backward
+        # (csrc/gwtf_film_train.hip), parameters read in place from the arena
+        film_raw, _, _ = FilmHeadsFn.apply(P['raw'], g, engine.C, engine.f, engine.G, 0, g.shape[0], eps, False)
+        a, bsh = film_raw[:, :, :, 0, :engine.f], film_raw[:, :, :, 1, :engine.f]
+    else:
+        hg, hb, hrm, hrv = P['hbn']
+        S = hg / torch.sqrt(hrv + BN_EPS)
+        T = hb - hrm * S
+        hraw = torch.einsum('bg,cxhfg->bcxhf', g, P['L0'])
+        hbn = hraw * S + T
+        hn = hbn * torch.sigmoid(hbn)
+        o = torch.einsum('bcxhi,cxhji->bcxhj', hn, P['L1']) + P['b1']
+        a, bsh = eps + torch.exp(o[:, :, :, 0]), o[:, :, :, 1]
+    cvec = c1 + bsh / a
     u = P['W2'].unsqueeze(0) * a.unsqueeze(3)
     # Range scaling of the split-f16 contraction's operands, as the eval packer applies it (csrc/gwtf_layout.h, RANGE SCALING):
     # exact powers of two -- constants for autograd, which un-scales every gradient by the chain rule.
