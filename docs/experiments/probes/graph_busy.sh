@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/diag/graph_busy.sh -- busy fraction of the GPU inside one replay of the graphed training step
+# usage (GPU box): bash docs/experiments/probes/graph_busy.sh -- busy fraction of the GPU inside one replay of the graphed training step
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/gb; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $OUT -o gb -- python3 tools/bench_train.py --graph --steps 6 > $OUT/run.log 2>&1

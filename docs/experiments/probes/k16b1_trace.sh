@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/diag/k16b1_trace.sh -- per-kernel durations of the one-shape K=16 sampling call (configs[3], reference batch of one)
+# usage (GPU box): bash docs/experiments/probes/k16b1_trace.sh -- per-kernel durations of the one-shape K=16 sampling call (configs[3], reference batch of one)
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_k16b1; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 bench.py --workload k16_b1 --no-cpu-baseline --no-also --steps 200 > $OUT/run.log 2>&1

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/diag/modelstep_kernels.sh  -- kernel-family breakdown of the graphed end-to-end training step
+# usage (GPU box): bash docs/experiments/probes/modelstep_kernels.sh  -- kernel-family breakdown of the graphed end-to-end training step
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/ms; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o ms -- python3 tools/bench_train.py --graph --steps 10 > $OUT/run.log 2>&1

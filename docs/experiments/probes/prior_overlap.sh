@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/diag/prior_overlap.sh -- where do the prior-flow kernels sit on the timeline of a graphed training step?
+# usage (GPU box): bash docs/experiments/probes/prior_overlap.sh -- where do the prior-flow kernels sit on the timeline of a graphed training step?
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/po; mkdir -p gpurun_out/po
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/po -o t -- python3 tools/bench_train.py --graph --steps 6 --batch ${1:-64} > gpurun_out/po.log 2>&1

@@ -1,4 +1,4 @@
-# usage (GPU box): bash tools/diag/train_kernel_times.sh [extra bench_train args] -- per-kernel average durations of the whole airplane train step (eager)
+# usage (GPU box): bash docs/experiments/probes/train_kernel_times.sh [extra bench_train args] -- per-kernel average durations of the whole airplane train step (eager)
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_tk; rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python3 tools/bench_train.py --steps 5 "$@" > $OUT/run.log 2>&1
