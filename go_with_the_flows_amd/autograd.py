@@ -100,7 +100,7 @@ def fold(engine, g, eps):
     s1 = 1.0 / torch.sqrt(rv1 + BN_EPS)
     W1p = P['W1'] * s1.unsqueeze(-1)
     c1 = -rm1 * s1
-    if g.is_cuda and g.shape[0] <= 128:
+    if g.is_cuda:
         # the FiLM heads (Linear -> BatchNorm with running statistics -> Swish -> Linear -> exp) in HIP, forward and backward
         # (csrc/gwtf_film_train.hip), parameters read in place from the arena
         film_raw, _, _ = FilmHeadsFn.apply(P['raw'], g, engine.C, engine.f, engine.G, 0, g.shape[0], eps, False)
@@ -424,8 +424,8 @@ class FilmHeadsFn(torch.autograd.Function):
         raw, g_all = raw.contiguous(), g_all.contiguous().float()
         dev = raw.device
         Ball, H, FP = g_all.shape[0], 4 * KC, L.gwtf_padded_width(f)
-        if Ball > 128 or raw.numel() != KC * L.gwtf_raw_coupling_floats(f, G):
-            raise _lib.GwtfError(f'FilmHeadsFn: {Ball} latent rows (limit 128) / arena of {raw.numel()} floats for {KC} couplings')
+        if raw.numel() != KC * L.gwtf_raw_coupling_floats(f, G):
+            raise _lib.GwtfError(f'FilmHeadsFn: arena of {raw.numel()} floats for {KC} couplings')
         poison = branch_poison(raw, KC).contiguous()
         hraw = torch.empty(Ball, H, f, device=dev, dtype=torch.float32)
         hn = torch.empty_like(hraw)
@@ -730,14 +730,9 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
     raw = stacked_raw_arena(engines)                          # (K, R): one gather launch, one autograd node
     # the FiLM heads of all K stacks (4 K C small MLPs, BatchNorm over the latent rows of ALL ranks): one HIP launch forward, two
     # backward, parameters read from / gradients written into the stacked arena in place (csrc/gwtf_film_train.hip)
-    if rows_total <= 128:
-        film_raw, film_mean, film_var = FilmHeadsFn.apply(raw, g_all, K * C, f, G, row0, B, eps, True)
-        film_var = film_var * (rows_total / max(rows_total - 1.0, 1.0))  # unbiased, as BatchNorm's running_var update takes it
-    else:
-        # more than 128 latent rows in the (global) batch: the heads as batched library products on views of the arena
-        film_a, film_b, film_mean, film_var = _film_train(_gather_film(raw, K * C, f, G), g_all, eps)
-        FP = _lib.lib().gwtf_padded_width(f)
-        film_raw = F.pad(torch.stack([film_a[row0:row0 + B], film_b[row0:row0 + B]], dim=3), (0, FP - f))   # (B, K*C, 2, 2, FP)
+    # (any number of latent rows: the kernels walk them 128 at a time)
+    film_raw, film_mean, film_var = FilmHeadsFn.apply(raw, g_all, K * C, f, G, row0, B, eps, True)
+    film_var = film_var * (rows_total / max(rows_total - 1.0, 1.0))  # unbiased, as BatchNorm's running_var update takes it
     if raw.requires_grad:
         # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
         # the FiLM heads' part, summed by autograd): hand it to the data-parallel reducer (dist.OverlappedGradients, looked up

@@ -30,8 +30,12 @@ static_assert(kWorkFloats >= kMaxM * kGyPitch, "the dL/dy block must fit the wor
 // C block = A . B^T: the long contractions split over the waves, the short ones one tile per wave
 __device__ __forceinline__ void head_gemm(int M, int N, int K, const float* A, long sai, long sak, const float* Bm, long sbj, long sbk,
                                           float* C, long ldc, bool accumulate, float* work) {
-  if (K >= kSplitK) gemm_splitk<kNJ>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate, work);
-  else gemm_direct(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate);
+  if (K >= kSplitK) {
+    gemm_splitk<kNJ>(M, N, K, A, sai, sak, Bm, sbj, sbk, C, ldc, accumulate, work);      // walks the rows 64 at a time: any M
+  } else {
+    for (int m0 = 0; m0 < M; m0 += kMaxM)                                              // one pass per 128 rows (its accumulators' reach)
+      gemm_direct(min(kMaxM, M - m0), N, K, A + (long)m0 * sai, sai, sak, Bm, sbj, sbk, C + (long)m0 * ldc, ldc, accumulate);
+  }
 }
 
 struct HeadDims { int B, Din, Dout; };
@@ -170,24 +174,30 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
     }
     if (g_bias) g_bias[col] = bn_mode == 1 ? 0.f : (bn_mode == 2 ? ga * rstd * sum_ds : sum_ds);   // a bias before a batch-statistic BatchNorm has no gradient
   }
-  if (live) {
-    const float invB = 1.0f / (float)B;
-    for (int b = cm.rg; b < B; b += cm.RG) {
-      const size_t o = (size_t)b * Dout + col;
-      float gy = ds_at(b, cm.col, mean, rstd, ga, be, bi);
-      if (bn_mode == 1) {
-        const float xh = (ypre[o] + bi - mean) * rstd;
-        gy = ga * rstd * (gy - invB * sum_ds - xh * invB * sum_dsx);
-      } else if (bn_mode == 2) {
-        gy = ga * rstd * gy;
+  // 128 rows at a time (the LDS block's reach): the weight gradient adds up over the row blocks of a longer batch
+  const float invB = 1.0f / (float)B;
+  for (int r0 = 0; r0 < B; r0 += kMaxM) {
+    const int nb = min(kMaxM, B - r0);
+    if (r0) __syncthreads();                                  // the previous block's product has read the LDS block
+    if (live) {
+      for (int b = r0 + cm.rg; b < r0 + nb; b += cm.RG) {
+        const size_t o = (size_t)b * Dout + col;
+        float gy = ds_at(b, cm.col, mean, rstd, ga, be, bi);
+        if (bn_mode == 1) {
+          const float xh = (ypre[o] + bi - mean) * rstd;
+          gy = ga * rstd * (gy - invB * sum_ds - xh * invB * sum_dsx);
+        } else if (bn_mode == 2) {
+          gy = ga * rstd * gy;
+        }
+        g_y[o] = gy;
+        gyt[(b - r0) * kGyPitch + cm.col] = gy;
       }
-      g_y[o] = gy;
-      gyt[b * kGyPitch + cm.col] = gy;
     }
+    __syncthreads();
+    // dW[c0 .. c0 + nc)[:] (+)= g_y[rows, block]^T x[rows] : M = nc, K = the block's rows, N = Din; the dL/dy operand from LDS (rows
+    // beyond nb: stale but finite, they meet zeros), the waves cut Din
+    if (g_W) gemm_nsplit_lds<kNJ>(nc, Din, nb, gyt, kGyPitch, (gptr_c)(x + (size_t)r0 * Din), Din, (gptr)(g_W + (size_t)c0 * Din), Din, r0 > 0);
   }
-  __syncthreads();
-  // dW[c0 .. c0 + nc)[:] = g_y[:, block]^T x : M = nc, K = B, N = Din; the dL/dy operand from LDS, the waves cut Din
-  if (g_W) gemm_nsplit_lds<kNJ>(nc, Din, B, gyt, kGyPitch, (gptr_c)x, Din, (gptr)(g_W + (size_t)c0 * Din), Din);
 }
 
 // ---- backward, pass 2: per block of 16 input columns: g_x[:, block] (+)= g_y W[:, block] ------------------------------------------
@@ -198,7 +208,8 @@ __global__ __launch_bounds__(kThreads) void head_bwd2_kernel(HeadDims d, const f
   head_gemm(d.B, nc, d.Dout, g_y, d.Dout, 1, W + c0, 1, d.Din, g_x + c0, d.Din, accumulate != 0, work);
 }
 
-bool dims_ok(int B, int Din, int Dout) { return B >= 1 && B <= kMaxM && Din >= 1 && Dout >= 1 && Din <= 4096 && Dout <= 4096; }
+constexpr int kMaxRows = 1 << 16;   // any batch: the kernels walk it in blocks of 64 / 128 rows
+bool dims_ok(int B, int Din, int Dout) { return B >= 1 && B <= kMaxRows && Din >= 1 && Dout >= 1 && Din <= 4096 && Dout <= 4096; }
 
 }  // namespace
 

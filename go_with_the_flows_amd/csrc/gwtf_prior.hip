@@ -2,7 +2,7 @@
 // lib/networks/decoders.py:7-38: n_flows RealNVPFlowCouple = 2 n_flows elementary RealNVPFlow, flows.py:163-243), forward and
 // backward, eval- and train-mode BatchNorm, from ONE C call per direction.
 //
-// The work is per SHAPE: B <= 128 rows of G latents through 14 flows of two (B x G/2)(G/2 x F) -> BN -> Swish ->
+// The work is per SHAPE: B rows (<= 128 in every shipped configuration on one GPU; more: row blocks) of G latents through 14 flows of two (B x G/2)(G/2 x F) -> BN -> Swish ->
 // (B x F)(F x G/2) MLPs -- a few MFLOP, a chain of 28 dependent layers.  The reference runs it as ~100 library launches forward and
 // ~200 backward.  Rounds 1-3 walked the whole chain in one workgroup on one compute unit (1.15 ms forward, 2.75 - 3.72 ms backward:
 // hidden behind the decoders on a side stream at 64 shapes per rank, the critical path at <= 16).  Round 4 (below): one launch per
@@ -18,7 +18,7 @@
 
 namespace {
 
-constexpr int kMaxFlows = 64, kMaxRows = 128, kMaxG = 512, kMaxF = 128;
+constexpr int kMaxFlows = 64, kMaxRows = 1 << 16, kMaxG = 512, kMaxF = 128;   // rows: any batch, walked 128 at a time
 
 struct Geom {          // one elementary flow
   int Gw, Gk, wstride, woff, kstride, koff;
@@ -115,69 +115,110 @@ __device__ __forceinline__ void tile_product(f32x4 (&acc)[MTW], const float* con
   }
 }
 
+// Row blocks: a workgroup holds 64 MTW latent rows in its accumulators (MTW = 1: B <= 64, else 2).  A longer batch (the gathered rows
+// of a large data-parallel group) is walked in blocks of 128 rows: whatever must wait for a column total over ALL rows (BatchNorm
+// statistics, their backward sums) is stashed in the element's own output slot by the lane that owns it and read back by the same
+// lane after the total -- no exchange, no extra barrier; weight gradients add up block by block in their own slots (one owner
+// each).  With one block (B <= 128: every shipped configuration on one GPU) nothing is stashed and the code path is the
+// register-resident one the timings in the header were taken on.
+
 // hidden layer of one flow: block (x = branch, ft = tile of 16 hidden columns).  H / XH [B][2][F], ST [2][2][F] = statistics used,
 // bn_stats_j [2][2][F] = batch statistics (train) or null
 template <int MTW>
 __global__ __launch_bounds__(256) void hidden_kernel(const Plan P, const Geom ge, const float* __restrict__ raw, const float* __restrict__ gin,
                                                      float* __restrict__ H, float* __restrict__ XH, float* __restrict__ ST,
                                                      float* __restrict__ bn_stats_j, int training) {
+  constexpr int ROWS = 64 * MTW;
   __shared__ float s_red[4][16];
   const int B = P.B, F = P.F, G = P.G, FT = (F + 15) / 16;
+  const int NRB = (B + ROWS - 1) / ROWS;
   const int x = blockIdx.x / FT, ft = blockIdx.x - x * FT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
   const Branch br = branch_of(raw, ge, F, x);
   const int f = 16 * ft + c16, fc = min(f, F - 1);
   f32x4 acc[MTW];
-  const float* arow[MTW];
-#pragma unroll
-  for (int m = 0; m < MTW; ++m) {
-    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    arow[m] = gin + (size_t)min(16 * (wave + 4 * m) + c16, B - 1) * G + ge.koff;
-  }
   const float* brow = br.W0 + (size_t)fc * ge.Gk;
-  if (ge.kstride == 1) tile_product<MTW, true, true>(acc, arow, 1, brow, 1, ge.Gk, q);
-  else tile_product<MTW, false, true>(acc, arow, (size_t)ge.kstride, brow, 1, ge.Gk, q);
-  float mean, var;
-  if (training) {
-    float s1[1] = {0.f};
+  auto product = [&](int r0) {
+    const float* arow[MTW];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) s1[0] += 16 * (wave + 4 * m) + 4 * q + r < B ? acc[m][r] : 0.f;
-    column_totals<1>(s1, s_red, wave, c16, q);
-    mean = s1[0] / (float)B;
-    float s2[1] = {0.f};
+    for (int m = 0; m < MTW; ++m) {
+      acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      arow[m] = gin + (size_t)min(r0 + 16 * (wave + 4 * m) + c16, B - 1) * G + ge.koff;
+    }
+    if (ge.kstride == 1) tile_product<MTW, true, true>(acc, arow, 1, brow, 1, ge.Gk, q);
+    else tile_product<MTW, false, true>(acc, arow, (size_t)ge.kstride, brow, 1, ge.Gk, q);
+  };
+  auto slot = [&](int b) { return (size_t)b * 2 * F + (size_t)x * F + f; };
+  auto reload = [&](int r0) {                  // the pre-activations this lane stashed
 #pragma unroll
     for (int m = 0; m < MTW; ++m)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float d = acc[m][r] - mean;
-        s2[0] += 16 * (wave + 4 * m) + 4 * q + r < B ? d * d : 0.f;
+        const int b = r0 + 16 * (wave + 4 * m) + 4 * q + r;
+        acc[m][r] = (b < B && f < F) ? H[slot(b)] : 0.f;
       }
+  };
+  float mean, var;
+  if (training) {
+    float s1[1] = {0.f};
+#pragma unroll 1
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int r0 = rb * ROWS;
+      product(r0);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = r0 + 16 * (wave + 4 * m) + 4 * q + r;
+          s1[0] += b < B ? acc[m][r] : 0.f;
+          if (NRB > 1 && b < B && f < F) H[slot(b)] = acc[m][r];
+        }
+    }
+    column_totals<1>(s1, s_red, wave, c16, q);
+    mean = s1[0] / (float)B;
+    float s2[1] = {0.f};
+#pragma unroll 1
+    for (int rb = 0; rb < NRB; ++rb) {
+      const int r0 = rb * ROWS;
+      if (NRB > 1) reload(r0);
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = acc[m][r] - mean;
+          s2[0] += r0 + 16 * (wave + 4 * m) + 4 * q + r < B ? d * d : 0.f;
+        }
+    }
     column_totals<1>(s2, s_red, wave, c16, q);
     var = s2[0] / (float)B;
   } else {
     mean = br.rm[fc];
     var = br.rv[fc];
   }
-  if (f >= F) return;
-  if (wave == 0 && q == 0) {
+  const bool fon = f < F;      // (no early exit: every lane supplies operand ROWS to the products of the loop below)
+  if (fon && wave == 0 && q == 0) {
     if (ST) { ST[(x * 2 + 0) * F + f] = mean; ST[(x * 2 + 1) * F + f] = var; }
     if (training && bn_stats_j) { bn_stats_j[(x * 2 + 0) * F + f] = mean; bn_stats_j[(x * 2 + 1) * F + f] = var; }
   }
-  const float isd = 1.0f / sqrtf(var + GWTF_BN_EPS), ga = br.gamma[f], be = br.beta[f];
+  const float isd = 1.0f / sqrtf(var + GWTF_BN_EPS), ga = br.gamma[fc], be = br.beta[fc];
+#pragma unroll 1
+  for (int rb = 0; rb < NRB; ++rb) {
+    const int r0 = rb * ROWS;
+    if (!training) product(r0);
+    else if (NRB > 1) reload(r0);
 #pragma unroll
-  for (int m = 0; m < MTW; ++m)
+    for (int m = 0; m < MTW; ++m)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = 16 * (wave + 4 * m) + 4 * q + r;
-      if (b < B) {
-        const float xh = (acc[m][r] - mean) * isd;
-        const size_t o = (size_t)b * 2 * F + (size_t)x * F + f;
-        if (XH) XH[o] = xh;
-        H[o] = swish(fmaf(xh, ga, be));
+      for (int r = 0; r < 4; ++r) {
+        const int b = r0 + 16 * (wave + 4 * m) + 4 * q + r;
+        if (b < B && fon) {
+          const float xh = (acc[m][r] - mean) * isd;
+          const size_t o = slot(b);
+          if (XH) XH[o] = xh;
+          H[o] = swish(fmaf(xh, ga, be));
+        }
       }
-    }
+  }
 }
 
 // output layer + affine map of one flow: block = 16 warped latents; every block also copies its share of the kept latents through
@@ -185,38 +226,42 @@ template <int MTW>
 __global__ __launch_bounds__(256) void out_kernel(const Plan P, const Geom ge, const float* __restrict__ raw, const float* __restrict__ gin,
                                                   const float* __restrict__ H, float* __restrict__ gout, float* __restrict__ mo,
                                                   float* __restrict__ lo) {
+  constexpr int ROWS = 64 * MTW;
   const int B = P.B, F = P.F, G = P.G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
   const Branch bm = branch_of(raw, ge, F, 0), bl = branch_of(raw, ge, F, 1);
   const int w = 16 * blockIdx.x + c16, wc = min(w, ge.Gw - 1);
-  f32x4 am[MTW], al[MTW];
-  const float* hm[MTW];
-  const float* hl[MTW];
+#pragma unroll 1
+  for (int r0 = 0; r0 < B; r0 += ROWS) {
+    f32x4 am[MTW], al[MTW];
+    const float* hm[MTW];
+    const float* hl[MTW];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m) {
-    am[m] = al[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    hm[m] = H + (size_t)min(16 * (wave + 4 * m) + c16, B - 1) * 2 * F;
-    hl[m] = hm[m] + F;
-  }
-  tile_product<MTW, true, true>(am, hm, 1, bm.W1 + (size_t)wc * F, 1, F, q);
-  tile_product<MTW, true, true>(al, hl, 1, bl.W1 + (size_t)wc * F, 1, F, q);
-  if (w < ge.Gw) {
-    const int col = ge.woff + ge.wstride * w;
-    const float b1m = bm.b1[w], b1l = bl.b1[w];
+    for (int m = 0; m < MTW; ++m) {
+      am[m] = al[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      hm[m] = H + (size_t)min(r0 + 16 * (wave + 4 * m) + c16, B - 1) * 2 * F;
+      hl[m] = hm[m] + F;
+    }
+    tile_product<MTW, true, true>(am, hm, 1, bm.W1 + (size_t)wc * F, 1, F, q);
+    tile_product<MTW, true, true>(al, hl, 1, bl.W1 + (size_t)wc * F, 1, F, q);
+    if (w < ge.Gw) {
+      const int col = ge.woff + ge.wstride * w;
+      const float b1m = bm.b1[w], b1l = bl.b1[w];
 #pragma unroll
-    for (int m = 0; m < MTW; ++m)
+      for (int m = 0; m < MTW; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int b = 16 * (wave + 4 * m) + 4 * q + r;
-        if (b < B) {
-          const size_t o = (size_t)b * G + col;
-          const float x0 = gin[o], mu = am[m][r] + b1m;
-          const float lv = logf(P.eps + expf(al[m][r] + b1l));                                                // flows.py:198-201
-          gout[o] = P.mode == GWTF_MODE_DIRECT ? expf(0.5f * lv) * x0 + mu : expf(-0.5f * lv) * (x0 - mu);   // :206-209
-          mo[o] = mu;
-          lo[o] = lv;
+        for (int r = 0; r < 4; ++r) {
+          const int b = r0 + 16 * (wave + 4 * m) + 4 * q + r;
+          if (b < B) {
+            const size_t o = (size_t)b * G + col;
+            const float x0 = gin[o], mu = am[m][r] + b1m;
+            const float lv = logf(P.eps + expf(al[m][r] + b1l));                                                // flows.py:198-201
+            gout[o] = P.mode == GWTF_MODE_DIRECT ? expf(0.5f * lv) * x0 + mu : expf(-0.5f * lv) * (x0 - mu);   // :206-209
+            mo[o] = mu;
+            lo[o] = lv;
+          }
         }
-      }
+    }
   }
   // kept latents pass through (mu = logvar = 0 there: exp(0) * g + 0)
   for (int t = blockIdx.x * 256 + threadIdx.x; t < B * ge.Gk; t += gridDim.x * 256) {
@@ -241,62 +286,68 @@ __global__ __launch_bounds__(256) void out_bwd_kernel(const Plan P, const Geom g
   const size_t BG = (size_t)B * G, BF = branch_floats(F, ge.Gw, ge.Gk);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
   const int w0 = 16 * blockIdx.x;
-  for (int t = threadIdx.x; t < ROWS * 16; t += 256) {
-    const int b = t >> 4, wl = t & 15, w = w0 + wl;
-    float dmu = 0.f, dol = 0.f;
-    if (b < B && w < ge.Gw) {
-      const size_t o = (size_t)b * G + ge.woff + ge.wstride * w;
-      const float go = Gcur[o] + (Ggs ? Ggs[(size_t)j * BG + o] : 0.f);
-      const float lv = lv_j[o];
-      float dx, dlv;
-      if (P.mode == GWTF_MODE_DIRECT) {          // y = e^{lv/2} x + mu
-        dx = go * expf(0.5f * lv);
-        dmu = go;
-        dlv = go * 0.5f * (gout[o] - mu_j[o]);
-      } else {                                    // y = e^{-lv/2} (x - mu)
-        const float e = expf(-0.5f * lv);
-        dx = go * e;
-        dmu = -go * e;
-        dlv = -0.5f * go * gout[o];
-      }
-      if (Glvs) dlv += Glvs[(size_t)j * BG + o];
-      dol = dlv * (1.0f - P.eps * expf(-lv));     // lv = log(eps + e^o): dlv/do = e^o / (eps + e^o)
-      dO[((size_t)b * 2 + 0) * Gwmax + w] = dmu;
-      dO[((size_t)b * 2 + 1) * Gwmax + w] = dol;
-      Gnext[o] = dx;
-    }
-    s_do[0][b][wl] = dmu;
-    s_do[1][b][wl] = dol;
-  }
-  __syncthreads();
-  if (threadIdx.x < 32) {                         // db1
-    const int x = threadIdx.x >> 4, wl = threadIdx.x & 15;
-    if (w0 + wl < ge.Gw) {
-      float sdo = 0.f;
-      for (int b = 0; b < B; ++b) sdo += s_do[x][b][wl];
-      gr[(size_t)x * BF + (size_t)F * ge.Gk + 4 * (size_t)F + (size_t)ge.Gw * F + w0 + wl] = sdo;
-    }
-  }
-  // dW1_x[w][f] = sum_b dO_x[b][w] H_x[b][f]: 2 x FT output tiles dealt over the waves
-  const int KB = (B + 15) / 16 * 16;
+  float sdo = 0.f;                                 // db1 of (branch, latent) = thread < 32, summed over the row blocks
 #pragma unroll 1
-  for (int id = wave; id < 2 * FT; id += 4) {
-    const int x = id / FT, nt = id - x * FT;
-    f32x4 dw = {0.f, 0.f, 0.f, 0.f};
-    const int f = 16 * nt + c16;
-    const float* hcol = H + (size_t)x * F + min(f, F - 1);
+  for (int r0 = 0; r0 < B; r0 += ROWS) {
+    const int nb = min(ROWS, B - r0);
+    if (r0) __syncthreads();                       // the previous block's products have read s_do
+    for (int t = threadIdx.x; t < ROWS * 16; t += 256) {
+      const int bl = t >> 4, b = r0 + bl, wl = t & 15, w = w0 + wl;
+      float dmu = 0.f, dol = 0.f;
+      if (b < B && w < ge.Gw) {
+        const size_t o = (size_t)b * G + ge.woff + ge.wstride * w;
+        const float go = Gcur[o] + (Ggs ? Ggs[(size_t)j * BG + o] : 0.f);
+        const float lv = lv_j[o];
+        float dx, dlv;
+        if (P.mode == GWTF_MODE_DIRECT) {          // y = e^{lv/2} x + mu
+          dx = go * expf(0.5f * lv);
+          dmu = go;
+          dlv = go * 0.5f * (gout[o] - mu_j[o]);
+        } else {                                    // y = e^{-lv/2} (x - mu)
+          const float e = expf(-0.5f * lv);
+          dx = go * e;
+          dmu = -go * e;
+          dlv = -0.5f * go * gout[o];
+        }
+        if (Glvs) dlv += Glvs[(size_t)j * BG + o];
+        dol = dlv * (1.0f - P.eps * expf(-lv));     // lv = log(eps + e^o): dlv/do = e^o / (eps + e^o)
+        dO[((size_t)b * 2 + 0) * Gwmax + w] = dmu;
+        dO[((size_t)b * 2 + 1) * Gwmax + w] = dol;
+        Gnext[o] = dx;
+      }
+      s_do[0][bl][wl] = dmu;
+      s_do[1][bl][wl] = dol;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {                         // db1
+      const int x = threadIdx.x >> 4, wl = threadIdx.x & 15;
+      for (int bl = 0; bl < nb; ++bl) sdo += s_do[x][bl][wl];
+    }
+    // dW1_x[w][f] (+)= sum_b dO_x[b][w] H_x[b][f]: 2 x FT output tiles dealt over the waves
+    const int KB = (nb + 15) / 16 * 16;
+#pragma unroll 1
+    for (int id = wave; id < 2 * FT; id += 4) {
+      const int x = id / FT, nt = id - x * FT;
+      f32x4 dw = {0.f, 0.f, 0.f, 0.f};
+      const int f = 16 * nt + c16;
+      const float* hcol = H + (size_t)r0 * 2 * F + (size_t)x * F + min(f, F - 1);
 #pragma unroll 2
-    for (int k0 = 0; k0 < KB; k0 += 16) {
-      const f32x4 bv = load4s(hcol, k0 + 4 * q, B, (size_t)2 * F);
+      for (int k0 = 0; k0 < KB; k0 += 16) {
+        const f32x4 bv = load4s(hcol, k0 + 4 * q, nb, (size_t)2 * F);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) dw = __builtin_amdgcn_mfma_f32_16x16x4f32(s_do[x][k0 + 4 * q + t][c16], bv[t], dw, 0, 0, 0);
-    }
-    float* dW1 = gr + (size_t)x * BF + (size_t)F * ge.Gk + 4 * (size_t)F;
+        for (int t = 0; t < 4; ++t) dw = __builtin_amdgcn_mfma_f32_16x16x4f32(s_do[x][k0 + 4 * q + t][c16], bv[t], dw, 0, 0, 0);
+      }
+      float* dW1 = gr + (size_t)x * BF + (size_t)F * ge.Gk + 4 * (size_t)F;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int w = w0 + 4 * q + r;
-      if (w < ge.Gw && f < F) dW1[(size_t)w * F + f] = dw[r];
+      for (int r = 0; r < 4; ++r) {
+        const int w = w0 + 4 * q + r;
+        if (w < ge.Gw && f < F) dW1[(size_t)w * F + f] = r0 ? dW1[(size_t)w * F + f] + dw[r] : dw[r];
+      }
     }
+  }
+  if (threadIdx.x < 32) {
+    const int x = threadIdx.x >> 4, wl = threadIdx.x & 15;
+    if (w0 + wl < ge.Gw) gr[(size_t)x * BF + (size_t)F * ge.Gk + 4 * (size_t)F + (size_t)ge.Gw * F + w0 + wl] = sdo;
   }
 }
 
@@ -309,37 +360,45 @@ __global__ __launch_bounds__(256) void hid_bwd_kernel(const Plan P, const Geom g
   __shared__ float s_dy[ROWS][17];
   __shared__ float s_red[4][16];
   const int B = P.B, F = P.F, G = P.G, FT = (F + 15) / 16;
+  const int NRB = (B + ROWS - 1) / ROWS;
   const size_t BF = branch_floats(F, ge.Gw, ge.Gk);
   const int x = blockIdx.x / FT, ft = blockIdx.x - x * FT;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
   const Branch br = branch_of(raw, ge, F, x);
   const int f = 16 * ft + c16, fc = min(f, F - 1);
-  f32x4 acc[MTW];
-  const float* arow[MTW];
-#pragma unroll
-  for (int m = 0; m < MTW; ++m) {
-    acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-    arow[m] = dO + ((size_t)min(16 * (wave + 4 * m) + c16, B - 1) * 2 + x) * Gwmax;
-  }
-  tile_product<MTW, true, false>(acc, arow, 1, br.W1 + fc, (size_t)F, ge.Gw, q);
   const float ga = br.gamma[fc], be = br.beta[fc];
   const float isd = 1.0f / sqrtf(ST[(x * 2 + 1) * F + fc] + GWTF_BN_EPS);
+  auto slot = [&](int b) { return (size_t)b * 2 * F + (size_t)x * F + f; };
+  f32x4 acc[MTW];
   float xh[MTW][4], sdy[1] = {0.f}, sdyx[1] = {0.f};
+  // pass A: dH through the Swish per row block; the column sums over ALL rows; with several blocks dH is stashed in DHP's slot
+#pragma unroll 1
+  for (int rb = 0; rb < NRB; ++rb) {
+    const int r0 = rb * ROWS;
+    const float* arow[MTW];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = 16 * (wave + 4 * m) + 4 * q + r;
-      const bool on = b < B && f < F;
-      const float xn = on ? XH[(size_t)b * 2 * F + (size_t)x * F + f] : 0.f;
-      const float hb = fmaf(xn, ga, be);
-      const float sg = 1.0f / (1.0f + expf(-hb));
-      const float dh = on ? acc[m][r] * (sg * (1.0f + hb * (1.0f - sg))) : 0.f;
-      xh[m][r] = xn;
-      acc[m][r] = dh;
-      sdy[0] += dh;
-      sdyx[0] = fmaf(dh, xn, sdyx[0]);
+    for (int m = 0; m < MTW; ++m) {
+      acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+      arow[m] = dO + ((size_t)min(r0 + 16 * (wave + 4 * m) + c16, B - 1) * 2 + x) * Gwmax;
     }
+    tile_product<MTW, true, false>(acc, arow, 1, br.W1 + fc, (size_t)F, ge.Gw, q);
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int b = r0 + 16 * (wave + 4 * m) + 4 * q + r;
+        const bool on = b < B && f < F;
+        const float xn = on ? XH[slot(b)] : 0.f;
+        const float hb = fmaf(xn, ga, be);
+        const float sg = 1.0f / (1.0f + expf(-hb));
+        const float dh = on ? acc[m][r] * (sg * (1.0f + hb * (1.0f - sg))) : 0.f;
+        xh[m][r] = xn;
+        acc[m][r] = dh;
+        sdy[0] += dh;
+        sdyx[0] = fmaf(dh, xn, sdyx[0]);
+        if (NRB > 1 && on) DHP[slot(b)] = dh;
+      }
+  }
   column_totals<1>(sdy, s_red, wave, c16, q);
   column_totals<1>(sdyx, s_red, wave, c16, q);
   if (wave == 0 && q == 0 && f < F) {
@@ -348,34 +407,49 @@ __global__ __launch_bounds__(256) void hid_bwd_kernel(const Plan P, const Geom g
     gb[F + f] = sdy[0];         // d beta
   }
   const float m1 = training ? sdy[0] / (float)B : 0.f, m2 = training ? sdyx[0] / (float)B : 0.f;   // eval: the statistics are constants
-#pragma unroll
-  for (int m = 0; m < MTW; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = 16 * (wave + 4 * m) + 4 * q + r;
-      const bool on = b < B && f < F;
-      const float dy = on ? ga * isd * (acc[m][r] - m1 - xh[m][r] * m2) : 0.f;
-      s_dy[b][c16] = dy;
-      if (on) DHP[(size_t)b * 2 * F + (size_t)x * F + f] = dy;
-    }
-  __syncthreads();
-  // dW0_x[f][kk] = sum_b dHpre[b][f] kept[b][kk]: ceil(Gk / 16) output tiles dealt over the waves
-  const int KB = (B + 15) / 16 * 16, GkT = (ge.Gk + 15) / 16;
+  // pass B: through the BatchNorm, the dHpre block, dW0 (+)= per row block
+  const int GkT = (ge.Gk + 15) / 16;
 #pragma unroll 1
-  for (int nt = wave; nt < GkT; nt += 4) {
-    f32x4 dw = {0.f, 0.f, 0.f, 0.f};
-    const int kk = 16 * nt + c16;
-    const float* kcol = xin + ge.koff + (size_t)ge.kstride * min(kk, ge.Gk - 1);
+  for (int rb = 0; rb < NRB; ++rb) {
+    const int r0 = rb * ROWS, nb = min(ROWS, B - r0);
+    if (rb) __syncthreads();                         // the previous block's products have read s_dy
+#pragma unroll
+    for (int m = 0; m < MTW; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int bl = 16 * (wave + 4 * m) + 4 * q + r, b = r0 + bl;
+        const bool on = b < B && f < F;
+        float dh = acc[m][r], xn = xh[m][r];
+        if (NRB > 1) {
+          dh = on ? DHP[slot(b)] : 0.f;
+          xn = on ? XH[slot(b)] : 0.f;
+        }
+        const float dy = on ? ga * isd * (dh - m1 - xn * m2) : 0.f;
+        s_dy[bl][c16] = dy;
+        if (on) DHP[slot(b)] = dy;
+      }
+    __syncthreads();
+    // dW0_x[f][kk] (+)= sum_b dHpre[b][f] kept[b][kk]: ceil(Gk / 16) output tiles dealt over the waves
+    const int KB = (nb + 15) / 16 * 16;
+#pragma unroll 1
+    for (int nt = wave; nt < GkT; nt += 4) {
+      f32x4 dw = {0.f, 0.f, 0.f, 0.f};
+      const int kk = 16 * nt + c16;
+      const float* kcol = xin + (size_t)r0 * G + ge.koff + (size_t)ge.kstride * min(kk, ge.Gk - 1);
 #pragma unroll 2
-    for (int k0 = 0; k0 < KB; k0 += 16) {
-      const f32x4 bv = load4s(kcol, k0 + 4 * q, B, (size_t)G);
+      for (int k0 = 0; k0 < KB; k0 += 16) {
+        const f32x4 bv = load4s(kcol, k0 + 4 * q, nb, (size_t)G);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) dw = __builtin_amdgcn_mfma_f32_16x16x4f32(s_dy[k0 + 4 * q + t][c16], bv[t], dw, 0, 0, 0);
-    }
+        for (int t = 0; t < 4; ++t) dw = __builtin_amdgcn_mfma_f32_16x16x4f32(s_dy[k0 + 4 * q + t][c16], bv[t], dw, 0, 0, 0);
+      }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int fo = 16 * ft + 4 * q + r;
-      if (fo < F && kk < ge.Gk) gr[(size_t)x * BF + (size_t)fo * ge.Gk + kk] = dw[r];
+      for (int r = 0; r < 4; ++r) {
+        const int fo = 16 * ft + 4 * q + r;
+        if (fo < F && kk < ge.Gk) {
+          float* d = gr + (size_t)x * BF + (size_t)fo * ge.Gk + kk;
+          *d = rb ? *d + dw[r] : dw[r];
+        }
+      }
     }
   }
 }
@@ -385,32 +459,37 @@ template <int MTW>
 __global__ __launch_bounds__(256) void kept_bwd_kernel(const Plan P, const Geom ge, int j, const float* __restrict__ raw,
                                                        const float* __restrict__ DHP, const float* __restrict__ Gcur,
                                                        const float* __restrict__ Ggs, float* __restrict__ Gnext) {
+  constexpr int ROWS = 64 * MTW;
   const int B = P.B, F = P.F, G = P.G;
   const size_t BG = (size_t)B * G;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, q = lane >> 4;
   const int kk = 16 * blockIdx.x + c16, kc = min(kk, ge.Gk - 1);
-  f32x4 acc[MTW];
-  const float* arow[MTW];
+#pragma unroll 1
+  for (int r0 = 0; r0 < B; r0 += ROWS) {
+    f32x4 acc[MTW];
+    const float* arow[MTW];
 #pragma unroll
-  for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int x = 0; x < 2; ++x) {
-    const Branch br = branch_of(raw, ge, F, x);
+    for (int m = 0; m < MTW; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int x = 0; x < 2; ++x) {
+      const Branch br = branch_of(raw, ge, F, x);
 #pragma unroll
-    for (int m = 0; m < MTW; ++m) arow[m] = DHP + (size_t)min(16 * (wave + 4 * m) + c16, B - 1) * 2 * F + (size_t)x * F;
-    tile_product<MTW, true, false>(acc, arow, 1, br.W0 + kc, (size_t)ge.Gk, F, q);
-  }
-  if (kk >= ge.Gk) return;
-  const int col = ge.koff + ge.kstride * kk;
-#pragma unroll
-  for (int m = 0; m < MTW; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int b = 16 * (wave + 4 * m) + 4 * q + r;
-      if (b < B) {
-        const size_t o = (size_t)b * G + col;
-        Gnext[o] = Gcur[o] + (Ggs ? Ggs[(size_t)j * BG + o] : 0.f) + acc[m][r];
-      }
+      for (int m = 0; m < MTW; ++m) arow[m] = DHP + (size_t)min(r0 + 16 * (wave + 4 * m) + c16, B - 1) * 2 * F + (size_t)x * F;
+      tile_product<MTW, true, false>(acc, arow, 1, br.W0 + kc, (size_t)ge.Gk, F, q);
     }
+    if (kk < ge.Gk) {
+      const int col = ge.koff + ge.kstride * kk;
+#pragma unroll
+      for (int m = 0; m < MTW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int b = r0 + 16 * (wave + 4 * m) + 4 * q + r;
+          if (b < B) {
+            const size_t o = (size_t)b * G + col;
+            Gnext[o] = Gcur[o] + (Ggs ? Ggs[(size_t)j * BG + o] : 0.f) + acc[m][r];
+          }
+        }
+    }
+  }
 }
 
 bool make_plan(Plan& P, int n_flows, int B, int G, int F, int mode, float eps) {

@@ -10,8 +10,8 @@ layer-at-a-time HIP pipeline of csrc/gwtf_encoder_train.hip, forward and backwar
 plain library GEMMs and batch-norms on the HIP device (torch.matmul -> rocBLAS, F.batch_norm -> MIOpen, differentiated by
 autograd): eval mode with a gradient required, ``forward`` (the full (B,C,N) feature map) in train mode, width lists
 without kernels, an input that itself requires a gradient.  CPU tensors raise: there is no CPU path.  The per-shape heads
-(FeatureEncoder, WeightsEncoder) run one HIP launch per layer, forward and backward (csrc/gwtf_heads.hip, ``_HeadLayerFn``), up to
-128 rows; beyond that (e.g. the gathered rows of a large data-parallel batch) they are library GEMMs and batch-norms.
+(FeatureEncoder, WeightsEncoder) run one HIP launch per layer, forward and backward (csrc/gwtf_heads.hip, ``_HeadLayerFn``), for any
+number of rows (the gathered rows of a large data-parallel batch are walked 64 / 128 at a time inside the kernels).
 """
 from collections import OrderedDict
 
@@ -448,10 +448,10 @@ class FeatureEncoder(nn.Module):
         return h
 
     def _hip_layers(self, input):
-        """[(Linear, BatchNorm or None)] of the trunk when csrc/gwtf_heads.hip covers this call (fp32 rows on the HIP device, at most
-        128 of them, plain Linear -> [BatchNorm1d with a momentum] -> Swish layers), else None: the library modules then run --
-        on the CPU (host-logic tests), for other dtypes, for more rows."""
-        if not (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and 1 <= input.shape[0] <= 128):
+        """[(Linear, BatchNorm or None)] of the trunk when csrc/gwtf_heads.hip covers this call (fp32 rows on the HIP device -- any
+        number of them: the kernels walk the batch in blocks --, plain Linear -> [BatchNorm1d with a momentum] -> Swish layers), else
+        None: the library modules then run -- on the CPU (host-logic tests), for other dtypes."""
+        if not (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and input.shape[0] >= 1):
             return None
         layers, mods = [], list(self.features) if self.n_layers > 0 else []
         i = 0
@@ -509,7 +509,7 @@ class FeatureEncoder(nn.Module):
 
     def _head(self, seq, h, act=0):
         lin = seq[-1]
-        if h.is_cuda and h.dtype == torch.float32 and len(seq) == 1 and lin.weight.dtype == torch.float32 and h.shape[0] <= 128 and \
+        if h.is_cuda and h.dtype == torch.float32 and len(seq) == 1 and lin.weight.dtype == torch.float32 and \
                 max(lin.weight.shape) <= self.hip_max_width and _lib.lib().gwtf_head_layer_supported(h.shape[0], lin.weight.shape[1], lin.weight.shape[0], act):
             return _HeadLayerFn.apply(h, lin.weight, lin.bias, None, None, None, 0, 1, act)
         out = seq(h)

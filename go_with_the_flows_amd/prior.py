@@ -7,7 +7,7 @@ work unchanged.  The work is per SHAPE -- B rows of G latents, 14 elementary flo
 ``GlobalRNVPDecoder.forward`` on a HIP device runs the WHOLE stack as one launch (csrc/gwtf_prior.hip: forward, and one
 more launch for the backward; eval- and train-mode BatchNorm, every list slot differentiable) instead of the ~100 + ~200
 library launches of the module-by-module evaluation; the per-module ``forward`` of ``RealNVPFlow`` / ``RealNVPFlowCouple``
-(used on their own, on the CPU by the host-logic tests, and for batches beyond 128 shapes) stays a chain of torch ops with
+(used on their own and on the CPU by the host-logic tests) stays a chain of torch ops with
 the two shipped warp patterns applied as strided slices instead of the reference's index gathers.
 """
 from collections import OrderedDict
@@ -146,11 +146,11 @@ class GlobalRNVPDecoder(nn.Module):
         return self.training and syncs_statistics(self._bn_modules())
 
     def _fused_ok(self, g, rows=None):
-        """The one-launch kernels cover this call (csrc/gwtf_prior.hip make_plan: rows <= 128, G <= 512, F <= 128, fp32 affine
+        """The one-launch kernels cover this call (csrc/gwtf_prior.hip make_plan: any number of rows, G <= 512, F <= 128, fp32 affine
         BatchNorm with a momentum); otherwise the module-by-module evaluation runs."""
         bns = self._bn_modules()
         rows = g.shape[0] if rows is None else rows
-        return (g.is_cuda and g.dim() == 2 and 2 <= g.shape[1] == self.g_n_features <= 512 and rows <= 128 and
+        return (g.is_cuda and g.dim() == 2 and 2 <= g.shape[1] == self.g_n_features <= 512 and rows >= 1 and
                 self.n_features <= 128 and 2 * self.n_flows <= 64 and g.dtype == torch.float32 and
                 all(bn.track_running_stats and bn.momentum is not None and bn.affine and bn.weight.dtype == torch.float32
                     for bn in bns))

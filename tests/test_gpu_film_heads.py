@@ -40,6 +40,10 @@ CASES = [  # K, L, f, G, B_all, row0, B
     (1, 2, 33, 512, 16, 0, 16),
     (1, 1, 64, 128, 100, 30, 40),
     (1, 1, 96, 48, 9, 0, 9),
+    # more than 128 latent rows (the gathered rows of a large data-parallel group): row blocks inside the kernels
+    (1, 1, 19, 32, 129, 0, 129),
+    (1, 2, 37, 128, 300, 120, 64),
+    (2, 1, 33, 64, 512, 256, 256),
 ]
 
 

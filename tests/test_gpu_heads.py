@@ -61,9 +61,10 @@ def test_heads_match_the_reference_outputs_gradients_and_buffers(tag, training):
             assert rel(buf.detach().cpu().numpy().astype(np.float64), want.astype(np.float64)) < 1e-5, name
 
 
-@pytest.mark.parametrize('B,din,dout,layers', [(2, 37, 5, 2), (128, 130, 70, 1), (17, 512, 128, 1), (64, 64, 64, 3)])
+@pytest.mark.parametrize('B,din,dout,layers', [(2, 37, 5, 2), (128, 130, 70, 1), (17, 512, 128, 1), (64, 64, 64, 3),
+                                                 (129, 40, 33, 2), (300, 512, 128, 1), (512, 128, 6, 3)])
 def test_heads_odd_sizes_against_the_library_modules_in_fp64(B, din, dout, layers):
-    """Row counts 2 .. 128, widths around the 16-column workgroup blocks and the split-K threshold, no-BatchNorm trunks, the
+    """Row counts 2 .. 512 (beyond 128: the kernels' row blocks), widths around the 16-column workgroup blocks and the split-K threshold, no-BatchNorm trunks, the
     closed-form replay of `bn_updates` running-statistic updates: HIP path == the same module evaluated by torch on the CPU in fp64."""
     for batch_norm in (True, False):
         torch.manual_seed(B + din)
@@ -94,8 +95,9 @@ def test_heads_odd_sizes_against_the_library_modules_in_fp64(B, din, dout, layer
 
 def test_heads_refuse_what_the_kernels_do_not_cover_and_fall_back_to_the_library_modules():
     m = encoders.FeatureEncoder(1, 16, 4).to(DEV).train()
-    big = torch.randn(129, 16, device=DEV)                     # more rows than one workgroup holds: torch modules on the device
-    assert m._hip_layers(big) is None
-    assert m(big)[0].shape == (129, 4)
+    assert m._hip_layers(torch.randn(129, 16, device=DEV)) is not None      # any number of rows is served by the kernels
+    assert m._hip_layers(torch.randn(8, 16, device=DEV, dtype=torch.float64)) is None   # other dtypes: torch modules on the device
+    assert m.double()(torch.randn(8, 16, device=DEV, dtype=torch.float64))[0].shape == (8, 4)
+    m = m.float()
     with pytest.raises(ValueError):                            # one row in train mode: BatchNorm raises (torch raises the same)
         m(torch.randn(1, 16, device=DEV))

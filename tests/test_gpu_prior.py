@@ -50,13 +50,16 @@ def test_fused_prior_flow_matches_reference(mode, training):
         assert abs(float(nll) - float(G12['gnll_' + t])) < 1e-5 * abs(float(G12['gnll_' + t]))
 
 
-@pytest.mark.parametrize('cfg', [(3, 24, 16, 6), (7, 128, 128, 64), (2, 40, 35, 5), (7, 128, 512, 16)])
+@pytest.mark.parametrize('cfg', [(3, 24, 16, 6), (7, 128, 128, 64), (2, 40, 35, 5), (7, 128, 512, 16),
+                                 (2, 40, 35, 130), (2, 128, 128, 300), (1, 64, 512, 512)])
 @pytest.mark.parametrize('training', [False, True])
 @pytest.mark.parametrize('mode', ['direct', 'inverse'])
 def test_fused_prior_flow_gradients(cfg, mode, training):
     """Every parameter, the input, and list slots in the middle of the stack: HIP backward == CPU autograd of the torch
     modules.  (7,128,128,64) / (7,128,512,16) are the shipped configs' prior flows (airplane; autoencoding per GPU),
-    (2,40,35,5) has an odd latent width and a hidden width that is no multiple of 16."""
+    (2,40,35,5) has an odd latent width and a hidden width that is no multiple of 16; the cases with 130 / 300 / 512 rows (the gathered
+    rows of a large data-parallel group) walk the batch in row blocks inside the kernels."""
+    assert prior.GlobalRNVPDecoder(cfg[0], cfg[1], cfg[2]).to(DEV)._fused_ok(torch.zeros(cfg[3], cfg[2], device=DEV))
     n_flows, F_, G, B = cfg
     ref = prior.GlobalRNVPDecoder(n_flows, F_, G)
     load_synth_(ref, 77)
