@@ -18,6 +18,13 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ ws, int n_p
   const int p0 = by * per, p1 = min(n_partials, p0 + per);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   int p = p0;
+  for (; p + 15 < p1; p += 16) {          // 16 loads in flight per thread (a chunk of the 64 x 2048 grid is exactly 16 partials)
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = __builtin_nontemporal_load(&ws[(size_t)(p + u) * rec + e]);
+#pragma unroll
+    for (int u = 0; u < 16; ++u) s[u & 3] += v[u];
+  }
   for (; p + 3 < p1; p += 4)
 #pragma unroll
     for (int u = 0; u < 4; ++u) s[u] += ws[(size_t)(p + u) * rec + e];

@@ -62,6 +62,30 @@ __global__ void enc_train_pack_kernel(const float* __restrict__ W, float* __rest
   *reinterpret_cast<float4*>(units + (size_t)unit * 512 + part * 256 + lane * 4) = *reinterpret_cast<const float4*>(out);
 }
 
+// the six fragment images of layers 1..3 (forward + transposed) in ONE launch: blockIdx.y = job
+struct PackJobs { const float* W[6]; float* units[6]; int rows[6], kdim[6], transposed[6]; };
+__global__ void enc_train_pack_all_kernel(const PackJobs J) {
+  const int j = blockIdx.y;
+  const float* __restrict__ W = J.W[j];
+  float* __restrict__ units = J.units[j];
+  const int rows = J.rows[j], kdim = J.kdim[j], transposed = J.transposed[j];
+  const int KS = kdim / 32, total = (rows / 16) * KS * 2 * 64;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+    const int lane = t & 63, part = (t >> 6) & 1, unit = t >> 7;
+    const int m = unit / KS, ks = unit % KS;
+    const int row = 16 * m + (lane & 15), q = lane >> 4;
+    _Float16 out[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 32 * ks + 16 * (e >> 2) + 4 * q + (e & 3);
+      const float v = transposed ? W[(size_t)k * rows + row] : W[(size_t)row * kdim + k];
+      const _Float16 hi = (_Float16)v;
+      out[e] = part == 0 ? hi : (_Float16)(v - (float)hi);
+    }
+    *reinterpret_cast<float4*>(units + (size_t)unit * 512 + part * 256 + lane * 4) = *reinterpret_cast<const float4*>(out);
+  }
+}
+
 // sum x (3) and sum x x^T (6: xx xy xz yy yz zz) over all points -> mom[replica][12] (pre-zeroed)
 __global__ __launch_bounds__(256) void enc_xmom_kernel(const float* __restrict__ x, float* __restrict__ mom, int B, int N) {
   __shared__ float part[4][9];
@@ -386,23 +410,34 @@ __global__ void enc_pool_finalize_kernel(const unsigned long long* __restrict__ 
 }
 
 // ---- top of the backward: gp = g_pooled where the pooled activation is > 0; the two BatchNorm-backward sums of layer 3 -----
-__global__ void enc_top_kernel(const float* __restrict__ g_pooled, const float* __restrict__ pooled,
-                               const float* __restrict__ ystar, const float* __restrict__ aff, float* __restrict__ gp,
-                               float* __restrict__ sums, float* __restrict__ gmax, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const float mean = aff[2 * C + c], rstd = aff[3 * C + c];
+__global__ __launch_bounds__(256) void enc_top_kernel(const float* __restrict__ g_pooled, const float* __restrict__ pooled,
+                                                      const float* __restrict__ ystar, const float* __restrict__ aff, float* __restrict__ gp,
+                                                      float* __restrict__ sums, float* __restrict__ gmax, int B, int C) {
+  // a workgroup = 32 channels x 8 slices of the shapes (a thread per channel walking all B shapes was B dependent round trips: 32 us
+  // for 64 shapes); the slices' partial sums are combined in slice order: the same sums on every run
+  __shared__ float s_db[8][32], s_dg[8][32], s_mx[8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
   float db = 0.f, dg = 0.f, mx = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float g = pooled[b * C + c] > 0.f ? g_pooled[b * C + c] : 0.f;
-    gp[b * C + c] = g;
-    db += g;
-    dg = fmaf(g, (ystar[b * C + c] - mean) * rstd, dg);
-    mx = fmaxf(mx, fabsf(g));
+  if (c < C) {
+    const float mean = aff[2 * C + c], rstd = aff[3 * C + c];
+#pragma unroll 4
+    for (int b = sl; b < B; b += 8) {
+      const float g = pooled[b * C + c] > 0.f ? g_pooled[b * C + c] : 0.f;
+      gp[b * C + c] = g;
+      db += g;
+      dg = fmaf(g, (ystar[b * C + c] - mean) * rstd, dg);
+      mx = fmaxf(mx, fabsf(g));
+    }
   }
-  sums[c] = db;
-  sums[C + c] = dg;
-  atomicMax(reinterpret_cast<int*>(gmax), __builtin_bit_cast(int, mx));
+  s_db[sl][cl] = db; s_dg[sl][cl] = dg; s_mx[sl][cl] = mx;
+  __syncthreads();
+  if (sl == 0 && c < C) {
+#pragma unroll
+    for (int u = 1; u < 8; ++u) { db += s_db[u][cl]; dg += s_dg[u][cl]; mx = fmaxf(mx, s_mx[u][cl]); }
+    sums[c] = db;
+    sums[C + c] = dg;
+    atomicMax(reinterpret_cast<int*>(gmax), __builtin_bit_cast(int, mx));
+  }
 }
 
 // ---- the arg-max rows of the top layer's backward -------------------------------------------------------------------------
@@ -415,7 +450,8 @@ __global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __res
                                                               int* __restrict__ slot_of, int* __restrict__ row_off,
                                                               int* __restrict__ row_list, int N, int C) {
   extern __shared__ int dyn[];                 // [N] row of a point | -1
-  __shared__ int s_am[512], s_cnt[512], s_off[512], s_list[512], s_scan[256];
+  __shared__ int s_am[512], s_cnt[512], s_off[512], s_scan[256];
+  __shared__ __align__(16) int s_list[512];
   __shared__ float s_cf[512];
   int* slot = dyn;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -449,12 +485,18 @@ __global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __res
   }
   const int rows = s_scan[255];
   __syncthreads();
-  // channel lists per row: count (LDS atomics), offsets (scan), fill, then every row's short list sorted ascending so that the
-  // sums below do not depend on the order the atomics happened to land in
+  // channel lists per row, ascending channel order inside a row (the sums of enc_top_rows_kernel must not depend on the order LDS
+  // atomics land in): count per row (integer atomics: order-free), offsets (scan), and each channel's place inside its row =
+  // the number of SMALLER channels with the same row, counted by brute force over broadcast LDS reads (C^2 / 256 compares per
+  // thread).  (The first version filled the lists by atomics and insertion-sorted every row with one thread: a shape whose
+  // arg-max points coincide for ~60 channels -- one extreme point -- held the whole launch for 80 us.)
   for (int r = tid; r < C; r += 256) s_cnt[r] = 0;
   __syncthreads();
-  for (int c = tid; c < C; c += 256)
-    if (s_cf[c] != 0.f) atomicAdd(&s_cnt[slot[s_am[c]]], 1);
+  for (int c = tid; c < C; c += 256) {
+    const int r = s_cf[c] != 0.f ? slot[s_am[c]] : -1;
+    s_list[c] = r;                                   // (s_list doubles as the channel -> row table until the fill below)
+    if (r >= 0) atomicAdd(&s_cnt[r], 1);
+  }
   __syncthreads();
   {
     const int a = 2 * tid < C ? s_cnt[2 * tid] : 0, c2 = 2 * tid + 1 < C ? s_cnt[2 * tid + 1] : 0;
@@ -470,23 +512,29 @@ __global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __res
     if (2 * tid < C) s_off[2 * tid] = base;
     if (2 * tid + 1 < C) s_off[2 * tid + 1] = base + a;
   }
-  for (int r = tid; r < C; r += 256) s_cnt[r] = 0;
   __syncthreads();
-  for (int c = tid; c < C; c += 256)
-    if (s_cf[c] != 0.f) {
-      const int r = slot[s_am[c]];
-      s_list[s_off[r] + atomicAdd(&s_cnt[r], 1)] = c;
-    }
-  __syncthreads();
-  for (int r = tid; r < rows; r += 256) {           // insertion sort: the lists average two entries
-    const int o = s_off[r], k = s_cnt[r];
-    for (int i = 1; i < k; ++i) {
-      const int v = s_list[o + i];
-      int j2 = i - 1;
-      while (j2 >= 0 && s_list[o + j2] > v) { s_list[o + j2 + 1] = s_list[o + j2]; --j2; }
-      s_list[o + j2 + 1] = v;
-    }
+  int place[2] = {0, 0}, myrow[2] = {-1, -1};
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (tid + 256 * u < C) myrow[u] = s_list[tid + 256 * u];
+  for (int c2 = 0; c2 < C; c2 += 4) {                // every lane reads the same words: LDS broadcast
+    const int4 rr = *reinterpret_cast<const int4*>(&s_list[c2]);
+    const int rv[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) place[u] += (c2 + e < tid + 256 * u && rv[e] == myrow[u]) ? 1 : 0;
   }
+  __syncthreads();                                    // everyone has read the channel -> row table
+  int dst[2] = {-1, -1};
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (myrow[u] >= 0) dst[u] = s_off[myrow[u]] + place[u];
+  for (int c = tid; c < C; c += 256) s_list[c] = 0;   // entries beyond the number of hits are never read (row_off bounds them)
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+    if (dst[u] >= 0) s_list[dst[u]] = tid + 256 * u;
   __syncthreads();
   // s_off is an exclusive prefix sum over ALL C entries (rows beyond `rows` have no hits): s_off[r + 1] ends row r
   for (int r = tid; r < C; r += 256) {
@@ -565,13 +613,13 @@ __global__ __launch_bounds__(512) void enc_bwd_consts_kernel(const float* __rest
 // points of a shape, one precomputed row each (`extra` [B][ex_rows][CIN], `slot_of` [B][N] = row or -1; enc_top_scatter_kernel).
 // The fragment images hold M times a power of two; bconst = v [CIN] followed by {down}.
 template <int CIN, int COUT, int NB, bool TOP, bool BOTTOM>
-__global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
+__global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
                                                                  const float* __restrict__ gp, const int* __restrict__ amax,
                                                                  const float* __restrict__ bconst, const float* __restrict__ units,
                                                                  const float* __restrict__ y_prev, const float* __restrict__ aff_prev,
                                                                  const float* __restrict__ w0, float* __restrict__ dA_prev,
                                                                  float* __restrict__ sums, float* __restrict__ gmax_prev, int B,
-                                                                 int N, int ex_rows) {
+                                                                 int N, int ex_rows, float* __restrict__ a2rows) {
   static_assert(!TOP || CIN == COUT, "the top layer contracts over its own input channels");
   constexpr int KS = COUT / 32, MT = CIN / 16, TM = 16 / KS, NCH = MT / TM, NS = BOTTOM ? 5 : (TOP ? 3 : 2);
   static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
@@ -627,6 +675,14 @@ __global__ __launch_bounds__(kThreads) void enc_train_bwd_kernel(const float* __
 #pragma unroll
           for (int r = 0; r < 4; ++r) a[r] = fmaf(s4[r], valid[nb] ? y_prev[((size_t)b * CIN + c0 + r) * N + n[nb]] : 0.f, t4[r]);
           split_into<true>(a, bhi[ks][nb], blo[ks][nb], half);
+          // the activations of the arg-max points, point-major: what the arg-max part of dW_3 contracts with (gwtf_enc_train_dw3).
+          // Here they are in registers; gathered from the (B, C, N) array afterwards every VALUE costs a 128-byte line (72 us).
+          if (a2rows && slot[nb] >= 0) {
+            f32x4 ar;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ar[r] = fmaxf(a[r], 0.f);
+            *reinterpret_cast<f32x4*>(&a2rows[((size_t)b * ex_rows + slot[nb]) * CIN + c0]) = ar;
+          }
         }
         continue;
       }
@@ -901,35 +957,85 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
         out[(size_t)(64 * wm + 16 * mt + 4 * q + r) * CB + 64 * wn + 16 * nt + i16] = acc[mt][nt][r] * down;
 }
 
-// S[c][k] = sum_b gp[b][c] a_2[k](b, amax[b][c]): the arg-max part of dW_3 (one workgroup per output channel c, a thread per k)
+// S[c][k] = sum_b gp[b][c] a_2[k](b, amax[b][c]): the arg-max part of dW_3 (one workgroup per output channel c, a thread per k).
+// a_2 at the arg-max points comes point-major from a2rows [B][C][CP] (row slot_of[b][amax[b][c]], written by the top layer's backward
+// kernel from its registers): contiguous 1-KiB rows.  (Gathered from the (B, C, N) activations every value cost a 128-byte line:
+// 500 MB of traffic, 72 us.)  The shapes with a non-zero gradient are compacted into LDS by the first wave, eight rows in flight per
+// thread; ascending shapes: the same sum on every run.
 __global__ __launch_bounds__(256) void enc_top_gather_kernel(const float* __restrict__ gp, const int* __restrict__ amax,
-                                                             const float* __restrict__ y_prev, const float* __restrict__ aff_prev,
+                                                             const int* __restrict__ slot_of, const float* __restrict__ a2rows,
                                                              float* __restrict__ S, int B, int N, int C, int CP) {
+  __shared__ float s_g[64];
+  __shared__ int s_row[64], s_n;
   const int c = blockIdx.x;
-  for (int k = threadIdx.x; k < CP; k += blockDim.x) {
-    const float s = aff_prev[k], t = aff_prev[CP + k];
+  for (int k0 = 0; k0 < CP; k0 += blockDim.x) {
+    const int k = k0 + threadIdx.x, kc = min(k, CP - 1);
     float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float g = gp[(size_t)b * C + c];
-      if (g != 0.f) acc = fmaf(g, fmaxf(fmaf(s, y_prev[((size_t)b * CP + k) * N + amax[(size_t)b * C + c]], t), 0.f), acc);
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int b = b0 + threadIdx.x;
+        const float g = b < B ? gp[(size_t)b * C + c] : 0.f;
+        int row = -1;
+        if (g != 0.f) row = slot_of[(size_t)b * N + min(max(amax[(size_t)b * C + c], 0), N - 1)];
+        const bool on = g != 0.f && row >= 0;          // (a point with a gradient always has a row: enc_top_scatter_kernel)
+        const unsigned long long live = __ballot(on);
+        const int pos = __popcll(live & ((1ull << threadIdx.x) - 1ull));
+        if (on) { s_g[pos] = g; s_row[pos] = b * C + row; }
+        if (threadIdx.x == 0) s_n = __popcll(live);
+      }
+      __syncthreads();
+      const int nb = s_n;
+      for (int i0 = 0; i0 < nb; i0 += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = a2rows[(size_t)s_row[min(i0 + u, nb - 1)] * CP + kc];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (i0 + u < nb) acc = fmaf(s_g[i0 + u], v[u], acc);
+      }
     }
-    S[(size_t)c * CP + k] = acc;
+    if (k < CP) S[(size_t)c * CP + k] = acc;
   }
 }
 
+// out[e] = sum over the slices of partials[slice][e]: a workgroup = 32 elements x 8 groups of slices, eight loads in flight per thread,
+// the groups combined in a fixed order (one thread per element walking 256 - 512 slices four at a time was 24 us of dependent loads)
 __global__ __launch_bounds__(256) void enc_dw_reduce_kernel(const float* __restrict__ partials, float* __restrict__ out, int slices,
                                                             int total) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e >= total) return;
+  __shared__ float part[8][32];
+  const int el = threadIdx.x & 31, gq = threadIdx.x >> 5, e = blockIdx.x * 32 + el, ec = min(e, total - 1);
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  int p = 0;
-  for (; p + 3 < slices; p += 4)
+  int p = gq;
+  for (; p + 56 < slices; p += 64) {
+    float v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s[u] += partials[(size_t)(p + u) * total + e];
-  for (; p < slices; ++p) s[0] += partials[(size_t)p * total + e];
-  out[e] = (s[0] + s[1]) + (s[2] + s[3]);
+    for (int u = 0; u < 8; ++u) v[u] = partials[(size_t)(p + 8 * u) * total + ec];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s[u & 3] += v[u];
+  }
+  for (; p < slices; p += 8) s[0] += partials[(size_t)p * total + ec];
+  part[gq][el] = (s[0] + s[1]) + (s[2] + s[3]);
+  __syncthreads();
+  if (gq == 0 && e < total) {
+    float t = part[0][el];
+#pragma unroll
+    for (int u = 1; u < 8; ++u) t += part[u][el];
+    out[e] = t;
+  }
 }
 
+// points per wave / 16 of the backward kernels (layer 2, layer 1, the top layer's M form)
+#ifndef GWTF_ENC_NB2
+#define GWTF_ENC_NB2 1
+#endif
+#ifndef GWTF_ENC_NB1
+#define GWTF_ENC_NB1 1
+#endif
+#ifndef GWTF_ENC_NBT
+#define GWTF_ENC_NBT 2
+#endif
+constexpr int kNB2 = GWTF_ENC_NB2, kNB1 = GWTF_ENC_NB1, kNBT = GWTF_ENC_NBT;
 int dw_slices_per_shape(int layer) { return layer == 1 ? 8 : 4; }
 int dw_per(int layer, int N) {
   const int nsl = dw_slices_per_shape(layer);
@@ -957,6 +1063,23 @@ extern "C" int gwtf_enc_train_pack(const float* W, float* units_fwd, float* unit
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(enc_train_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, units_fwd, cout, cin, 0);
   hipLaunchKernelGGL(enc_train_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, W, units_bwd, cin, cout, 1);
+  return (int)hipGetLastError();
+}
+
+// all three layers' images from one launch (what the training step calls: six launches of gwtf_enc_train_pack otherwise)
+extern "C" int gwtf_enc_train_pack_all(const float* W1, const float* W2, const float* W3, float* uf1, float* ub1, float* uf2, float* ub2,
+                                       float* uf3, float* ub3, void* stream) {
+  if (!W1 || !W2 || !W3 || !uf1 || !ub1 || !uf2 || !ub2 || !uf3 || !ub3) return GWTF_E_BADARG;
+  PackJobs J;
+  const float* Ws[3] = {W1, W2, W3};
+  float* uf[3] = {uf1, uf2, uf3};
+  float* ub[3] = {ub1, ub2, ub3};
+  for (int l = 1; l <= 3; ++l) {
+    const int cin = kC[l], cout = kC[l + 1];
+    J.W[2 * (l - 1)] = Ws[l - 1]; J.units[2 * (l - 1)] = uf[l - 1]; J.rows[2 * (l - 1)] = cout; J.kdim[2 * (l - 1)] = cin; J.transposed[2 * (l - 1)] = 0;
+    J.W[2 * l - 1] = Ws[l - 1]; J.units[2 * l - 1] = ub[l - 1]; J.rows[2 * l - 1] = cin; J.kdim[2 * l - 1] = cout; J.transposed[2 * l - 1] = 1;
+  }
+  hipLaunchKernelGGL(enc_train_pack_all_kernel, dim3(64, 6), dim3(256), 0, (hipStream_t)stream, J);
   return (int)hipGetLastError();
 }
 
@@ -1032,7 +1155,7 @@ extern "C" int gwtf_enc_train_top(const float* g_pooled, const float* pooled, co
                                   float* sums, float* gmax, int B, void* stream) {
   if (!g_pooled || !pooled || !ystar || !aff3 || !gp || !sums || !gmax || B <= 0) return GWTF_E_BADARG;
   const int C = kC[4];
-  hipLaunchKernelGGL(enc_top_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, g_pooled, pooled, ystar, aff3, gp, sums,
+  hipLaunchKernelGGL(enc_top_kernel, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)stream, g_pooled, pooled, ystar, aff3, gp, sums,
                      gmax, B, C);
   return (int)hipGetLastError();
 }
@@ -1051,28 +1174,30 @@ extern "C" int gwtf_enc_train_backward(int layer, const float* y_l, const float*
   if (!y_l || !up_g || !bconst || !units_bwd || !y_prev || !aff_prev || !sums || B <= 0 || N <= 0 || layer < 1 || layer > 2)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  const dim3 block(kThreads), grid((N + 255) / 256, B);
+  const dim3 block(kThreads);
   if (layer == 2) {
     if (!dA_prev || !gmax_prev) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_bwd_kernel<128, 256, 2, false, false>), grid, block, 0, st, y_l, up_g, nullptr, nullptr, bconst,
-                       units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N, 0);
+    hipLaunchKernelGGL((enc_train_bwd_kernel<128, 256, kNB2, false, false>), dim3((N + 128 * kNB2 - 1) / (128 * kNB2), B), block, 0, st, y_l, up_g, nullptr, nullptr, bconst,
+                       units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N, 0, nullptr);
   } else {
     if (!w0) return GWTF_E_BADARG;
-    hipLaunchKernelGGL((enc_train_bwd_kernel<64, 128, 2, false, true>), grid, block, 0, st, y_l, up_g, nullptr, nullptr, bconst,
-                       units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N, 0);
+    hipLaunchKernelGGL((enc_train_bwd_kernel<64, 128, kNB1, false, true>), dim3((N + 128 * kNB1 - 1) / (128 * kNB1), B), block, 0, st, y_l, up_g, nullptr, nullptr, bconst,
+                       units_bwd, y_prev, aff_prev, w0, dA_prev, sums, gmax_prev, B, N, 0, nullptr);
   }
   return (int)hipGetLastError();
 }
 
 // layer 3 in the M form (see enc_train_bwd_kernel): units_m = fragment images of M * 2^k, mconst = v [256] | {2^-k},
-// extra / slot_of from gwtf_enc_train_top_scatter
+// extra / slot_of from gwtf_enc_train_top_scatter; a2rows [B][512][256] (out): row slot_of[b][n] of shape b = a_2(b, :, n) for every
+// arg-max point n (the other rows are not written) -- what gwtf_enc_train_dw3 contracts the top gradients with
 extern "C" int gwtf_enc_train_backward_top(const float* y2, const float* aff2, const float* units_m, const float* mconst,
-                                           const float* extra, const int* slot_of, float* dA2, float* sums, float* gmax2, int B,
-                                           int N, void* stream) {
-  if (!y2 || !aff2 || !units_m || !mconst || !extra || !slot_of || !dA2 || !sums || !gmax2 || B <= 0 || N <= 0) return GWTF_E_BADARG;
-  hipLaunchKernelGGL((enc_train_bwd_kernel<256, 256, 2, true, false>), dim3((N + 255) / 256, B), dim3(kThreads), 0,
+                                           const float* extra, const int* slot_of, float* dA2, float* sums, float* gmax2,
+                                           float* a2rows, int B, int N, void* stream) {
+  if (!y2 || !aff2 || !units_m || !mconst || !extra || !slot_of || !dA2 || !sums || !gmax2 || !a2rows || B <= 0 || N <= 0)
+    return GWTF_E_BADARG;
+  hipLaunchKernelGGL((enc_train_bwd_kernel<256, 256, kNBT, true, false>), dim3((N + 128 * kNBT - 1) / (128 * kNBT), B), dim3(kThreads), 0,
                      (hipStream_t)stream, nullptr, nullptr, extra, slot_of, mconst, units_m, y2, aff2, nullptr, dA2, sums, gmax2, B, N,
-                     kC[4]);
+                     kC[4], a2rows);
   return (int)hipGetLastError();
 }
 
@@ -1094,7 +1219,7 @@ extern "C" int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g,
   else
     hipLaunchKernelGGL((enc_train_dw_kernel<2, 1, 0, true>), dim3(B * nsl), dim3(128), 0, st, y_l, up_g, bconst, y_prev, tab_prev, partials, B, N, nsl, per);
   const int total = CA * CB;
-  hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, st, partials, dW, B * nsl, total);
+  hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((total + 31) / 32), dim3(256), 0, st, partials, dW, B * nsl, total);
   return (int)hipGetLastError();
 }
 
@@ -1102,14 +1227,14 @@ extern "C" int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g,
 // y_3 = W_3 a_2,   dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2,   S[c][:] = sum_b gp[b][c] a_2(b, amax[b][c]) (gm_3 is
 // non-zero at the arg-max points only), G_2 = sum_p a_2 a_2^T.  This call leaves G_2 (256 x 256) and S (512 x 256); the caller
 // finishes with one small library GEMM (W_3 G_2) -- half the matrix work of the direct product and no pass over y_3.
-extern "C" int gwtf_enc_train_dw3(const float* gp, const int* amax, const float* y2, const float* aff2, float* partials,
-                                  float* gram, float* S, int B, int N, void* stream) {
-  if (!gp || !amax || !y2 || !aff2 || !partials || !gram || !S || B <= 0 || N <= 0 || (N & 3)) return GWTF_E_BADARG;
+extern "C" int gwtf_enc_train_dw3(const float* gp, const int* amax, const int* slot_of, const float* a2rows, const float* y2,
+                                  const float* aff2, float* partials, float* gram, float* S, int B, int N, void* stream) {
+  if (!gp || !amax || !slot_of || !a2rows || !y2 || !aff2 || !partials || !gram || !S || B <= 0 || N <= 0 || (N & 3)) return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   const int C2 = kC[3], nsl = dw_slices_per_shape(3), per = dw_per(3, N);
   hipLaunchKernelGGL((enc_train_dw_kernel<4, 4, 2, false>), dim3(B * nsl), dim3(1024), 0, st, nullptr, nullptr, aff2, y2, aff2, partials,
                      B, N, nsl, per);
-  hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((C2 * C2 + 255) / 256), dim3(256), 0, st, partials, gram, B * nsl, C2 * C2);
-  hipLaunchKernelGGL(enc_top_gather_kernel, dim3(kC[4]), dim3(256), 0, st, gp, amax, y2, aff2, S, B, N, kC[4], C2);
+  hipLaunchKernelGGL(enc_dw_reduce_kernel, dim3((C2 * C2 + 31) / 32), dim3(256), 0, st, partials, gram, B * nsl, C2 * C2);
+  hipLaunchKernelGGL(enc_top_gather_kernel, dim3(kC[4]), dim3(256), 0, st, gp, amax, slot_of, a2rows, S, B, N, kC[4], C2);
   return (int)hipGetLastError();
 }

@@ -76,7 +76,8 @@ class _EncoderTrainFn(torch.autograd.Function):
                 n_units = L.gwtf_enc_train_units_floats(l)
                 units_f.append(torch.empty(n_units, **f32))
                 units_b.append(torch.empty(n_units, **f32))
-                check(L.gwtf_enc_train_pack(P(Ws[l]), P(units_f[l]), P(units_b[l]), l, st))
+            check(L.gwtf_enc_train_pack_all(P(Ws[1]), P(Ws[2]), P(Ws[3]), P(units_f[1]), P(units_b[1]), P(units_f[2]), P(units_b[2]),
+                                            P(units_f[3]), P(units_b[3]), st))       # one launch for the six fragment images
             ys, ymax = [None], torch.zeros(4, **f32)
             keys = torch.zeros(2, B, C[4], device=dev, dtype=torch.int64)        # arg-max / arg-min keys of y_3 (never stored)
             for l in (1, 2, 3):
@@ -151,12 +152,14 @@ class _EncoderTrainFn(torch.autograd.Function):
                                                slot_of.data_ptr(), tables.data_ptr(), B, N, st))
             up = torch.empty(B, C[3], N, **f32)                                    # masked dL/da_2
             sums = torch.zeros(R, 3, C[3], **f32)
+            a2rows = torch.empty(B, C[4], C[3], **f32)                             # a_2 at the arg-max points, point-major
             check(L.gwtf_enc_train_backward_top(P(ys[2]), P(aff[2]), P(units_m), P(mconst), P(extra), slot_of.data_ptr(), P(up),
-                                                P(sums), P(gmax[2:3]), B, N, st))
+                                                P(sums), P(gmax[2:3]), P(a2rows), B, N, st))
             red = sums.sum(0)
             # dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2  (gwtf_enc_train_dw3)
             gram, S = torch.empty(C[3], C[3], **f32), torch.empty(C[4], C[3], **f32)
-            check(L.gwtf_enc_train_dw3(P(gp), b['amax'].data_ptr(), P(ys[2]), P(aff[2]), P(partials), P(gram), P(S), B, N, st))
+            check(L.gwtf_enc_train_dw3(P(gp), b['amax'].data_ptr(), slot_of.data_ptr(), P(a2rows), P(ys[2]), P(aff[2]), P(partials), P(gram),
+                                       P(S), B, N, st))
             grads[9] = (s3[:, None] * S + q3[:, None] * (W3 @ gram) + r3[:, None] * red[2][None, :]).view_as(params[9])
             for l in (2, 1):
                 grads[3 * l + 1], grads[3 * l + 2] = red[1].clone(), red[0].clone()          # bn.weight, bn.bias of layer l

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWTF_ABI_VERSION 3
+#define GWTF_ABI_VERSION 4
 #define GWTF_E_BADARG 10001   /* shape / mode / width outside what the kernels support */
 #define GWTF_E_UNSUPPORTED 10002   /* a layer-width list no kernel instantiation was built for */
 #define GWTF_MODE_DIRECT 0    /* sampling direction  base -> data (reference models.py:202) */
@@ -402,6 +402,9 @@ int gwtf_enc_train_supported(const int* widths, int n_widths);
 size_t gwtf_enc_train_units_floats(int layer);
 /* W [C[l+1]][C[l]] -> MFMA fragment images of W (forward) and W^T (backward), gwtf_enc_train_units_floats(layer) floats each */
 int gwtf_enc_train_pack(const float* W, float* units_fwd, float* units_bwd, int layer, void* stream);
+/* the same for layers 1, 2, 3 from ONE launch (W_l, forward images uf_l, backward images ub_l) */
+int gwtf_enc_train_pack_all(const float* W1, const float* W2, const float* W3, float* uf1, float* ub1, float* uf2, float* ub2,
+                            float* uf3, float* ub3, void* stream);
 /* mom [64][12] += {sum x (3), sum x x^T (xx xy xz yy yz zz), -} over this rank's points */
 int gwtf_enc_train_xmoments(const float* x, float* mom, int B, int N, void* stream);
 /* layer 0: batch statistics of y_0 = W_0 x from the summed moments mom12; updates the running statistics (NULL: skip) */
@@ -436,12 +439,14 @@ int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, cons
  *                                extra [B][512][256]: row r of shape b = sum of coef[b][c] W_3[c][:] over the channels whose
  *                                arg-max is that point (only the used rows are written); tables: B (2 * 512 + 2) ints of scratch
  *   gwtf_enc_train_backward_top  dA2 (B,256,N) = (M a_2 + v + extra) masked by a_2 > 0; mconst = v [256] | {2^-k};
- *                                sums [64][3][256] += {sum gm_2, sum gm_2 yhat_2, sum a_2}; gmax2[0] = max |dA2| */
+ *                                sums [64][3][256] += {sum gm_2, sum gm_2 yhat_2, sum a_2}; gmax2[0] = max |dA2|;
+ *                                a2rows [B][512][256] (out): row slot_of[b][n] of shape b = a_2(b, :, n) of every arg-max point n,
+ *                                point-major (the kernel has them in registers; other rows are not written) */
 int gwtf_enc_train_pack_matrix(const float* W, float* units, int rows, int kdim, void* stream);
 int gwtf_enc_train_top_scatter(const float* coef, const int* amax, const float* W3, float* extra, int* slot_of, int* tables,
                                int B, int N, void* stream);
 int gwtf_enc_train_backward_top(const float* y2, const float* aff2, const float* units_m, const float* mconst, const float* extra,
-                                const int* slot_of, float* dA2, float* sums, float* gmax2, int B, int N, void* stream);
+                                const int* slot_of, float* dA2, float* sums, float* gmax2, float* a2rows, int B, int N, void* stream);
 /* layer = 1, 2: dA_prev (B, C[layer], N) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
  * (y_l, up_g = masked dL/da_layer).  y_prev / aff_prev: y_{layer-1} and its aff (layer 1: x, aff_0, and w0 = raw W_0).
  * sums [64][2 (layer 1: 5)][C[layer]] += {sum gm, sum gm yhat (layer 1: , sum gm x_d)} of the layer below;
@@ -454,11 +459,12 @@ int gwtf_enc_train_backward(int layer, const float* y_l, const float* up_g, cons
 size_t gwtf_enc_train_dw_partial_floats(int layer, int B, int N);
 int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const float* bconst, const float* y_prev,
                       const float* tab_prev, float* partials, float* dW, int B, int N, void* stream);
-/* layer 3 through the Gram matrix: gram (256,256) = sum_p a_2 a_2^T, S (512,256)[c] = sum_b gp[b][c] a_2(b, amax[b][c]); then
+/* layer 3 through the Gram matrix: gram (256,256) = sum_p a_2 a_2^T, S (512,256)[c] = sum_b gp[b][c] a_2(b, amax[b][c]) (read from
+ * a2rows / slot_of as gwtf_enc_train_backward_top and gwtf_enc_train_top_scatter left them: call those first); then
  * dW_3 = s (.) S + Q (.) (W_3 gram) + R (x) sum_p a_2  (s, Q, R = bconst of layer 3; sum_p a_2 = row 2 of the sums that
  * gwtf_enc_train_backward_top accumulates). */
-int gwtf_enc_train_dw3(const float* gp, const int* amax, const float* y2, const float* aff2, float* partials, float* gram,
-                       float* S, int B, int N, void* stream);
+int gwtf_enc_train_dw3(const float* gp, const int* amax, const int* slot_of, const float* a2rows, const float* y2, const float* aff2,
+                       float* partials, float* gram, float* S, int B, int N, void* stream);
 
 /* Global prior flow on the shape latent: the whole GlobalRNVPDecoder (lib/networks/decoders.py:7-38; RealNVPFlowCouple /
  * RealNVPFlow, flows.py:163-243) as ONE launch per direction -- forward (the lists the reference returns) and backward

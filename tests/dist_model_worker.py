@@ -44,10 +44,20 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     D = np.load(os.path.join(GOLDEN, 'g13_full_model.npz'))
     g_all, p_all, noise = (torch.from_numpy(D[k]).cuda() for k in ('gcloud', 'pcloud', 'noise_g'))
+    rows = int(os.environ.get('GWTF_ROWS', '0'))
+    if rows:
+        # a batch beyond 128 shapes (e.g. 96 per rank): every per-shape module sees the gathered rows of both ranks, which the HIP
+        # kernels walk in row blocks (csrc/gwtf_heads.hip, gwtf_prior.hip, gwtf_film_train.hip) -- no library fallback
+        rng = np.random.default_rng(4242)
+        mk = lambda *s: torch.from_numpy(rng.standard_normal(s).astype(np.float32)).cuda()
+        g_all, p_all, noise = 0.5 * mk(rows, 3, g_all.shape[2]), 0.5 * mk(rows, 3, p_all.shape[2]), mk(rows, noise.shape[1])
     B = g_all.shape[0]
     b0, b1 = shard_bounds(B, rank, world)
     m, cfg = build()
     m = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+    if rows:
+        assert m.g_prior._fused_ok(torch.zeros(b1 - b0, cfg['g_latent_space_size'], device='cuda'), rows)
+        assert m.g_posterior._hip_layers(torch.zeros(rows, cfg['pc_enc_n_features'][-1], device='cuda')) is not None
     loss = step(m, cfg, g_all[b0:b1], p_all[b0:b1], noise[b0:b1])
     all_reduce_gradients(m, average=True)
     grads = torch.cat([q.grad.reshape(-1) for q in m.parameters() if q.grad is not None])

@@ -253,13 +253,15 @@ def test_training_loop_reduces_the_loss_eager_and_graphed():
     assert abs(finals[0] - finals[1]) < 0.25 * abs(finals[0])      # same regime (the noise draws differ between the two runs)
 
 
-def test_two_rank_whole_model_training_step_matches_single_process(tmp_path):
+@pytest.mark.parametrize('rows', [0, 192], ids=['g13', '96rows_per_rank'])
+def test_two_rank_whole_model_training_step_matches_single_process(tmp_path, rows):
     """Data-parallel semantics of the WHOLE model (reference train_ae.py:152-153: SyncBatchNorm + averaged gradients): two ranks
     with half of the batch each == one process with the whole batch -- the encoder's train pipeline, the K-batched decoder
-    pipeline, the FiLM heads over the all-gathered latents, the prior flow and the per-shape heads all in one step."""
+    pipeline, the FiLM heads over the all-gathered latents, the prior flow and the per-shape heads all in one step.
+    rows = 192: 96 shapes per rank, so that every per-shape module sees MORE than 128 gathered rows (the kernels' row blocks)."""
     import subprocess
     import sys
-    env = dict(os.environ, GWTF_TMP=str(tmp_path), MASTER_ADDR='127.0.0.1')
+    env = dict(os.environ, GWTF_TMP=str(tmp_path), MASTER_ADDR='127.0.0.1', GWTF_ROWS=str(rows))
     port = 29800 + os.getpid() % 1000
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.join(os.path.dirname(__file__), 'dist_model_worker.py')]

@@ -147,8 +147,12 @@ ms = timed(step, a.steps)
 pts = a.batch * a.points * WORLD
 say(f'ranks: {WORLD}  per-rank batch: {a.batch}  sharded path: {sharded()}')
 _rows = a.batch * (WORLD if sharded() else 1)      # rows the per-shape modules see (all ranks' rows when data parallel)
-say(f'per-shape modules: rows={_rows} film_heads={"hip" if _rows <= 128 else "library"} heads={"hip" if _rows <= 128 else "library"} '
-    f'prior_flow={"hip" if _rows <= 128 else "library"}')
+_Gl = CFG['g_latent_space_size']
+_heads_hip = all(m._hip_layers(torch.zeros(_rows, m.features[0].weight.shape[1] if m.n_layers else 1, device='cuda')) is not None
+                 for m in (model.g_posterior, model.p_prior) if m.n_layers)
+_prior_hip = model.g_prior._fused_ok(torch.zeros(a.batch, _Gl, device='cuda'), _rows)
+# (the FiLM heads under autograd have no library path left: autograd.train_density_forward_multi always runs csrc/gwtf_film_train.hip)
+say(f'per-shape modules: rows={_rows} film_heads=hip heads={"hip" if _heads_hip else "library"} prior_flow={"hip" if _prior_hip else "library"}')
 say(f'eager   : {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s (each point through all {CFG["n_components"]} components)')
 if a.graph:
     s = torch.cuda.Stream()

@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/t1
-timeout -k 10 900 python -m pytest tests/test_gpu_heads.py tests/test_gpu_prior.py tests/test_gpu_film_heads.py -q 2>&1 | tail -15 > gpurun_out/t1/pytest_rows.txt
-cat gpurun_out/t1/pytest_rows.txt
+timeout -k 10 600 python -m pytest tests/test_gpu_encoder.py -x -q 2>&1 | tail -3
+bash tools/enc_kstats.sh 2>&1 | tail -24
+for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 2>&1 | grep -E "hipGraph"; done
