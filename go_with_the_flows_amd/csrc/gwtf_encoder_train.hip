@@ -30,6 +30,9 @@
 #include <hip/hip_runtime.h>
 #include "gwtf_device.h"
 
+#ifndef GWTF_ENC_DBG
+#define GWTF_ENC_DBG 0      // timing experiments only (tools/ab_build.sh): 1 no dA stores, 2 no epilogue loads, 3 no prologue loads
+#endif
 using namespace gwtf_dev;
 
 namespace {
@@ -237,13 +240,13 @@ __device__ __forceinline__ unsigned long long argmax_key(unsigned ordered, int n
 // code only needs max_n y and min_n y per (shape, channel) (which one: the sign of s, known after the fold): 64-bit keys
 // (order-preserving bits of y | inverted point index) combined by integer max -- DPP row max to find the candidates, one
 // exec-masked LDS atomic per (row, tile), one global atomic per (workgroup, channel).
-template <int CIN, int COUT, bool FIRST, bool LAST>
-__global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __restrict__ in, const float* __restrict__ in_tab,
+template <int CIN, int COUT, bool FIRST, bool LAST, int NB>
+__global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kernel(const float* __restrict__ in, const float* __restrict__ in_tab,
                                                                  const float* __restrict__ units, float* __restrict__ y_out,
                                                                  float* __restrict__ sums, float* __restrict__ ymax,
                                                                  unsigned long long* __restrict__ kmax,
                                                                  unsigned long long* __restrict__ kmin, int B, int N) {
-  constexpr int NB = 2, KS = CIN / 32, MT = COUT / 16, TM = 16 / KS, NCH = MT / TM;
+  constexpr int KS = CIN / 32, MT = COUT / 16, TM = 16 / KS, NCH = MT / TM;
   static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
   __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
   __shared__ __attribute__((aligned(16))) float tab[FIRST ? 4 * CIN : 2 * CIN];
@@ -251,7 +254,7 @@ __global__ __launch_bounds__(kThreads) void enc_train_fwd_kernel(const float* __
   __shared__ float wmax[8];
   __shared__ unsigned long long wkey[LAST ? 2 * COUT : 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
-  const int b = blockIdx.y, n_wave0 = blockIdx.x * 256 + wave * 32;
+  const int b = blockIdx.y, n_wave0 = blockIdx.x * (128 * NB) + wave * 16 * NB;
   if (LAST)
     for (int t = tid; t < 2 * COUT; t += kThreads) wkey[t] = 0ull;
 
@@ -694,8 +697,12 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const size_t idx = ((size_t)b * COUT + c0 + r) * N + n[nb];
+#if GWTF_ENC_DBG == 3
+          const float yv = 1.0f + (float)idx * 1e-9f, gm = 0.5f;
+#else
           const float yv = valid[nb] ? y_l[idx] : 0.f;
           const float gm = valid[nb] ? up_g[idx] : 0.f;
+#endif
           d[r] = valid[nb] ? fmaf(s4[r], gm, fmaf(q4[r], yv, r4[r])) : 0.f;
         }
         split_into<false>(d, bhi[ks][nb], blo[ks][nb], half);
@@ -745,13 +752,21 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
             const f32x4 w = *reinterpret_cast<const f32x4*>(&w0s[4 * j]);
             yv = w[0] * px[nb] + (w[1] * py[nb] + w[2] * pz[nb]);
           } else {
+#if GWTF_ENC_DBG == 2
+            yv = 1.0f;
+#else
             yv = valid[nb] ? y_prev[((size_t)b * CIN + j) * N + n[nb]] : 0.f;
+#endif
           }
           const float pre = fmaf(sp[r], yv, tp[r]);
           const bool on = valid[nb] && pre > 0.f;
           const float gm = on ? (TOP ? fmaf(acc[nb][r], down, bc[j] + ex[nb][r]) : acc[nb][r] * down) : 0.f;
           if (TOP) sx0 += on ? pre : 0.f;                  // sum_p a_{l-1}: the R term of dW_3 (gwtf_enc_train_dw3)
+#if GWTF_ENC_DBG == 1
+          if (!BOTTOM && valid[nb] && gm == 123.456f) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
+#else
           if (!BOTTOM && valid[nb]) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
+#endif
           sb += gm;
           sg = fmaf(gm, (yv - mp[r]) * rp[r], sg);
           if (BOTTOM) {
@@ -1036,6 +1051,17 @@ __global__ __launch_bounds__(256) void enc_dw_reduce_kernel(const float* __restr
 #define GWTF_ENC_NBT 2
 #endif
 constexpr int kNB2 = GWTF_ENC_NB2, kNB1 = GWTF_ENC_NB1, kNBT = GWTF_ENC_NBT;
+// the same for the forward kernels (layers 1, 2, 3)
+#ifndef GWTF_ENC_NF1
+#define GWTF_ENC_NF1 2
+#endif
+#ifndef GWTF_ENC_NF2
+#define GWTF_ENC_NF2 2
+#endif
+#ifndef GWTF_ENC_NF3
+#define GWTF_ENC_NF3 2
+#endif
+constexpr int kNF1 = GWTF_ENC_NF1, kNF2 = GWTF_ENC_NF2, kNF3 = GWTF_ENC_NF3;
 int dw_slices_per_shape(int layer) { return layer == 1 ? 8 : 4; }
 int dw_per(int layer, int N) {
   const int nsl = dw_slices_per_shape(layer);
@@ -1120,11 +1146,12 @@ extern "C" int gwtf_enc_train_forward(int layer, const float* in, const float* i
                                       void* stream) {
   if (!in || !in_tab || !units || !sums || !ymax || B <= 0 || N <= 0 || layer < 1 || layer > 3) return GWTF_E_BADARG;
   if (layer < 3 ? !y_out : (!kmax || !kmin)) return GWTF_E_BADARG;
-  const dim3 grid((N + 255) / 256, B), block(kThreads);
+  const dim3 block(kThreads);
+  auto grid = [&](int nb) { return dim3((N + 128 * nb - 1) / (128 * nb), B); };
   hipStream_t st = (hipStream_t)stream;
-  if (layer == 1) hipLaunchKernelGGL((enc_train_fwd_kernel<64, 128, true, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
-  else if (layer == 2) hipLaunchKernelGGL((enc_train_fwd_kernel<128, 256, false, false>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
-  else hipLaunchKernelGGL((enc_train_fwd_kernel<256, 512, false, true>), grid, block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
+  if (layer == 1) hipLaunchKernelGGL((enc_train_fwd_kernel<64, 128, true, false, kNF1>), grid(kNF1), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
+  else if (layer == 2) hipLaunchKernelGGL((enc_train_fwd_kernel<128, 256, false, false, kNF2>), grid(kNF2), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
+  else hipLaunchKernelGGL((enc_train_fwd_kernel<256, 512, false, true, kNF3>), grid(kNF3), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
   return (int)hipGetLastError();
 }
 

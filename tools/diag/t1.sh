@@ -1,2 +1,2 @@
-mkdir -p gpurun_out/t1
-timeout -k 10 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 | tee gpurun_out/t1/pytest.txt
+for d in 1 2 3; do echo "== DBG $d"; bash tools/enc_kstats.sh --parts e --lib build_ab/libgwtf_encdbg$d.so 2>&1 | grep -E "bwd_kernel"; done
+echo "== base"; bash tools/enc_kstats.sh --parts e 2>&1 | grep -E "bwd_kernel"
