@@ -116,26 +116,47 @@ def reset_row_layouts():
     _ROW_LAYOUTS.clear()
 
 
+_ROW_CHECK = {'calls': 0}
+
+
+def _exchange_sizes(rows, device, world, rank):
+    on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
+    sizes = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([int(rows)], dtype=torch.int64, device=on))
+    return RowLayout([int(x.item()) for x in sizes], rank)
+
+
 def row_layout(rows, device):
     """The number of rows every rank of the default group holds, given that this rank holds `rows`.  Collective on first
-    use of a value of `rows` (every rank must call it then), cached afterwards."""
+    use of a value of `rows` (every rank must call it then), cached afterwards.  The cache is keyed by THIS rank's row count,
+    so a batch size that changes on some other rank only (a loader without drop_last, an evaluation pass) would go unnoticed:
+    the model's train() / eval() transitions call reset_row_layouts(), and outside hipGraph captures every
+    GWTF_ROW_LAYOUT_CHECK_EVERY-th lookup (default 64; 0 = never) exchanges the sizes again and raises on a mismatch.  A
+    captured step cannot check: its loader must keep the per-rank batch fixed (the reference's loaders use drop_last=True)."""
     if not (dist.is_available() and dist.is_initialized()):
         return RowLayout([rows], 0)
     world, rank = dist.get_world_size(), dist.get_rank()
     key = (world, rank, int(rows))
     lay = _ROW_LAYOUTS.get(key)
+    capturing = device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
     if lay is None:
         if world == 1:
             lay = RowLayout([rows], 0)
         else:
-            if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise RuntimeError('the per-rank batch sizes are exchanged on the first step with a given batch size: run one '
                                    'step outside the hipGraph capture first (GraphedTrainStep does)')
-            on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
-            sizes = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
-            dist.all_gather(sizes, torch.tensor([int(rows)], dtype=torch.int64, device=on))
-            lay = RowLayout([int(x.item()) for x in sizes], rank)
+            lay = _exchange_sizes(rows, device, world, rank)
         _ROW_LAYOUTS[key] = lay
+    elif world > 1 and not capturing and int(os.environ.get('GWTF_ROW_LAYOUT_CHECK_EVERY', '64')) > 0:
+        # (the lookup count advances identically on every rank: the lookups are the model's per-step calls)
+        _ROW_CHECK['calls'] += 1
+        if _ROW_CHECK['calls'] % int(os.environ.get('GWTF_ROW_LAYOUT_CHECK_EVERY', '64')) == 0:
+            now = _exchange_sizes(rows, device, world, rank)
+            if now.sizes != lay.sizes:
+                _ROW_LAYOUTS.clear()
+                raise RuntimeError(f'per-rank batch sizes changed from {lay.sizes} to {now.sizes} while this rank kept {rows} rows: '
+                                   'call dist.reset_row_layouts() on every rank when any rank\'s batch size changes')
     return lay
 
 

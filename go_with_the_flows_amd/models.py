@@ -66,6 +66,14 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
         return LocalCondRNVPDecoder(self.p_decoder_n_flows, self.p_decoder_n_features, self.g_latent_space_size,
                                     weight_std=0.01)
 
+    def train(self, mode=True):
+        """nn.Module.train + the data-parallel row-layout cache is dropped on a train <-> eval transition (an evaluation pass
+        usually runs another per-rank batch size; dist.row_layout caches per-rank sizes by THIS rank's size only)."""
+        if bool(mode) != self.training:
+            from .dist import reset_row_layouts
+            reset_row_layouts()
+        return super().train(mode)
+
     def reparameterize(self, mu, logvar):
         """mu + exp(0.5 logvar) * N(0,1)   (models.py:99-109; torch RNG of the tensors' device)."""
         std = torch.exp(0.5 * logvar)

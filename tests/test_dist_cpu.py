@@ -193,3 +193,36 @@ def test_data_parallel_wrapper_starts_every_rank_from_rank0_state(world):
     reference sets no seed, so the hand-rolled reducer must do the same or ranks train different models with averaged gradients."""
     port = 31500 + os.getpid() % 2000 + world
     mp.spawn(_state_worker, args=(world, port), nprocs=world, join=True)
+
+
+def _row_layout_worker(rank, world, port):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      GWTF_ROW_LAYOUT_CHECK_EVERY='4')
+    from go_with_the_flows_amd import dist as gd
+    gd.init_from_env('gloo')
+    cpu = torch.device('cpu')
+    lay = gd.row_layout(5, cpu)                       # both ranks hold 5 rows: exchanged once, cached
+    assert lay.sizes == [5, 5] and lay.total == 10 and lay.row0 == 5 * rank
+    for _ in range(3):
+        assert gd.row_layout(5, cpu) is lay           # cached lookups (no collective)
+    assert gd.row_layout(5, cpu) is lay               # 4th cached lookup: sizes exchanged again, still equal
+    # rank 1's loader now delivers 3 rows while rank 0 keeps 5: rank 0's cache key (its own 5 rows) is unchanged -- without the
+    # periodic check it would go on slicing with the stale layout.  Rank 1 has no entry for 3 rows and exchanges at once; rank 0
+    # joins that exchange with its 4th lookup since the last check and raises.
+    if rank == 1:
+        assert gd.row_layout(3, cpu).sizes == [5, 3]
+    else:
+        for _ in range(3):
+            gd.row_layout(5, cpu)
+        with pytest.raises(RuntimeError, match='per-rank batch sizes changed'):
+            gd.row_layout(5, cpu)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_layout_cache_notices_a_batch_size_change_on_another_rank():
+    """the per-rank row counts are cached by THIS rank's count only; a periodic re-exchange outside graph captures
+    turns a silent stale layout into an error."""
+    port = 29500 + (os.getpid() + 977) % 2000
+    mp.spawn(_row_layout_worker, args=(2, port), nprocs=2, join=True)
