@@ -721,6 +721,28 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 
   int g = 0;
   float gmx = 0.f;
+  // The epilogue of a row tile needs y_prev at (row, point) -- the mask a_{l-1} > 0 and the BatchNorm-backward sum -- and, for
+  // the top layer, the arg-max row of the point.  Loaded where they are used, every tile waited for its own round trip (38 - 47 us
+  // of a 160 us kernel: docs/LOG.md, ablation); they are fetched one tile AHEAD instead, behind the previous tile's product.
+  float yv_cur[4][NB], yv_nxt[4][NB];
+  f32x4 ex_cur[NB], ex_nxt[NB];
+  auto fetch_tile = [&](int m, float (&yv)[4][NB], f32x4 (&ex)[NB]) {
+    const int j0 = 16 * m + 4 * q;
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+      ex[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (TOP && slot[nb] >= 0) ex[nb] = *reinterpret_cast<const f32x4*>(&gp[((size_t)b * ex_rows + slot[nb]) * CIN + j0]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+#if GWTF_ENC_DBG == 2
+        yv[r][nb] = 1.0f;
+#else
+        yv[r][nb] = (!BOTTOM && valid[nb]) ? y_prev[((size_t)b * CIN + j0 + r) * N + n[nb]] : 0.f;
+#endif
+      }
+    }
+  };
+  fetch_tile(0, yv_cur, ex_cur);
 #pragma unroll 1
   for (int ci = 0; ci < NCH; ++ci) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -731,16 +753,11 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       const int m = ci * TM + t, j0 = 16 * m + 4 * q;
+      if (m + 1 < MT) fetch_tile(m + 1, yv_nxt, ex_nxt);
       f32x4 acc[NB];
       tile_mfma<KS, NB>(L + t * KS * 512, lane, bhi, blo, acc);
       const f32x4 sp = *reinterpret_cast<const f32x4*>(&ap[j0]), tp = *reinterpret_cast<const f32x4*>(&ap[CIN + j0]),
                   mp = *reinterpret_cast<const f32x4*>(&ap[2 * CIN + j0]), rp = *reinterpret_cast<const f32x4*>(&ap[3 * CIN + j0]);
-      f32x4 ex[NB];
-#pragma unroll
-      for (int nb = 0; nb < NB; ++nb) {     // TOP: the arg-max rows of this point (`gp` carries `extra`)
-        ex[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (TOP && slot[nb] >= 0) ex[nb] = *reinterpret_cast<const f32x4*>(&gp[((size_t)b * ex_rows + slot[nb]) * CIN + j0]);
-      }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int j = j0 + r;
@@ -752,15 +769,11 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
             const f32x4 w = *reinterpret_cast<const f32x4*>(&w0s[4 * j]);
             yv = w[0] * px[nb] + (w[1] * py[nb] + w[2] * pz[nb]);
           } else {
-#if GWTF_ENC_DBG == 2
-            yv = 1.0f;
-#else
-            yv = valid[nb] ? y_prev[((size_t)b * CIN + j) * N + n[nb]] : 0.f;
-#endif
+            yv = yv_cur[r][nb];
           }
           const float pre = fmaf(sp[r], yv, tp[r]);
           const bool on = valid[nb] && pre > 0.f;
-          const float gm = on ? (TOP ? fmaf(acc[nb][r], down, bc[j] + ex[nb][r]) : acc[nb][r] * down) : 0.f;
+          const float gm = on ? (TOP ? fmaf(acc[nb][r], down, bc[j] + ex_cur[nb][r]) : acc[nb][r] * down) : 0.f;
           if (TOP) sx0 += on ? pre : 0.f;                  // sum_p a_{l-1}: the R term of dW_3 (gwtf_enc_train_dw3)
 #if GWTF_ENC_DBG == 1
           if (!BOTTOM && valid[nb] && gm == 123.456f) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
@@ -794,6 +807,12 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
             atomicAdd(&wsum[4][j], sx2);
           }
         }
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        ex_cur[nb] = ex_nxt[nb];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) yv_cur[r][nb] = yv_nxt[r][nb];
       }
     }
   }
