@@ -78,7 +78,7 @@ _SIGNATURES = {
     'gwtf_enc_train_xmoments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_fold0': (ctypes.c_int, [_c_fp, ctypes.c_double] + [_c_fp] * 5 + [ctypes.c_float, _c_fp, _c_fp, _c_fp]),
     'gwtf_enc_train_fold': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 4 + [ctypes.c_float, _c_fp, _c_fp, _c_fp]),
-    'gwtf_enc_train_forward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 8 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_forward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 9 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_pool': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_pack_matrix': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_top_scatter': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),

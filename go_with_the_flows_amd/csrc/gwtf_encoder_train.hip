@@ -245,18 +245,23 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
                                                                  const float* __restrict__ units, float* __restrict__ y_out,
                                                                  float* __restrict__ sums, float* __restrict__ ymax,
                                                                  unsigned long long* __restrict__ kmax,
-                                                                 unsigned long long* __restrict__ kmin, int B, int N) {
+                                                                 unsigned long long* __restrict__ kmin, int B, int N,
+                                                                 const float* __restrict__ gamma_out) {
   constexpr int KS = CIN / 32, MT = COUT / 16, TM = 16 / KS, NCH = MT / TM;
   static_assert(16 % KS == 0 && MT % TM == 0, "whole chunks");
   __shared__ __attribute__((aligned(16))) float lds[2][kChunk];
   __shared__ __attribute__((aligned(16))) float tab[FIRST ? 4 * CIN : 2 * CIN];
   __shared__ float wsum[2][COUT];
   __shared__ float wmax[8];
-  __shared__ unsigned long long wkey[LAST ? 2 * COUT : 1];
+  __shared__ unsigned long long wkey[LAST ? COUT : 1];
+  __shared__ float wsgn[LAST ? COUT : 1];     // LAST: -1 where this layer's BatchNorm weight is negative (the pooled extreme is the MINIMUM of y there)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, q = lane >> 4;
   const int b = blockIdx.y, n_wave0 = blockIdx.x * (128 * NB) + wave * 16 * NB;
   if (LAST)
-    for (int t = tid; t < 2 * COUT; t += kThreads) wkey[t] = 0ull;
+    for (int t = tid; t < COUT; t += kThreads) {
+      wkey[t] = 0ull;
+      wsgn[t] = gamma_out[t] < 0.f ? -1.0f : 1.0f;
+    }
 
   auto stage = [&](int buf, int g) {
 #pragma unroll
@@ -355,19 +360,21 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
           atomicAdd(&wsum[1][ch], s2);
         }
         if (LAST) {
-          // this lane's best (largest / smallest) of its NB points, then the row's; only the lanes that hold it touch the LDS
-          const float big = 3.0e38f;
-          float hi = -big, lo = big;
-          int nhi = 0, nlo = 0;
+          // BatchNorm + ReLU + max over the points is monotone in y per channel, rising or falling with the sign of s = gamma rstd,
+          // i.e. of the layer's BatchNorm weight, known before the pass: only ONE extreme per channel is tracked -- the maximum of
+          // sgn y (the first version tracked maximum and minimum and let the fold choose: twice the select / DPP / atomic work in a
+          // kernel whose epilogue, not its MFMAs, sets the time).  This lane's best of its NB points, then the row's; only the lanes
+          // that hold it touch the LDS.
+          const float big = 3.0e38f, sgn = wsgn[ch];
+          float hi = -big;
+          int nhi = 0;
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
-            const float v = acc[nb][r];
+            const float v = acc[nb][r] * sgn;
             if (valid[nb] && v > hi) { hi = v; nhi = n[nb]; }
-            if (valid[nb] && v < lo) { lo = v; nlo = n[nb]; }
           }
-          const float rhi = row_max16(hi), rlo = -row_max16(-lo);
+          const float rhi = row_max16(hi);
           if (hi == rhi && hi > -big) atomicMax(&wkey[ch], argmax_key(ordered_bits(hi), nhi));
-          if (lo == rlo && lo < big) atomicMax(&wkey[COUT + ch], argmax_key(~ordered_bits(lo), nlo));
         }
       }
     }
@@ -379,8 +386,10 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
   for (int t = tid; t < 2 * COUT; t += kThreads) atomicAdd(&dst[t], (&wsum[0][0])[t]);
   if (LAST)
     for (int t = tid; t < COUT; t += kThreads) {
-      atomicMax(&kmax[(size_t)b * COUT + t], wkey[t]);
-      atomicMax(&kmin[(size_t)b * COUT + t], wkey[COUT + t]);
+      // maximum of y where gamma >= 0 (kmax), minimum where gamma < 0 (kmin; the key of -y is the key enc_pool_finalize_kernel
+      // decodes for a minimum: ordered_bits(-y) == ~ordered_bits(y))
+      unsigned long long* dstk = wsgn[t] < 0.f ? kmin : kmax;
+      atomicMax(&dstk[(size_t)b * COUT + t], wkey[t]);
     }
   if (tid == 0) {
     float m = wmax[0];
@@ -1161,16 +1170,16 @@ extern "C" int gwtf_enc_train_fold(const float* sums, int layer, double n_total,
 }
 
 extern "C" int gwtf_enc_train_forward(int layer, const float* in, const float* in_tab, const float* units, float* y_out,
-                                      float* sums, float* ymax, unsigned long long* kmax, unsigned long long* kmin, int B, int N,
-                                      void* stream) {
+                                      float* sums, float* ymax, unsigned long long* kmax, unsigned long long* kmin,
+                                      const float* gamma3, int B, int N, void* stream) {
   if (!in || !in_tab || !units || !sums || !ymax || B <= 0 || N <= 0 || layer < 1 || layer > 3) return GWTF_E_BADARG;
-  if (layer < 3 ? !y_out : (!kmax || !kmin)) return GWTF_E_BADARG;
+  if (layer < 3 ? !y_out : (!kmax || !kmin || !gamma3)) return GWTF_E_BADARG;
   const dim3 block(kThreads);
   auto grid = [&](int nb) { return dim3((N + 128 * nb - 1) / (128 * nb), B); };
   hipStream_t st = (hipStream_t)stream;
-  if (layer == 1) hipLaunchKernelGGL((enc_train_fwd_kernel<64, 128, true, false, kNF1>), grid(kNF1), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
-  else if (layer == 2) hipLaunchKernelGGL((enc_train_fwd_kernel<128, 256, false, false, kNF2>), grid(kNF2), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
-  else hipLaunchKernelGGL((enc_train_fwd_kernel<256, 512, false, true, kNF3>), grid(kNF3), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N);
+  if (layer == 1) hipLaunchKernelGGL((enc_train_fwd_kernel<64, 128, true, false, kNF1>), grid(kNF1), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N, gamma3);
+  else if (layer == 2) hipLaunchKernelGGL((enc_train_fwd_kernel<128, 256, false, false, kNF2>), grid(kNF2), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N, gamma3);
+  else hipLaunchKernelGGL((enc_train_fwd_kernel<256, 512, false, true, kNF3>), grid(kNF3), block, 0, st, in, in_tab, units, y_out, sums, ymax, kmax, kmin, B, N, gamma3);
   return (int)hipGetLastError();
 }
 

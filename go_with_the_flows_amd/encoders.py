@@ -85,7 +85,8 @@ class _EncoderTrainFn(torch.autograd.Function):
                 sums = torch.zeros(R, 2, C[l + 1], **f32)
                 check(L.gwtf_enc_train_forward(l, P(x if l == 1 else ys[l - 1]), P(table0 if l == 1 else aff[l - 1]),
                                                P(units_f[l]), P(y), P(sums), P(ymax[l:l + 1]),
-                                               keys[0].data_ptr() if l == 3 else 0, keys[1].data_ptr() if l == 3 else 0, B, N, st))
+                                               keys[0].data_ptr() if l == 3 else 0, keys[1].data_ptr() if l == 3 else 0,
+                                               P(gam[3]) if l == 3 else 0, B, N, st))
                 check(L.gwtf_enc_train_fold(P(over_ranks(sums.sum(0))), l, n_total, P(gam[l]), P(bet[l]), P(rm[l]), P(rv[l]),
                                             float(bns[l].momentum), P(aff[l]), P(aff[l - 1]), st))
                 ys.append(y)

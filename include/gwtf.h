@@ -417,10 +417,13 @@ int gwtf_enc_train_fold(const float* sums, int layer, double n_total, const floa
                         void* stream);
 /* y_out (B, C[layer+1], N) = W_layer . relu(s in + t); in = x and in_tab = table0 for layer 1, else y_{layer-1} and its aff.
  * sums [64][2][C[layer+1]] += {sum y, sum y^2}; ymax[0] = max |y| (bit pattern max, zero on entry).
- * layer 3 stores no y: kmax / kmin [B][512] (zero on entry) receive 64-bit arg-max / arg-min keys of y_3 per (shape, channel) --
- * all the max-pool needs, because BatchNorm + ReLU is monotone in y per channel (y_out may be NULL; kmax / kmin NULL otherwise) */
+ * layer 3 stores no y: kmax / kmin [B][512] (zero on entry) receive the 64-bit arg-max (channels with BatchNorm weight gamma3 >= 0)
+ * or arg-min (gamma3 < 0) key of y_3 per (shape, channel) -- all the max-pool needs, because BatchNorm + ReLU is monotone in y per
+ * channel, rising or falling with the sign of gamma3 (the other array's entry stays zero; y_out may be NULL; kmax / kmin / gamma3
+ * NULL for layers 1, 2) */
 int gwtf_enc_train_forward(int layer, const float* in, const float* in_tab, const float* units, float* y_out, float* sums,
-                           float* ymax, unsigned long long* kmax, unsigned long long* kmin, int B, int N, void* stream);
+                           float* ymax, unsigned long long* kmax, unsigned long long* kmin, const float* gamma3, int B, int N,
+                           void* stream);
 /* pooled (B,512) = max_n relu(s y3 + t) from the keys (max or min by the sign of s), amax = its first arg-max, ystar = y3 there;
  * NaN where a statistic or the extreme is not finite */
 int gwtf_enc_train_pool(const unsigned long long* kmax, const unsigned long long* kmin, const float* aff3, float* pooled, int* amax,

@@ -253,3 +253,34 @@ def test_train_pipeline_odd_shapes_against_library_path(B, N):
         assert float((p.grad - q.grad).abs().max()) < 2e-3 * gs + 1e-6, (B, N, name)
     for (name, a), b in zip(m.named_buffers(), lib.buffers()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5), name
+
+
+def test_train_pipeline_with_negative_batchnorm_weights_pools_the_minimum():
+    """BatchNorm + ReLU + max over the points falls with y where the layer's BatchNorm weight is negative: the top layer's forward kernel
+    tracks the arg-MIN of y for those channels (one extreme per channel, chosen by the sign of gamma).  Half of the top layer's (and some
+    of the lower layers') weights negated; outputs, arg-max gradients and running statistics against the library path."""
+    import copy
+    B, N, seed = 3, 700, 77
+    m = encoders.PointNetCloudEncoder(3, 64, [128, 256, 512])
+    load_synth_(m, seed)
+    with torch.no_grad():
+        for name, prm in m.named_parameters():
+            if name.endswith('_bn.weight'):
+                prm[::2].neg_()
+                if 'sd2' in name:
+                    prm[5] = 0.0                                    # a zero weight: the channel is constant, any point is "the" maximum
+    m = m.to(DEV).train()
+    x = dev(synth_inputs(B, N, 4, seed + 1)[0])
+    wgt = torch.randn(B, 512, device=DEV, generator=torch.Generator(DEV).manual_seed(seed))
+    lib = copy.deepcopy(m)
+    pooled = m.forward_max(x)
+    (pooled * wgt).sum().backward()
+    ref = torch.max(lib.features(x), dim=2)[0]
+    (ref * wgt).sum().backward()
+    scale = max(1.0, float(ref.detach().abs().max()))
+    assert float((pooled - ref).detach().abs().max()) < 5e-5 * scale
+    for (name, p), q in zip(m.named_parameters(), lib.parameters()):
+        gs = float(q.grad.abs().max()) + 1e-12
+        assert float((p.grad - q.grad).abs().max()) < 1e-3 * gs, name
+    for (name, a), b in zip(m.named_buffers(), lib.buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-4, atol=1e-5), name
