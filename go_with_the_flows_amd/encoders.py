@@ -132,7 +132,7 @@ class _EncoderTrainFn(torch.autograd.Function):
             check(L.gwtf_enc_train_top(P(g_pooled), P(pooled), P(b['ystar']), P(aff[3]), P(gp), P(red), P(gmax[3:4]), B, st))
             partials = torch.empty(max(L.gwtf_enc_train_dw_partial_floats(l, B, N) for l in (1, 2, 3)), **f32)
             # ---- layer 3 in the M form (csrc/gwtf_encoder_train.hip): dy_3 = s gm_3 + Q y_3 + R with y_3 = W_3 a_2 ----
-            grads[10], grads[11] = red[1].clone(), red[0].clone()
+            grads[10], grads[11] = red[1], red[0]            # (views of `red`: nothing writes it again; a clone each was 8 launches per step)
             bconst = torch.empty(3 * C[4] + 4, **f32)
             check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), 3, n_total, P(gam[3]), P(aff[3]), 0, 0, P(bconst), st))
             s3, q3, r3 = (bconst[i * C[4]:(i + 1) * C[4]] for i in range(3))
@@ -163,7 +163,7 @@ class _EncoderTrainFn(torch.autograd.Function):
                                        P(S), B, N, st))
             grads[9] = (s3[:, None] * S + q3[:, None] * (W3 @ gram) + r3[:, None] * red[2][None, :]).view_as(params[9])
             for l in (2, 1):
-                grads[3 * l + 1], grads[3 * l + 2] = red[1].clone(), red[0].clone()          # bn.weight, bn.bias of layer l
+                grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]                          # bn.weight, bn.bias of layer l
                 bconst = torch.empty(3 * C[l + 1] + 4, **f32)
                 check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), l, n_total, P(gam[l]), P(aff[l]),
                                                   P(gmax[l:l + 1]), P(b['ymax'][l:l + 1]), P(bconst), st))
@@ -179,7 +179,7 @@ class _EncoderTrainFn(torch.autograd.Function):
                 red = sums.sum(0)
                 up = dA
             # layer 0 (3 -> 64): every sum its gradient needs is already there
-            grads[1], grads[2] = red[1].clone(), red[0].clone()
+            grads[1], grads[2] = red[1], red[0]
             bconst = torch.empty(3 * C[1] + 4, **f32)
             check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), 0, n_total, P(gam[0]), P(aff[0]), 0, 0,
                                               P(bconst), st))

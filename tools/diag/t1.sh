@@ -1,1 +1,3 @@
-timeout -k 10 600 python -m pytest tests/test_gpu_encoder.py -x -q -k "negative" 2>&1 | tail -12
+timeout -k 10 600 python -m pytest tests/test_gpu_encoder.py tests/test_gpu_models.py -x -q 2>&1 | tail -3
+for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 2>&1 | grep -E "hipGraph"; done
+GWTF_FORCE_SHARDED=1 timeout -k 10 200 python tools/bench_train.py --graph --steps 30 2>&1 | grep -E "hipGraph"
