@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libgwtf_hip.so')
+LIB_PATH = os.environ.get('GWTF_LIB') or os.path.join(_HERE, 'libgwtf_hip.so')      # GWTF_LIB: an A/B build (tools/ab_build.sh)
 ABI_VERSION = 4
 
 MODE_DIRECT, MODE_INVERSE = 0, 1

@@ -25,6 +25,9 @@
 #include "gwtf_dw1.h"
 #include <algorithm>
 
+#ifndef GWTF_K2_MASK
+#define GWTF_K2_MASK 15     // A/B knob: which compile-time-pattern variants the launcher uses (1 / 2: light pass, one warped / one kept; 4 / 8: merged pass)
+#endif
 namespace {
 
 using namespace gwtf_dev;
@@ -52,8 +55,12 @@ struct BCfg {
 //              dy, the sd0 sums, dx, the dW1 partial -- ONCE on dy = dacc + gS + 2 gQ (acc - c) instead of once per path (both are
 //              linear in dy): per level one full pass and one forward-sized pass instead of two full ones, and one set of dW1 partials.
 // waves per SIMD the register allocation is held to: the LDS footprint admits three workgroups per CU up to FP = 48
+// K2: the warp pattern's number of kept coordinates known at compile time (1: two kept / ONE warped coordinate, patterns 0-2;
+// 0: one kept / two warped; -1: read from `pat`).  With one warped coordinate the second output column of sd2 does not exist: its
+// u_1 terms, its FiLM-record sum (one of three 16-lane reductions + LDS atomics per feature row in the light pass) and the second
+// tail slot fold away -- the train pipeline's launcher picks the variant per level (the pattern is a host-side fact).
 enum { BW_DIRECT = 0, BW_STATS = 1, BW_LIGHT = 2, BW_MERGED = 3 };
-template <int MB, int NB, int VAR, int MG = -1>
+template <int MB, int NB, int VAR, int MG = -1, int K2 = -1>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2 : (MB <= 3 ? 3 : 1)))) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
@@ -141,8 +148,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   }
   int k0, k1, w0, w1;
   gwtf_pattern_dims(pat, &k0, &k1, &w0, &w1);
-  const bool keep2 = pat < 3;
+  const bool keep2 = K2 < 0 ? pat < 3 : K2 == 1;
   const int nw = keep2 ? 1 : 2;
+#ifdef GWTF_NO_ONE_W
+  constexpr bool ONE_W = false;
+#else
+  constexpr bool ONE_W = K2 == 1;          // compile-time: one warped coordinate (everything with index 1 of a warped slot is absent)
+#endif
+  constexpr bool ONE_K = K2 == 0;          // compile-time: one kept coordinate (sd0 has ONE input: its second weight column, x_b and their sums are absent)
 
   for (int it = 0; it < tpw; ++it) {
   const int tile = tile0 + it;
@@ -183,7 +196,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
     f32x4 cinit[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) cinit[m] = STATS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(fe + 16 * m);
-    if (keep2) sd1_contract<MB, NB, true, MG>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
+    // The dispatch stays a RUN-TIME branch on `pat` even where K2 fixes the pattern at compile time: with a constant condition the
+    // contraction (its f16 splits are inline asm) is inlined into the surrounding basic block and the merged pass came out wrong
+    // (errors of 1e-4 .. O(1) in dL/dx at 128 x 2048, f = 37; the asm-hazard rule of docs/LOG.md: a value produced by inline asm is
+    // consumed in the block that produces it).
+    if (pat < 3) sd1_contract<MB, NB, true, MG>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
     else sd1_contract<MB, NB, false, MG>(L, br, kk_steps, lane, q, xa, xb, cinit, acc[br]);
     if (STATS) continue;
     float o0[NB], o1[NB];
@@ -199,11 +216,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
         for (int nb = 0; nb < NB; ++nb) {
           const float v = fmaxf(acc[br][m][nb][r], 0.f);
           o0[nb] = fmaf(u0[r], v, o0[nb]);
-          o1[nb] = fmaf(u1[r], v, o1[nb]);
+          if (!ONE_W) o1[nb] = fmaf(u1[r], v, o1[nb]);
         }
     }
     res[br][0] = quarter_reduce<NB>(o0, q);
-    res[br][1] = quarter_reduce<NB>(o1, q);
+    if (!ONE_W) res[br][1] = quarter_reduce<NB>(o1, q);
   }
   const f32x4 bias = STATS ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(L + K::PW + 6 * FP);
   const float s_keep = sqrtf(eps + 1.0f);
@@ -294,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
       d0[nb] = __shfl(dt[br][0], 16 * nb + i16);
-      d1[nb] = __shfl(dt[br][1], 16 * nb + i16);
+      d1[nb] = ONE_W ? 0.f : __shfl(dt[br][1], 16 * nb + i16);
     }
     const float* fe = L + K::PW + br * 3 * FP + 4 * q;
 #pragma unroll
@@ -322,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           for (int nb = 0; nb < NB; ++nb) {
             const int n = n_wave0 + 16 * nb + i16;
             const float a = acc[br][m][nb][r];
-            const float da = a > 0.f ? fmaf(u0[r], d0[nb], u1[r] * d1[nb]) : 0.f;
+            const float da = a > 0.f ? (ONE_W ? u0[r] * d0[nb] : fmaf(u0[r], d0[nb], u1[r] * d1[nb])) : 0.f;
             acc[br][m][nb][r] = n < N ? da + fmaf(gq2, a - cc, gs) : 0.f;
           }
           continue;
@@ -333,18 +350,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           const float a = acc[br][m][nb][r];
           const float z = fmaxf(a, 0.f);
           sdu0 = fmaf(d0[nb], z, sdu0);
-          sdu1 = fmaf(d1[nb], z, sdu1);
-          const float da = a > 0.f ? fmaf(u0[r], d0[nb], u1[r] * d1[nb]) : 0.f;
+          if (!ONE_W) sdu1 = fmaf(d1[nb], z, sdu1);
+          const float da = a > 0.f ? (ONE_W ? u0[r] * d0[nb] : fmaf(u0[r], d0[nb], u1[r] * d1[nb])) : 0.f;
           sdc += da;
           acc[br][m][nb][r] = da;
         }
         sdc = row_sum16(sdc);
         sdu0 = row_sum16(sdu0);
-        sdu1 = row_sum16(sdu1);
+        if (!ONE_W) sdu1 = row_sum16(sdu1);
         if (i16 == 0) {
           atomicAdd(&s_film[br][0][ft], sdc);
           atomicAdd(&s_film[br][1][ft], sdu0);
-          atomicAdd(&s_film[br][2][ft], sdu1);
+          if (!ONE_W) atomicAdd(&s_film[br][2][ft], sdu1);        // (zero on entry: the absent column's sum stays zero)
         }
       }
     }
@@ -418,26 +435,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
         float g0 = 0.f, g1 = 0.f, g2 = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-          const float pre = fmaf(sp[0], xa[nb], fmaf(sp[1], xb[nb], sp[2]));
+          const float pre = ONE_K ? fmaf(sp[0], xa[nb], sp[2]) : fmaf(sp[0], xa[nb], fmaf(sp[1], xb[nb], sp[2]));
           const float dp = pre > 0.f ? dh[nb][r] : 0.f;
           pxa[nb] = fmaf(sp[0], dp, pxa[nb]);
-          pxb[nb] = fmaf(sp[1], dp, pxb[nb]);
+          if (!ONE_K) pxb[nb] = fmaf(sp[1], dp, pxb[nb]);
           g0 = fmaf(dp, xa[nb], g0);
-          g1 = fmaf(dp, xb[nb], g1);
+          if (!ONE_K) g1 = fmaf(dp, xb[nb], g1);
           g2 += dp;
         }
         g0 = row_sum16(g0);
-        g1 = row_sum16(g1);
+        if (!ONE_K) g1 = row_sum16(g1);
         g2 = row_sum16(g2);
         if (i16 == 0) {
           atomicAdd(&s_sd0[br][0][fi], g0);
-          atomicAdd(&s_sd0[br][1][fi], g1);
+          if (!ONE_K) atomicAdd(&s_sd0[br][1][fi], g1);          // (zero on entry: the absent column's sum stays zero)
           atomicAdd(&s_sd0[br][2][fi], g2);
         }
       }
     }
     dxa_own += quarter_reduce<NB>(pxa, q);
-    dxb_own += quarter_reduce<NB>(pxb, q);
+    if (!ONE_K) dxb_own += quarter_reduce<NB>(pxb, q);
 
     // ---- dW1[br] partial of this workgroup: X = scaled dacc (hi/lo), transposed through LDS; H recomputed --------------
     {
@@ -474,8 +491,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 #pragma unroll
           for (int e2 = 0; e2 < 4; ++e2) {
             const float4 two = pp[e2];                         // points 32 s + 8 q + 2 e2, + 1: (xa, xb) each
-            f32x2 h = {fmaxf(fmaf(sp[0], two.x, fmaf(sp[1], two.y, sp[2])), 0.f),
-                       fmaxf(fmaf(sp[0], two.z, fmaf(sp[1], two.w, sp[2])), 0.f)};
+            f32x2 h = {fmaxf(ONE_K ? fmaf(sp[0], two.x, sp[2]) : fmaf(sp[0], two.x, fmaf(sp[1], two.y, sp[2])), 0.f),
+                       fmaxf(ONE_K ? fmaf(sp[0], two.z, sp[2]) : fmaf(sp[0], two.z, fmaf(sp[1], two.w, sp[2])), 0.f)};
             f16x2 hh, hl;
             split_pair(h, hh, hl);
             hhi[2 * e2] = hh[0]; hhi[2 * e2 + 1] = hh[1];
@@ -644,9 +661,15 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
         k4.tpw = (int)std::max(1L, std::min((long)tps, (long)B * tps * K / 512));
         if (ks.tune & GWTF_TUNE_SINGLE_TILE) k4.tpw = 1;
         const dim3 grid4((unsigned)(B * ((tps + k4.tpw - 1) / k4.tpw)), (unsigned)K);
-        hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c, cmb);
+        if (pat < 3 && (GWTF_K2_MASK & 1)) hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c, cmb);
+        else if (pat >= 3 && (GWTF_K2_MASK & 2)) hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1, 0>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c, cmb);
+        else hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c, cmb);
       } else if (nb == 1) {
         hipLaunchKernelGGL((bwd_kernel<MB, 1, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
+      } else if (pat < 3 && (GWTF_K2_MASK & 4)) {
+        hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
+      } else if (pat >= 3 && (GWTF_K2_MASK & 8)) {
+        hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1, 0>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
       } else {
         hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
       }

@@ -1,0 +1,28 @@
+"""scratch: the full-tile train-gradient comparison of tests/test_gpu_parity.py (f = 37, 128 x 2048) with error statistics printed"""
+import sys, os
+import numpy as np, torch
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from helpers import decoder_and_state
+from go_with_the_flows_amd.synth import synth_inputs
+from oracle import torch_port as tp
+DEV = 'cuda:0'
+dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+L, f, G, N, B = 1, 37, 16, 2048, 128
+m, st = decoder_and_state(L, f, G, 458)
+m = m.to(DEV).train()
+p, g = synth_inputs(B, N, G, 459)
+rng = np.random.default_rng(460)
+wz, wl = np.abs(rng.normal(size=(B, 3, N))).astype(np.float32), np.abs(rng.normal(size=(B, 3, N))).astype(np.float32)
+tst = {k: torch.from_numpy(v).clone().requires_grad_(v.dtype == np.float32 and not k.endswith(('running_mean', 'running_var', 'eps'))) for k, v in st.items()}
+pc, gc = torch.from_numpy(p).requires_grad_(True), torch.from_numpy(g).requires_grad_(True)
+zc, ldc = tp.decoder_fused(pc, gc, tst, L, 'inverse', grad=True, training=True)
+((zc * torch.from_numpy(wz)).sum() + (ldc * torch.from_numpy(wl)).sum()).backward()
+pt, gt = dev(p).requires_grad_(True), dev(g).requires_grad_(True)
+z, ld = m.forward_fused(pt, gt, 'inverse')
+((z * dev(wz)).sum() + (ld * dev(wl)).sum()).backward()
+d = np.abs(pt.grad.cpu().numpy() - pc.grad.numpy())
+ref = np.abs(pc.grad.numpy()).mean()
+print('lib', os.environ.get('GWTF_LIB'), 'pattern0', m.decoder_pattern0 if hasattr(m, 'decoder_pattern0') else '?')
+for dd in range(3):
+    e = d[:, dd] / ref
+    print(f'dim {dd}: median {np.median(e):.2e}  p99 {np.quantile(e, 0.99):.2e}  max {e.max():.2e}  >1e-3: {(e > 1e-3).sum()}')
