@@ -60,7 +60,8 @@ struct BCfg {
 // u_1 terms, its FiLM-record sum (one of three 16-lane reductions + LDS atomics per feature row in the light pass) and the second
 // tail slot fold away -- the train pipeline's launcher picks the variant per level (the pattern is a host-side fact).
 enum { BW_DIRECT = 0, BW_STATS = 1, BW_LIGHT = 2, BW_MERGED = 3 };
-template <int MB, int NB, int VAR, int MG = -1, int K2 = -1>
+// FULL: N is a multiple of the workgroup's tile (no point beyond the cloud: the per-element bound selects of the merged pass fold away).
+template <int MB, int NB, int VAR, int MG = -1, int K2 = -1, bool FULL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2 : (MB <= 3 ? 3 : 1)))) void bwd_kernel(const float* __restrict__ x_in, const float* __restrict__ g_out,
                                                   const float* __restrict__ g_ld, const float* __restrict__ pw_c,
                                                   const float* __restrict__ pb_c, const float* __restrict__ film,
@@ -162,8 +163,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   if (tile >= tiles_per_shape) break;
   const int n_wave0 = (tile * 4 + wave) * 16 * NB;
   const int n_own = n_wave0 + 16 * own_nb + i16;
-  const bool own_valid = n_own < N && q < NB;
-  const bool own_inrange = n_own < N;
+  const bool own_inrange = FULL || n_own < N;
+  const bool own_valid = own_inrange && q < NB;
   // own point: input coordinates and upstream gradients (zero beyond N: every derived gradient is then zero)
   float xo[3], go[3], gl[3];
 #pragma unroll
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
             const int n = n_wave0 + 16 * nb + i16;
             const float a = acc[br][m][nb][r];
             const float da = a > 0.f ? (ONE_W ? u0[r] * d0[nb] : fmaf(u0[r], d0[nb], u1[r] * d1[nb])) : 0.f;
-            acc[br][m][nb][r] = n < N ? da + fmaf(gq2, a - cc, gs) : 0.f;
+            acc[br][m][nb][r] = (FULL || n < N) ? da + fmaf(gq2, a - cc, gs) : 0.f;
           }
           continue;
         }
@@ -666,6 +667,10 @@ int launch_bwd(int nb, const float* x_in, const float* g_out, const float* g_ld,
         else hipLaunchKernelGGL((bwd_kernel<MB, 4, VAR, 1>), grid4, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, k4, g_ps_c, g_lvs_c, cmb);
       } else if (nb == 1) {
         hipLaunchKernelGGL((bwd_kernel<MB, 1, VAR, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
+      } else if (pat < 3 && (GWTF_K2_MASK & 4) && N % 128 == 0 && VAR == BW_MERGED) {
+        hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1, 1, true>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
+      } else if (pat >= 3 && (GWTF_K2_MASK & 8) && N % 128 == 0 && VAR == BW_MERGED) {
+        hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1, 0, true>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
       } else if (pat < 3 && (GWTF_K2_MASK & 4)) {
         hipLaunchKernelGGL((bwd_kernel<MB, 2, VAR, 1, 1>), grid, block, 0, st, x_in, g_out, g_ld, pw_c, pb_c, film, g_in, dw1_ws, g_film, g_sd0, g_bias, g_stats, B, N, C, c, pat, eps, kk_steps, f, mode, ks, g_ps_c, g_lvs_c, cmb);
       } else if (pat >= 3 && (GWTF_K2_MASK & 8)) {
