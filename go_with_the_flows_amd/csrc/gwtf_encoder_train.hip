@@ -31,7 +31,7 @@
 #include "gwtf_device.h"
 
 #ifndef GWTF_ENC_DBG
-#define GWTF_ENC_DBG 0      // timing experiments only (tools/ab_build.sh): 1 no dA stores, 2 no epilogue loads, 3 no prologue loads
+#define GWTF_ENC_DBG 0      // timing experiments only (tools/ab_build.sh): 1 no dA stores, 2 no epilogue loads, 3 no prologue loads, 4 no dW operand loads
 #endif
 using namespace gwtf_dev;
 
@@ -851,8 +851,13 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
 
 __device__ __forceinline__ void load8(const float* row, int n0, int p1, float (&v)[8]) {
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#if GWTF_ENC_DBG == 4
+  const float t0 = (float)(n0 & 15) * 0.01f + 0.5f;
+  const float4 a = make_float4(t0, t0 + 0.1f, t0 - 0.2f, t0), c = make_float4(-t0, t0, 0.3f, t0);
+#else
   const float4 a = n0 < p1 ? *reinterpret_cast<const float4*>(row + n0) : z;
   const float4 c = n0 + 4 < p1 ? *reinterpret_cast<const float4*>(row + n0 + 4) : z;
+#endif
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
 }
 
@@ -863,6 +868,15 @@ __device__ __forceinline__ void load8(const float* row, int n0, int p1, float (&
 // workgroup and every consumer read is one conflict-free ds_read_b128.  One barrier per k-step.
 // AMODE 0: A = dy_l = s gm + Q y + R from (y_l, up_g), scaled by `up`;  AMODE 2: A = a_l = relu(s y_l + t) and B IS A (the Gram
 // matrix of layer 3's input; bconst = that layer's aff).  FIRST: B = a_0 = relu(W_0' x + t_0) from x and table0.
+// producer item `it` of the weight-gradient kernel -> (operand row, point group).  Consecutive lanes own consecutive 16-byte slots of
+// the LDS fragment image (slot = 64 (row >> 4) 2 + (row & 15) + 16 q): a wave's ds_write_b128 covers one contiguous KiB.  (The first
+// mapping, row = it >> 2, q = it & 3, put the four lanes of a quad 256 bytes apart -- one bank: 6-10 conflict cycles per LDS instruction.)
+#ifndef GWTF_ENC_DWMAP
+#define GWTF_ENC_DWMAP 1
+#endif
+__device__ __forceinline__ int dw_item_row(int it) { return GWTF_ENC_DWMAP ? (((it >> 6) << 4) | (it & 15)) : (it >> 2); }
+__device__ __forceinline__ int dw_item_q(int it) { return GWTF_ENC_DWMAP ? ((it >> 4) & 3) : (it & 3); }
+
 template <int WM, int WN, int AMODE, bool FIRST>
 __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float* __restrict__ y_l, const float* __restrict__ up_g,
                                                                     const float* __restrict__ bconst,
@@ -885,14 +899,14 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
   float cA0[IA], cA1[IA], cA2[IA], cB0[IB > 0 ? IB : 1], cB1[IB > 0 ? IB : 1], cB2[IB > 0 ? IB : 1], cB3[IB > 0 ? IB : 1];
 #pragma unroll
   for (int i = 0; i < IA; ++i) {
-    const int row = (tid + NT * i) >> 2;
+    const int row = dw_item_row(tid + NT * i);
     cA0[i] = bconst[row] * up;
     cA1[i] = bconst[CA + row] * up;
     cA2[i] = SAME ? 0.f : bconst[2 * CA + row] * up;
   }
 #pragma unroll
   for (int i = 0; i < IB; ++i) {
-    const int row = (tid + NT * i) >> 2;
+    const int row = dw_item_row(tid + NT * i);
     if (FIRST) {
       cB0[i] = tab_prev[4 * row]; cB1[i] = tab_prev[4 * row + 1]; cB2[i] = tab_prev[4 * row + 2]; cB3[i] = tab_prev[4 * row + 3];
     } else {
@@ -904,13 +918,13 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
   auto fetch = [&](int p) {
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const int it = tid + NT * i, row = it >> 2, n0 = p + 8 * (it & 3);
+      const int it = tid + NT * i, row = dw_item_row(it), n0 = p + 8 * dw_item_q(it);
       load8((SAME ? y_prev : y_l) + ((size_t)b * CA + row) * N, n0, p1, rA[i]);
       if (!SAME) load8(up_g + ((size_t)b * CA + row) * N, n0, p1, rG[i]);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const int it = tid + NT * i, row = it >> 2, n0 = p + 8 * (it & 3);
+      const int it = tid + NT * i, row = dw_item_row(it), n0 = p + 8 * dw_item_q(it);
       if (FIRST) {
 #pragma unroll
         for (int d = 0; d < 3; ++d) load8(y_prev + ((size_t)b * 3 + d) * N, n0, p1, rB[i][d]);
@@ -922,7 +936,7 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
   auto produce = [&](int buf, int p) {
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
-      const int it = tid + NT * i, row = it >> 2, qq = it & 3, n0 = p + 8 * qq;
+      const int it = tid + NT * i, row = dw_item_row(it), qq = dw_item_q(it), n0 = p + 8 * qq;
       float d[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -938,7 +952,7 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
-      const int it = tid + NT * i, row = it >> 2, qq = it & 3, n0 = p + 8 * qq;
+      const int it = tid + NT * i, row = dw_item_row(it), qq = dw_item_q(it), n0 = p + 8 * qq;
       float d[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
