@@ -713,15 +713,18 @@ def test_train_mode_gradients_vs_torch_cpu_autograd(cfg):
             assert maxabs(host(sd[k]), v.detach().numpy()) < 1e-4, k
 
 
-@pytest.mark.parametrize('B', [16, 128])
-def test_train_mode_gradients_at_full_tile_sizes_f37_vs_torch_cpu_autograd(B):
+@pytest.mark.parametrize('B,f,L', [(16, 37, 1), (128, 37, 1), (128, 33, 1), (64, 37, 2)])
+def test_train_mode_gradients_at_full_tile_sizes_f37_vs_torch_cpu_autograd(B, f, L):
     """The same comparison at the sizes the training step runs at -- 128 x 2048 points, f = 37: the statistics pass and the light
     backward pass on their 256-point tiles, the merged pass on its 128-point tile, the abs-form contraction with its compile-time
     merged flag (csrc/gwtf_device.h sd1_contract MG = 1) -- against CPU autograd of the oracle.  Loss weights are positive (a few of
     the 2.9e7 ReLU pre-activations sit within rounding of their kink and differ between ANY two evaluations, docs/LOG.md 4.11: with
     random-sign weights the sums cancel and one flipped point shows at 1e-3 of a tensor's gradient)."""
     from oracle import torch_port as tp
-    L, f, G, N = 1, 37, 16, 2048          # B = 16: the 64-point tiles (512 workgroups: still two per compute unit); 128: the large ones
+    # B = 16: the 64-point tiles (512 workgroups: still two per compute unit); 128: the large ones, where the launcher picks the
+    # kernels compiled per warp pattern (one warped / one kept coordinate: csrc/gwtf_bwd.hip K2) -- at f = 37 (airplane) and f = 33
+    # (autoencoding / single-view configs); L = 1: patterns 0-2 (one warped coordinate), L = 2: also 3-5 (one kept coordinate)
+    G, N = 16, 2048
     m, st = decoder_and_state(L, f, G, 458)
     m = m.to(DEV).train()
     p, g = synth_inputs(B, N, G, 459)

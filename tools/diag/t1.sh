@@ -1,1 +1,1 @@
-for v in encdbg4 dwmap0 dwmap1; do echo "== $v"; bash tools/enc_kstats.sh --parts e --lib build_ab/libgwtf_$v.so 2>&1 | grep -E "dw_kernel"; done
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -k "full_tile_sizes" 2>&1 | tail -3
