@@ -73,6 +73,7 @@ _SIGNATURES = {
     'gwtf_encoder_forward': (ctypes.c_int, [_c_fp] * 4 + [ctypes.c_int, ctypes.c_int, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_supported': (ctypes.c_int, [_c_fp, ctypes.c_int]),
     'gwtf_enc_train_units_floats': (ctypes.c_size_t, [ctypes.c_int]),
+    'gwtf_enc_train_act_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'gwtf_enc_train_pack': (ctypes.c_int, [_c_fp] * 3 + [ctypes.c_int, _c_fp]),
     'gwtf_enc_train_pack_all': (ctypes.c_int, [_c_fp] * 10),
     'gwtf_enc_train_xmoments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),

@@ -44,6 +44,21 @@ constexpr int kC[5] = {3, 64, 128, 256, 512};
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+// LAYOUT OF THE STORED ACTIVATIONS (y_1, y_2 and the masked gradients dA_2, dA_1; internal to the pipeline, never seen by the caller):
+// [B][N / 32][C][32] -- tiles of 32 points with all channels of a tile contiguous (C x 128 bytes), not the reference's (B, C, N).
+// Every consumer here takes 32 points x ALL channels at a time (a wave of the forward / backward kernels, a k-step of the weight-
+// gradient kernels): in (B, C, N) that is C separate 128-byte pieces 8 KB apart (every access another DRAM page: the weight-gradient
+// kernels ran at 2 TB/s), in tiles it is ONE contiguous block.  N is padded to whole tiles in the allocation (gwtf_enc_train_act_floats).
+// the same split in two: the point's offset inside channel 0 of its tile (computed once per point) + 32 floats per channel
+__device__ __forceinline__ size_t tix_point(int b, int C, int n, int N) {
+  const int NT = (N + 31) >> 5;
+  return ((size_t)b * NT + (n >> 5)) * C * 32 + (n & 31);
+}
+__device__ __forceinline__ size_t tix(int b, int C, int ch, int n, int N) {
+  const int NT = (N + 31) >> 5;
+  return (((size_t)b * NT + (n >> 5)) * C + ch) * 32 + (n & 31);
+}
+
 // units [m][ks] of [hi | lo] x 64 lanes x 8 f16: A-operand row 16 m + (lane & 15), k-slot (ks, q, e) <-> contraction index
 // 32 ks + 16 (e >> 2) + 4 q + (e & 3) (the map gwtf_encoder.hip uses).  transposed = 0: A[row][k] = W[row][k] (W [rows][kdim]);
 // transposed = 1: A[row][k] = W[k][row] (W [kdim][rows]).
@@ -277,10 +292,13 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
 
   int n[NB];
   bool valid[NB];
+  size_t tin[NB], tout[NB];          // the point's base offsets in the tiled input / output arrays
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     n[nb] = n_wave0 + 16 * nb + i16;
     valid[nb] = n[nb] < N;
+    tin[nb] = tix_point(b, CIN, valid[nb] ? n[nb] : 0, N);
+    tout[nb] = tix_point(b, COUT, valid[nb] ? n[nb] : 0, N);
   }
   __syncthreads();
 
@@ -319,7 +337,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
           f32x4 a;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = valid[nb] ? in[((size_t)b * CIN + c0 + r) * N + n[nb]] : 0.f;
+            const float v = valid[nb] ? in[tin[nb] + (size_t)(c0 + r) * 32] : 0.f;
             a[r] = fmaf(s4[r], v, t4[r]);
           }
           split_into<true>(a, bhi[ks][nb], blo[ks][nb], half);
@@ -348,7 +366,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float v = valid[nb] ? acc[nb][r] : 0.f;
-          if (!LAST && valid[nb]) y_out[((size_t)b * COUT + ch) * N + n[nb]] = v;
+          if (!LAST && valid[nb]) y_out[tout[nb] + (size_t)ch * 32] = v;
           s1 += v;
           s2 = fmaf(v, v, s2);
           amax = fmaxf(amax, fabsf(v));
@@ -664,10 +682,13 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 
   int n[NB], slot[NB];
   bool valid[NB];
+  size_t toff_l[NB], toff_p[NB];             // the point's base offsets in the tiled arrays of COUT (y_l, up_g) and CIN (y_prev, dA_prev) channels
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
     n[nb] = n_wave0 + 16 * nb + i16;
     valid[nb] = n[nb] < N;
+    toff_l[nb] = tix_point(b, COUT, valid[nb] ? n[nb] : 0, N);
+    toff_p[nb] = tix_point(b, CIN, valid[nb] ? n[nb] : 0, N);
     slot[nb] = (TOP && valid[nb]) ? amax[(size_t)b * N + n[nb]] : -1;          // TOP: `amax` carries slot_of [B][N]
   }
   __syncthreads();
@@ -685,7 +706,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
         for (int nb = 0; nb < NB; ++nb) {
           f32x4 a;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] = fmaf(s4[r], valid[nb] ? y_prev[((size_t)b * CIN + c0 + r) * N + n[nb]] : 0.f, t4[r]);
+          for (int r = 0; r < 4; ++r) a[r] = fmaf(s4[r], valid[nb] ? y_prev[toff_p[nb] + (size_t)(c0 + r) * 32] : 0.f, t4[r]);
           split_into<true>(a, bhi[ks][nb], blo[ks][nb], half);
           // the activations of the arg-max points, point-major: what the arg-max part of dW_3 contracts with (gwtf_enc_train_dw3).
           // Here they are in registers; gathered from the (B, C, N) array afterwards every VALUE costs a 128-byte line (72 us).
@@ -705,7 +726,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
         f32x4 d;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const size_t idx = ((size_t)b * COUT + c0 + r) * N + n[nb];
+          const size_t idx = toff_l[nb] + (size_t)(c0 + r) * 32;
 #if GWTF_ENC_DBG == 3
           const float yv = 1.0f + (float)idx * 1e-9f, gm = 0.5f;
 #else
@@ -746,7 +767,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 #if GWTF_ENC_DBG == 2
         yv[r][nb] = 1.0f;
 #else
-        yv[r][nb] = (!BOTTOM && valid[nb]) ? y_prev[((size_t)b * CIN + j0 + r) * N + n[nb]] : 0.f;
+        yv[r][nb] = (!BOTTOM && valid[nb]) ? y_prev[toff_p[nb] + (size_t)(j0 + r) * 32] : 0.f;
 #endif
       }
     }
@@ -785,9 +806,9 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
           const float gm = on ? (TOP ? fmaf(acc[nb][r], down, bc[j] + ex_cur[nb][r]) : acc[nb][r] * down) : 0.f;
           if (TOP) sx0 += on ? pre : 0.f;                  // sum_p a_{l-1}: the R term of dW_3 (gwtf_enc_train_dw3)
 #if GWTF_ENC_DBG == 1
-          if (!BOTTOM && valid[nb] && gm == 123.456f) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
+          if (!BOTTOM && valid[nb] && gm == 123.456f) dA_prev[toff_p[nb] + (size_t)j * 32] = gm;
 #else
-          if (!BOTTOM && valid[nb]) dA_prev[((size_t)b * CIN + j) * N + n[nb]] = gm;
+          if (!BOTTOM && valid[nb]) dA_prev[toff_p[nb] + (size_t)j * 32] = gm;
 #endif
           sb += gm;
           sg = fmaf(gm, (yv - mp[r]) * rp[r], sg);
@@ -919,8 +940,9 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       const int it = tid + NT * i, row = dw_item_row(it), n0 = p + 8 * dw_item_q(it);
-      load8((SAME ? y_prev : y_l) + ((size_t)b * CA + row) * N, n0, p1, rA[i]);
-      if (!SAME) load8(up_g + ((size_t)b * CA + row) * N, n0, p1, rG[i]);
+      // (the pointer is biased by -n0: load8 adds it back; n0 is a multiple of 8 inside one 32-point tile)
+      load8((SAME ? y_prev : y_l) + tix(b, CA, row, n0, N) - n0, n0, p1, rA[i]);
+      if (!SAME) load8(up_g + tix(b, CA, row, n0, N) - n0, n0, p1, rG[i]);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
@@ -929,7 +951,7 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
 #pragma unroll
         for (int d = 0; d < 3; ++d) load8(y_prev + ((size_t)b * 3 + d) * N, n0, p1, rB[i][d]);
       } else {
-        load8(y_prev + ((size_t)b * CB + row) * N, n0, p1, rB[i][0]);
+        load8(y_prev + tix(b, CB, row, n0, N) - n0, n0, p1, rB[i][0]);
       }
     }
   };
@@ -1117,6 +1139,12 @@ extern "C" int gwtf_enc_train_supported(const int* widths, int n_widths) {
   for (int i = 0; i < 5; ++i)
     if (widths[i] != kC[i]) return 0;
   return 1;
+}
+
+// floats of one stored activation array of `channels` channels (tiles of 32 points: N padded to whole tiles)
+extern "C" size_t gwtf_enc_train_act_floats(int B, int channels, int N) {
+  if (B <= 0 || channels <= 0 || N <= 0) return 0;
+  return (size_t)B * ((N + 31) / 32) * channels * 32;
 }
 
 extern "C" size_t gwtf_enc_train_units_floats(int layer) {

@@ -81,7 +81,8 @@ class _EncoderTrainFn(torch.autograd.Function):
             ys, ymax = [None], torch.zeros(4, **f32)
             keys = torch.zeros(2, B, C[4], device=dev, dtype=torch.int64)        # arg-max / arg-min keys of y_3 (never stored)
             for l in (1, 2, 3):
-                y = torch.empty(B, C[l + 1], N, **f32) if l < 3 else None
+                # y_1, y_2 (and the backward's dA arrays) in tiles of 32 points x all channels: include/gwtf.h gwtf_enc_train_act_floats
+                y = torch.empty(L.gwtf_enc_train_act_floats(B, C[l + 1], N), **f32) if l < 3 else None
                 sums = torch.zeros(R, 2, C[l + 1], **f32)
                 check(L.gwtf_enc_train_forward(l, P(x if l == 1 else ys[l - 1]), P(table0 if l == 1 else aff[l - 1]),
                                                P(units_f[l]), P(y), P(sums), P(ymax[l:l + 1]),
@@ -151,7 +152,7 @@ class _EncoderTrainFn(torch.autograd.Function):
             tables = torch.empty(B * (2 * C[4] + 2), device=dev, dtype=torch.int32)
             check(L.gwtf_enc_train_top_scatter(P((gp * s3[None, :]).contiguous()), b['amax'].data_ptr(), P(W3), P(extra),
                                                slot_of.data_ptr(), tables.data_ptr(), B, N, st))
-            up = torch.empty(B, C[3], N, **f32)                                    # masked dL/da_2
+            up = torch.empty(L.gwtf_enc_train_act_floats(B, C[3], N), **f32)       # masked dL/da_2 (tiled like y_2)
             sums = torch.zeros(R, 3, C[3], **f32)
             a2rows = torch.empty(B, C[4], C[3], **f32)                             # a_2 at the arg-max points, point-major
             check(L.gwtf_enc_train_backward_top(P(ys[2]), P(aff[2]), P(units_m), P(mconst), P(extra), slot_of.data_ptr(), P(up),
@@ -167,7 +168,7 @@ class _EncoderTrainFn(torch.autograd.Function):
                 bconst = torch.empty(3 * C[l + 1] + 4, **f32)
                 check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), l, n_total, P(gam[l]), P(aff[l]),
                                                   P(gmax[l:l + 1]), P(b['ymax'][l:l + 1]), P(bconst), st))
-                dA = torch.empty(B, C[l], N, **f32) if l > 1 else None
+                dA = torch.empty(L.gwtf_enc_train_act_floats(B, C[l], N), **f32) if l > 1 else None
                 sums = torch.zeros(R, 5 if l == 1 else 2, C[l], **f32)
                 check(L.gwtf_enc_train_backward(l, P(ys[l]), P(up), P(bconst), P(b['units_b'][l]), P(x if l == 1 else ys[l - 1]),
                                                 P(aff[l - 1]), P(Ws[0] if l == 1 else None), P(dA), P(sums),

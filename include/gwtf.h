@@ -393,13 +393,18 @@ int gwtf_encoder_forward(const float* x, const float* packed, float* features, f
  * Replaces, for lib/networks/encoders.py:9-28 + models.py:127-128 inside the training step (training.py:43-54), the chain of
  * library GEMM / batch-norm / elementwise calls and their autograd.  Channel counts C = {3, 64, 128, 256, 512}: layer l maps
  * C[l] -> C[l+1] channels with weight W_l [C[l+1]][C[l]]; kernels exist for layer = 1..3 (layer 0, 3 -> 64, is three FMAs
- * folded into layer 1's prologue).  All activations are the reference's (B, C, N) fp32 tensors.
+ * folded into layer 1's prologue).  x is the reference's (B, 3, N) fp32 tensor; the stored activations y_1, y_2 and gradients dA_2, dA_1 are
+ * fp32 in tiles of 32 points, [B][ceil(N/32)][C][32] (gwtf_enc_train_act_floats): written and read by these entry points only.
  *   aff     [4][C]  = s, t, mean, rstd of a layer's BatchNorm (a = relu(s y + t));  table0 [64][4] = (s W_0 row, t)
  *   sums    replicated accumulators, zero on entry: the caller sums the 64 replicas (and the ranks) before the fold
  *   bconst  [3][C] + 4: dy = s gm + Q y + R per channel, then {up, down} = the power-of-two scale of the f16-split operand
  * gwtf_enc_train_supported(widths, n) -> 1 when this width list has kernels. */
 int gwtf_enc_train_supported(const int* widths, int n_widths);
 size_t gwtf_enc_train_units_floats(int layer);
+/* floats of one stored activation / gradient array of `channels` channels.  y_1, y_2, dA_2, dA_1 are internal to the pipeline and live in
+ * tiles of 32 points, [B][ceil(N / 32)][channels][32] (a wave / a k-step takes 32 points x all channels: one contiguous block), NOT in the
+ * reference's (B, C, N); only x (B, 3, N) and the pooled (B, 512) outputs keep the reference's layouts. */
+size_t gwtf_enc_train_act_floats(int B, int channels, int N);
 /* W [C[l+1]][C[l]] -> MFMA fragment images of W (forward) and W^T (backward), gwtf_enc_train_units_floats(layer) floats each */
 int gwtf_enc_train_pack(const float* W, float* units_fwd, float* units_bwd, int layer, void* stream);
 /* the same for layers 1, 2, 3 from ONE launch (W_l, forward images uf_l, backward images ub_l) */
@@ -415,7 +420,7 @@ int gwtf_enc_train_fold0(const float* mom12, double n_total, const float* W0, co
 int gwtf_enc_train_fold(const float* sums, int layer, double n_total, const float* gamma, const float* beta,
                         float* running_mean, float* running_var, float momentum, float* aff, const float* aff_prev,
                         void* stream);
-/* y_out (B, C[layer+1], N) = W_layer . relu(s in + t); in = x and in_tab = table0 for layer 1, else y_{layer-1} and its aff.
+/* y_out (C[layer+1] channels, tiled) = W_layer . relu(s in + t); in = x and in_tab = table0 for layer 1, else y_{layer-1} and its aff.
  * sums [64][2][C[layer+1]] += {sum y, sum y^2}; ymax[0] = max |y| (bit pattern max, zero on entry).
  * layer 3 stores no y: kmax / kmin [B][512] (zero on entry) receive the 64-bit arg-max (channels with BatchNorm weight gamma3 >= 0)
  * or arg-min (gamma3 < 0) key of y_3 per (shape, channel) -- all the max-pool needs, because BatchNorm + ReLU is monotone in y per
@@ -441,7 +446,7 @@ int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, cons
  *   gwtf_enc_train_top_scatter   coef [B][512] = s_c gp[b][c] -> slot_of [B][N] (row of a point, or -1) and
  *                                extra [B][512][256]: row r of shape b = sum of coef[b][c] W_3[c][:] over the channels whose
  *                                arg-max is that point (only the used rows are written); tables: B (2 * 512 + 2) ints of scratch
- *   gwtf_enc_train_backward_top  dA2 (B,256,N) = (M a_2 + v + extra) masked by a_2 > 0; mconst = v [256] | {2^-k};
+ *   gwtf_enc_train_backward_top  dA2 (256 channels, tiled) = (M a_2 + v + extra) masked by a_2 > 0; mconst = v [256] | {2^-k};
  *                                sums [64][3][256] += {sum gm_2, sum gm_2 yhat_2, sum a_2}; gmax2[0] = max |dA2|;
  *                                a2rows [B][512][256] (out): row slot_of[b][n] of shape b = a_2(b, :, n) of every arg-max point n,
  *                                point-major (the kernel has them in registers; other rows are not written) */
@@ -450,7 +455,7 @@ int gwtf_enc_train_top_scatter(const float* coef, const int* amax, const float* 
                                int B, int N, void* stream);
 int gwtf_enc_train_backward_top(const float* y2, const float* aff2, const float* units_m, const float* mconst, const float* extra,
                                 const int* slot_of, float* dA2, float* sums, float* gmax2, float* a2rows, int B, int N, void* stream);
-/* layer = 1, 2: dA_prev (B, C[layer], N) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
+/* layer = 1, 2: dA_prev (C[layer] channels, tiled) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
  * (y_l, up_g = masked dL/da_layer).  y_prev / aff_prev: y_{layer-1} and its aff (layer 1: x, aff_0, and w0 = raw W_0).
  * sums [64][2 (layer 1: 5)][C[layer]] += {sum gm, sum gm yhat (layer 1: , sum gm x_d)} of the layer below;
  * gmax_prev[0] = max |dA_prev| */
