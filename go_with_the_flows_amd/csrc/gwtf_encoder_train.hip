@@ -28,6 +28,7 @@
 // chosen from a bound on |dy_l| (host-free: the bound comes from max |gm_l| and max |y_l| tracked by the producing
 // kernels) and the result is scaled back: exact.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "gwtf_device.h"
 
 #ifndef GWTF_ENC_DBG
@@ -870,15 +871,24 @@ __device__ __forceinline__ void split8(const float (&v)[8], f16x8& hi, f16x8& lo
   }
 }
 
+// eight consecutive points of an operand row.  UNCONDITIONAL 16-byte loads: written as `n0 < p1 ? load : 0` hipcc turned each of
+// the eight floats into its own exec-masked branch around a global_load_dword (168 dword loads and 160 branches per k-step in the
+// layer-2 kernel, which then ran at 2 TB/s whatever the prefetch depth, layout or barrier).  The tiled activation arrays are padded to
+// whole 32-point tiles, so a read inside a tile is always in bounds; what lies beyond the slice is zeroed by the producer's select.
 __device__ __forceinline__ void load8(const float* row, int n0, int p1, float (&v)[8]) {
-  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #if GWTF_ENC_DBG == 4
   const float t0 = (float)(n0 & 15) * 0.01f + 0.5f;
   const float4 a = make_float4(t0, t0 + 0.1f, t0 - 0.2f, t0), c = make_float4(-t0, t0, 0.3f, t0);
 #else
-  const float4 a = n0 < p1 ? *reinterpret_cast<const float4*>(row + n0) : z;
-  const float4 c = n0 + 4 < p1 ? *reinterpret_cast<const float4*>(row + n0 + 4) : z;
+  const float4 a = *reinterpret_cast<const float4*>(row + n0);
+  const float4 c = *reinterpret_cast<const float4*>(row + n0 + 4);
 #endif
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
+}
+// the same for the input clouds x (B, 3, N), which are NOT padded: the address is clamped into the row instead (N % 4 == 0, N >= 8)
+__device__ __forceinline__ void load8_clamped(const float* row, int n0, int N, float (&v)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(row + min(n0, N - 4));
+  const float4 c = *reinterpret_cast<const float4*>(row + min(n0 + 4, N - 4));
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = c.x; v[5] = c.y; v[6] = c.z; v[7] = c.w;
 }
 
@@ -935,27 +945,37 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
     }
   }
 
-  float rA[IA][8], rG[SAME ? 1 : IA][8], rB[IB > 0 ? IB : 1][FIRST ? 3 : 1][8];
-  auto fetch = [&](int p) {
+  // DEEP: two register sets -- the operands of the step after next are in flight while this step's products run.  Only together with
+  // the LDS-only barrier below (a __syncthreads() waits for every outstanding global load: the second set would never be in flight
+  // across it).  Where the registers allow it: layer 2 (222 VGPRs at two waves per SIMD); the Gram kernel sits at its 128-register cap,
+  // layer 1 at 256.
+  constexpr bool DEEP = !FIRST && !SAME;
+  constexpr int SETS = DEEP ? 2 : 1;
+  float rA[SETS][IA][8], rG[SETS][SAME ? 1 : IA][8], rB[SETS][IB > 0 ? IB : 1][FIRST ? 3 : 1][8];
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, DEEP ? 1 : 0>;
+  auto fetch = [&](int p, auto SC) __attribute__((always_inline)) {
+    constexpr int S = decltype(SC)::value;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       const int it = tid + NT * i, row = dw_item_row(it), n0 = p + 8 * dw_item_q(it);
       // (the pointer is biased by -n0: load8 adds it back; n0 is a multiple of 8 inside one 32-point tile)
-      load8((SAME ? y_prev : y_l) + tix(b, CA, row, n0, N) - n0, n0, p1, rA[i]);
-      if (!SAME) load8(up_g + tix(b, CA, row, n0, N) - n0, n0, p1, rG[i]);
+      load8((SAME ? y_prev : y_l) + tix(b, CA, row, n0, N) - n0, n0, p1, rA[S][i]);
+      if (!SAME) load8(up_g + tix(b, CA, row, n0, N) - n0, n0, p1, rG[S][i]);
     }
 #pragma unroll
     for (int i = 0; i < IB; ++i) {
       const int it = tid + NT * i, row = dw_item_row(it), n0 = p + 8 * dw_item_q(it);
       if (FIRST) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) load8(y_prev + ((size_t)b * 3 + d) * N, n0, p1, rB[i][d]);
+        for (int d = 0; d < 3; ++d) load8_clamped(y_prev + ((size_t)b * 3 + d) * N, n0, N, rB[S][i][d]);
       } else {
-        load8(y_prev + tix(b, CB, row, n0, N) - n0, n0, p1, rB[i][0]);
+        load8(y_prev + tix(b, CB, row, n0, N) - n0, n0, p1, rB[S][i][0]);
       }
     }
   };
-  auto produce = [&](int buf, int p) {
+  auto produce = [&](int buf, int p, auto SC) __attribute__((always_inline)) {
+    constexpr int S = decltype(SC)::value;
 #pragma unroll
     for (int i = 0; i < IA; ++i) {
       const int it = tid + NT * i, row = dw_item_row(it), qq = dw_item_q(it), n0 = p + 8 * qq;
@@ -963,8 +983,8 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const bool on = n0 + (e & 4) < p1;
-        if (SAME) d[e] = on ? fmaxf(fmaf(cA0[i], rA[i][e], cA1[i]), 0.f) : 0.f;
-        else d[e] = on ? fmaf(cA0[i], rG[i][e], fmaf(cA1[i], rA[i][e], cA2[i])) : 0.f;
+        if (SAME) d[e] = on ? fmaxf(fmaf(cA0[i], rA[S][i][e], cA1[i]), 0.f) : 0.f;
+        else d[e] = on ? fmaf(cA0[i], rG[S][i][e], fmaf(cA1[i], rA[S][i][e], cA2[i])) : 0.f;
       }
       f16x8 hi, lo;
       split8(d, hi, lo);
@@ -979,8 +999,8 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const bool on = n0 + (e & 4) < p1;
-        const float pre = FIRST ? cB0[i] * rB[i][0][e] + (cB1[i] * rB[i][FIRST ? 1 : 0][e] + (cB2[i] * rB[i][FIRST ? 2 : 0][e] + cB3[i]))
-                                : fmaf(cB0[i], rB[i][0][e], cB1[i]);
+        const float pre = FIRST ? cB0[i] * rB[S][i][0][e] + (cB1[i] * rB[S][i][FIRST ? 1 : 0][e] + (cB2[i] * rB[S][i][FIRST ? 2 : 0][e] + cB3[i]))
+                                : fmaf(cB0[i], rB[S][i][0][e], cB1[i]);
         d[e] = on ? fmaxf(pre, 0.f) : 0.f;
       }
       f16x8 hi, lo;
@@ -997,15 +1017,7 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  if (p0 < p1) {
-    fetch(p0);
-    produce(0, p0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int p = p0; p < p1; p += 32, buf ^= 1) {
-    const bool more = p + 32 < p1;
-    if (more) fetch(p + 32);                    // global loads in flight behind the MFMAs
+  auto products = [&](int buf) __attribute__((always_inline)) {
     f16x8 ahi[4], alo[4], bhi[4], blo[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -1023,8 +1035,35 @@ __global__ __launch_bounds__(64 * WM * WN) void enc_train_dw_kernel(const float*
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ahi[mt], blo[nt], acc[mt][nt], 0, 0, 0);
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(alo[mt], bhi[nt], acc[mt][nt], 0, 0, 0);
       }
-    if (more) produce(buf ^ 1, p + 32);
-    __syncthreads();
+  };
+  const int nsteps = p0 < p1 ? (p1 - p0 + 31) / 32 : 0;
+  auto point_of = [&](int st) { return p0 + 32 * st; };
+  if (nsteps > 0) {
+    fetch(point_of(0), S0{});
+    produce(0, point_of(0), S0{});
+  }
+  if (DEEP && nsteps > 1) fetch(point_of(1), S1{});
+  __syncthreads();
+  int buf = 0;
+  // one k-step: the image of step st is in img[buf]; the operands of step st + 1 are in flight in set SN (DEEP) or are fetched now;
+  // DEEP fetches step st + 2 into the other set
+  auto step = [&](int st, auto SN, auto SNN) __attribute__((always_inline)) {
+    if (DEEP) {
+      if (st + 2 < nsteps) fetch(point_of(st + 2), SNN);
+    } else if (st + 1 < nsteps) {
+      fetch(point_of(st + 1), SN);
+    }
+    products(buf);
+    if (st + 1 < nsteps) produce(buf ^ 1, point_of(st + 1), SN);
+    // An LDS-only barrier: __syncthreads() also waits for every outstanding GLOBAL load (its fence is s_waitcnt vmcnt(0)), i.e. for
+    // the operands in flight for the coming steps.  Only the LDS image must be visible to the other waves here; the loads in flight
+    // target this lane's own registers.
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    buf ^= 1;
+  };
+  for (int st = 0; st < nsteps; st += 2) {
+    step(st, S1{}, S0{});
+    if (st + 1 < nsteps) step(st + 1, S0{}, S1{});
   }
   float* out = partials + (size_t)sl * CA * CB;
 #pragma unroll
