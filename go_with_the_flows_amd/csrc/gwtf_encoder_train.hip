@@ -49,11 +49,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 // [B][N / 32][C][32] -- tiles of 32 points with all channels of a tile contiguous (C x 128 bytes), not the reference's (B, C, N).
 // Every consumer here takes 32 points x ALL channels at a time (a wave of the forward / backward kernels, a k-step of the weight-
 // gradient kernels): in (B, C, N) that is C separate 128-byte pieces 8 KB apart (every access another DRAM page: the weight-gradient
-// kernels ran at 2 TB/s), in tiles it is ONE contiguous block.  N is padded to whole tiles in the allocation (gwtf_enc_train_act_floats).
+// kernels ran at 2 TB/s), in tiles it is ONE contiguous block.  N is padded to whole tiles in the allocation, plus one spare tile
+// (gwtf_enc_train_act_floats).
 // the same split in two: the point's offset inside channel 0 of its tile (computed once per point) + 32 floats per channel
-__device__ __forceinline__ size_t tix_point(int b, int C, int n, int N) {
+// A point beyond the cloud (a lane of the last workgroup of a ragged N) maps into ONE spare tile behind the B shapes' tiles, so that
+// loads and stores need no bounds branch (written as `if (n < N)` every access compiled to its own exec-masked block).
+__device__ __forceinline__ size_t tix_point(int b, int C, int n, int N, int B) {
   const int NT = (N + 31) >> 5;
-  return ((size_t)b * NT + (n >> 5)) * C * 32 + (n & 31);
+  return n < N ? ((size_t)b * NT + (n >> 5)) * C * 32 + (n & 31) : (size_t)B * NT * C * 32 + (n & 31);
 }
 __device__ __forceinline__ size_t tix(int b, int C, int ch, int n, int N) {
   const int NT = (N + 31) >> 5;
@@ -298,8 +301,8 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
   for (int nb = 0; nb < NB; ++nb) {
     n[nb] = n_wave0 + 16 * nb + i16;
     valid[nb] = n[nb] < N;
-    tin[nb] = tix_point(b, CIN, valid[nb] ? n[nb] : 0, N);
-    tout[nb] = tix_point(b, COUT, valid[nb] ? n[nb] : 0, N);
+    tin[nb] = tix_point(b, CIN, n[nb], N, B);
+    tout[nb] = tix_point(b, COUT, n[nb], N, B);
   }
   __syncthreads();
 
@@ -308,9 +311,11 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
     float px[NB], py[NB], pz[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      px[nb] = valid[nb] ? in[((size_t)b * 3 + 0) * N + n[nb]] : 0.f;
-      py[nb] = valid[nb] ? in[((size_t)b * 3 + 1) * N + n[nb]] : 0.f;
-      pz[nb] = valid[nb] ? in[((size_t)b * 3 + 2) * N + n[nb]] : 0.f;
+      // (unconditional loads from a clamped address: `valid ? load : 0` compiles to an exec-masked branch per load -- docs/LOG.md)
+      const int nc = min(n[nb], N - 1);
+      px[nb] = in[((size_t)b * 3 + 0) * N + nc];
+      py[nb] = in[((size_t)b * 3 + 1) * N + nc];
+      pz[nb] = in[((size_t)b * 3 + 2) * N + nc];
     }
     const float4* t4 = reinterpret_cast<const float4*>(tab);
 #pragma unroll
@@ -338,7 +343,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
           f32x4 a;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const float v = valid[nb] ? in[tin[nb] + (size_t)(c0 + r) * 32] : 0.f;
+            const float v = in[tin[nb] + (size_t)(c0 + r) * 32];     // (padded tiles: in bounds; points beyond N never leave the wave)
             a[r] = fmaf(s4[r], v, t4[r]);
           }
           split_into<true>(a, bhi[ks][nb], blo[ks][nb], half);
@@ -367,7 +372,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_fwd_kerne
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
           const float v = valid[nb] ? acc[nb][r] : 0.f;
-          if (!LAST && valid[nb]) y_out[tout[nb] + (size_t)ch * 32] = v;
+          if (!LAST) y_out[tout[nb] + (size_t)ch * 32] = v;      // (unconditional: beyond N it writes zeros into the tile's padding)
           s1 += v;
           s2 = fmaf(v, v, s2);
           amax = fmaxf(amax, fabsf(v));
@@ -688,9 +693,10 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
   for (int nb = 0; nb < NB; ++nb) {
     n[nb] = n_wave0 + 16 * nb + i16;
     valid[nb] = n[nb] < N;
-    toff_l[nb] = tix_point(b, COUT, valid[nb] ? n[nb] : 0, N);
-    toff_p[nb] = tix_point(b, CIN, valid[nb] ? n[nb] : 0, N);
-    slot[nb] = (TOP && valid[nb]) ? amax[(size_t)b * N + n[nb]] : -1;          // TOP: `amax` carries slot_of [B][N]
+    toff_l[nb] = tix_point(b, COUT, n[nb], N, B);
+    toff_p[nb] = tix_point(b, CIN, n[nb], N, B);
+    slot[nb] = TOP ? amax[(size_t)b * N + min(n[nb], N - 1)] : -1;             // TOP: `amax` carries slot_of [B][N]
+    if (!valid[nb]) slot[nb] = -1;
   }
   __syncthreads();
 
@@ -707,7 +713,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
         for (int nb = 0; nb < NB; ++nb) {
           f32x4 a;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) a[r] = fmaf(s4[r], valid[nb] ? y_prev[toff_p[nb] + (size_t)(c0 + r) * 32] : 0.f, t4[r]);
+          for (int r = 0; r < 4; ++r) a[r] = fmaf(s4[r], y_prev[toff_p[nb] + (size_t)(c0 + r) * 32], t4[r]);
           split_into<true>(a, bhi[ks][nb], blo[ks][nb], half);
           // the activations of the arg-max points, point-major: what the arg-max part of dW_3 contracts with (gwtf_enc_train_dw3).
           // Here they are in registers; gathered from the (B, C, N) array afterwards every VALUE costs a 128-byte line (72 us).
@@ -731,8 +737,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 #if GWTF_ENC_DBG == 3
           const float yv = 1.0f + (float)idx * 1e-9f, gm = 0.5f;
 #else
-          const float yv = valid[nb] ? y_l[idx] : 0.f;
-          const float gm = valid[nb] ? up_g[idx] : 0.f;
+          const float yv = y_l[idx], gm = up_g[idx];          // (padded tiles: unconditional loads; masked below)
 #endif
           d[r] = valid[nb] ? fmaf(s4[r], gm, fmaf(q4[r], yv, r4[r])) : 0.f;
         }
@@ -744,9 +749,10 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
   if (BOTTOM) {
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-      px[nb] = valid[nb] ? y_prev[((size_t)b * 3 + 0) * N + n[nb]] : 0.f;
-      py[nb] = valid[nb] ? y_prev[((size_t)b * 3 + 1) * N + n[nb]] : 0.f;
-      pz[nb] = valid[nb] ? y_prev[((size_t)b * 3 + 2) * N + n[nb]] : 0.f;
+      const int nc = min(n[nb], N - 1);
+      px[nb] = y_prev[((size_t)b * 3 + 0) * N + nc];
+      py[nb] = y_prev[((size_t)b * 3 + 1) * N + nc];
+      pz[nb] = y_prev[((size_t)b * 3 + 2) * N + nc];
     }
   }
 
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 #if GWTF_ENC_DBG == 2
         yv[r][nb] = 1.0f;
 #else
-        yv[r][nb] = (!BOTTOM && valid[nb]) ? y_prev[toff_p[nb] + (size_t)(j0 + r) * 32] : 0.f;
+        yv[r][nb] = BOTTOM ? 0.f : y_prev[toff_p[nb] + (size_t)(j0 + r) * 32];
 #endif
       }
     }
@@ -800,7 +806,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
             const f32x4 w = *reinterpret_cast<const f32x4*>(&w0s[4 * j]);
             yv = w[0] * px[nb] + (w[1] * py[nb] + w[2] * pz[nb]);
           } else {
-            yv = yv_cur[r][nb];
+            yv = valid[nb] ? yv_cur[r][nb] : 0.f;       // (a select: the padding of the last tile is uninitialised memory)
           }
           const float pre = fmaf(sp[r], yv, tp[r]);
           const bool on = valid[nb] && pre > 0.f;
@@ -809,7 +815,7 @@ __global__ __launch_bounds__(kThreads, NB == 1 ? 4 : 1) void enc_train_bwd_kerne
 #if GWTF_ENC_DBG == 1
           if (!BOTTOM && valid[nb] && gm == 123.456f) dA_prev[toff_p[nb] + (size_t)j * 32] = gm;
 #else
-          if (!BOTTOM && valid[nb]) dA_prev[toff_p[nb] + (size_t)j * 32] = gm;
+          if (!BOTTOM) dA_prev[toff_p[nb] + (size_t)j * 32] = gm;  // (unconditional: zeros into the padding beyond N)
 #endif
           sb += gm;
           sg = fmaf(gm, (yv - mp[r]) * rp[r], sg);
@@ -1183,7 +1189,7 @@ extern "C" int gwtf_enc_train_supported(const int* widths, int n_widths) {
 // floats of one stored activation array of `channels` channels (tiles of 32 points: N padded to whole tiles)
 extern "C" size_t gwtf_enc_train_act_floats(int B, int channels, int N) {
   if (B <= 0 || channels <= 0 || N <= 0) return 0;
-  return (size_t)B * ((N + 31) / 32) * channels * 32;
+  return ((size_t)B * ((N + 31) / 32) + 1) * channels * 32;      // + the spare tile of tix_point
 }
 
 extern "C" size_t gwtf_enc_train_units_floats(int layer) {

@@ -402,7 +402,7 @@ int gwtf_encoder_forward(const float* x, const float* packed, float* features, f
 int gwtf_enc_train_supported(const int* widths, int n_widths);
 size_t gwtf_enc_train_units_floats(int layer);
 /* floats of one stored activation / gradient array of `channels` channels.  y_1, y_2, dA_2, dA_1 are internal to the pipeline and live in
- * tiles of 32 points, [B][ceil(N / 32)][channels][32] (a wave / a k-step takes 32 points x all channels: one contiguous block), NOT in the
+ * tiles of 32 points, [B][ceil(N / 32)][channels][32] + one spare tile (a wave / a k-step takes 32 points x all channels: one contiguous block), NOT in the
  * reference's (B, C, N); only x (B, 3, N) and the pooled (B, 512) outputs keep the reference's layouts. */
 size_t gwtf_enc_train_act_floats(int B, int channels, int N);
 /* W [C[l+1]][C[l]] -> MFMA fragment images of W (forward) and W^T (backward), gwtf_enc_train_units_floats(layer) floats each */
