@@ -101,6 +101,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   }
   __shared__ __align__(16) float lds[K::PW + K::FSP + (LIGHT ? 0 : KB::PB_LDS)];
   __shared__ float s_film[2][3][FP], s_sd0[2][3][FP], s_bias[4];
+  // MERGED / STATS: the statistics' upstream g_stats [2][2][FP] staged once per workgroup (read from global memory where it is used
+  // it was 48 conditional loads -- each its own exec-masked block -- per wave inside the dacc loop)
+  __shared__ __align__(16) float s_gst[(STATS || MERGED) ? 4 * FP : 4];
   // dW1 machinery: coordinates of the workgroup's points, per-wave |dacc| maxima, the transposed dacc image
   constexpr int PTS = 64 * NB;                      // points per workgroup
   constexpr int XPITCH = 2 * PTS + 8;               // bytes per feature row (+8: rows land 8 B apart in the banks)
@@ -114,6 +117,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
     (&s_sd0[0][0][0])[t] = 0.f;
   }
   if (threadIdx.x < 4) s_bias[threadIdx.x] = 0.f;
+  if (STATS || MERGED)
+    for (int t = threadIdx.x; t < 4 * FP; t += blockDim.x) s_gst[t] = (t % FP) < f ? g_stats[t] : 0.f;
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
       for (int r = 0; r < 4; ++r) {
         const int ft = 16 * m + 4 * q + r;
         if (STATS) {
-          const float gs = ft < f ? g_stats[(br * 2 + 0) * FP + ft] : 0.f, gq2 = ft < f ? 2.0f * g_stats[(br * 2 + 1) * FP + ft] : 0.f;
+          const float gs = s_gst[(br * 2 + 0) * FP + ft], gq2 = 2.0f * s_gst[(br * 2 + 1) * FP + ft];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
             const int n = n_wave0 + 16 * nb + i16;
@@ -334,7 +339,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           continue;
         }
         if (MERGED) {     // dy = dacc (coupling path) + gS + 2 gQ y (statistics path), y = acc - c; the FiLM sums were LIGHT's job
-          const float gs = ft < f ? g_stats[(br * 2 + 0) * FP + ft] : 0.f, gq2 = ft < f ? 2.0f * g_stats[(br * 2 + 1) * FP + ft] : 0.f;
+          const float gs = s_gst[(br * 2 + 0) * FP + ft], gq2 = 2.0f * s_gst[(br * 2 + 1) * FP + ft];
           const float cc = fe[16 * m + r];
 #pragma unroll
           for (int nb = 0; nb < NB; ++nb) {
