@@ -1,1 +1,2 @@
-for i in 1 2; do timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -q 2>&1 | grep -E "^E  +(Assert|assert)|passed|failed|^FAILED" | head -6; done
+mkdir -p gpurun_out/t1
+timeout -k 10 1100 python -m pytest tests -m gpu -q 2>&1 | tail -4 | tee gpurun_out/t1/pytest.txt
