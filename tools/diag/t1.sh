@@ -1,6 +1,3 @@
-mkdir -p gpurun_out/t1
-bash tools/profile.sh r15 > gpurun_out/prof_r15.log 2>&1
-bash tools/profile_train.sh r15 > gpurun_out/prof_r15_train.log 2>&1
-bash tools/pmc_any.sh enc15 'enc_' tools/bench_train.py --parts e --steps 4 > /dev/null 2>&1
-timeout -k 10 600 python bench.py > gpurun_out/t1/bench.json 2> gpurun_out/t1/bench.err
-tail -c 300 gpurun_out/t1/bench.json
+timeout -k 10 600 python -m pytest tests/test_gpu_heads.py tests/test_gpu_models.py -x -q 2>&1 | tail -3
+bash tools/step_kstats.sh k6 2>&1 | grep -E "head_"
+for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 2>&1 | grep -E "hipGraph"; done
