@@ -25,7 +25,7 @@ constexpr int kNJ = 1, kCols = 16 * kNJ;   // output (pass 1) / input (pass 2) c
 constexpr int kSplitK = 128;         // contractions at least this long are cut over the eight waves (gemm_splitk)
 constexpr int kGyPitch = kCols + 1;  // the dL/dy block in LDS for the weight gradient: [128 rows][17]
 constexpr int kWorkFloats = 8 * 64 * kCols;      // split-K slabs (32 KB); the dL/dy block (8.5 KB) reuses them
-static_assert(kWorkFloats >= 3 * kMaxM * kGyPitch, "the dL/dy block and the two staged blocks must fit the work area");
+static_assert(kWorkFloats >= kMaxM * kGyPitch, "the dL/dy block must fit the work area");
 
 // C block = A . B^T: the long contractions split over the waves, the short ones one tile per wave
 __device__ __forceinline__ void head_gemm(int M, int N, int K, const float* A, long sai, long sak, const float* Bm, long sbj, long sbk,
@@ -64,21 +64,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
   const ColMap cm = col_map(kCols);
   const int col = c0 + cm.col;
   const bool live = cm.on && cm.col < nc;
-  // The block's Linear outputs (+ bias) are read three times below (mean, variance, epilogue): up to 128 rows they are staged in LDS once
-  // (the product's work area is free again) instead of three dependent round trips to L2 per launch.
-  const bool staged = B <= kMaxM;
-  lptr yb = (lptr)work;                                       // [row][kGyPitch]
-  if (staged) {
-    for (int t = threadIdx.x; t < B * kCols; t += kThreads) {
-      const int b = t / kCols, c = t - b * kCols;
-      yb[b * kGyPitch + c] = c < nc ? ypre[(size_t)b * Dout + c0 + c] + (bias ? bias[c0 + c] : 0.f) : 0.f;
-    }
-    __syncthreads();
-  }
-  auto yat = [&](int b, int c) {
-    if (staged) return yb[b * kGyPitch + c];
-    return c < nc ? ypre[(size_t)b * Dout + c0 + c] + (bias ? bias[c0 + c] : 0.f) : 0.f;
-  };
+  auto yat = [&](int b, int c) { return c < nc ? ypre[(size_t)b * Dout + c0 + c] + (bias ? bias[c0 + c] : 0.f) : 0.f; };
   float mean = 0.f, var = 1.f, rstd = 1.f, ga = 1.f, be = 0.f;
   if (bn_mode == 1) {
     mean = col_sum(cm, kCols, B, [&](int b, int c) { return yat(b, c); }, red) / (float)B;
@@ -158,40 +144,28 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
     }
     phase_sync();
   }
-  __shared__ float work[kWorkFloats];
-  lptr gyt = (lptr)work;                                      // dL/dy block [row][col], pitch 17, zero beyond the batch rows
-  // The block's pre-activations and upstream gradients are read by two column sums and the final pass: up to 128 rows they are staged
-  // in LDS once (one round trip to L2 instead of three dependent ones per launch).
-  const bool staged = B <= kMaxM;
-  lptr sy = (lptr)work + kMaxM * kGyPitch, sgo = sy + kMaxM * kGyPitch;
-  for (int t = threadIdx.x; t < kMaxM * kGyPitch; t += kThreads) gyt[t] = 0.f;
-  if (staged)
-    for (int t = threadIdx.x; t < B * kCols; t += kThreads) {
-      const int b = t / kCols, c = t - b * kCols;
-      const size_t o = (size_t)b * Dout + c0 + min(c, nc - 1);
-      sy[b * kGyPitch + c] = c < nc ? ypre[o] : 0.f;
-      sgo[b * kGyPitch + c] = c < nc ? (act == 2 ? g_y[o] : g_out[o]) : 0.f;
-    }
-  __syncthreads();
-  auto ypre_at = [&](int b, int c) { return staged ? sy[b * kGyPitch + c] : ypre[(size_t)b * Dout + c0 + c]; };
   // ds = dL/d(BatchNorm output) per element, recomputed wherever it is needed (two column sums + the final pass)
   auto ds_at = [&](int b, int c, float mean_c, float rstd_c, float ga_c, float be_c, float bi_c) {
     if (c >= nc) return 0.f;
     const size_t o = (size_t)b * Dout + c0 + c;
-    if (act == 2) return staged ? sgo[b * kGyPitch + c] : g_y[o];
-    const float g = staged ? sgo[b * kGyPitch + c] : g_out[o];
+    if (act == 2) return g_y[o];
+    const float g = g_out[o];
     if (act == 0) return g;
-    float s = ypre_at(b, c) + bi_c;
+    float s = ypre[o] + bi_c;
     if (bn_mode != 0) s = bn_apply(s, mean_c, rstd_c, ga_c, be_c);
     const float sg = 1.0f / (1.0f + expf(-s));
     return g * sg * (1.0f + s * (1.0f - sg));                 // d swish / ds
   };
+  __shared__ float work[kWorkFloats];
+  lptr gyt = (lptr)work;                                      // dL/dy block [row][col], pitch 17, zero beyond the batch rows
+  for (int t = threadIdx.x; t < kMaxM * kGyPitch; t += kThreads) gyt[t] = 0.f;
+  __syncthreads();
   float sum_ds = 0.f, sum_dsx = 0.f;
   if (bn_mode != 0 || g_bias) {
     sum_ds = col_sum(cm, kCols, B, [&](int b, int c) { return ds_at(b, c, mean, rstd, ga, be, bi); }, red);
     if (bn_mode != 0)
       sum_dsx = col_sum(cm, kCols, B, [&](int b, int c) {
-        return c < nc ? ds_at(b, c, mean, rstd, ga, be, bi) * ((ypre_at(b, c) + bi - mean) * rstd) : 0.f; }, red);
+        return c < nc ? ds_at(b, c, mean, rstd, ga, be, bi) * ((ypre[(size_t)b * Dout + c0 + c] + bi - mean) * rstd) : 0.f; }, red);
   }
   if (live && cm.rg == 0) {
     if (bn_mode != 0) {
@@ -210,7 +184,7 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
         const size_t o = (size_t)b * Dout + col;
         float gy = ds_at(b, cm.col, mean, rstd, ga, be, bi);
         if (bn_mode == 1) {
-          const float xh = (ypre_at(b, cm.col) + bi - mean) * rstd;
+          const float xh = (ypre[o] + bi - mean) * rstd;
           gy = ga * rstd * (gy - invB * sum_ds - xh * invB * sum_dsx);
         } else if (bn_mode == 2) {
           gy = ga * rstd * gy;
