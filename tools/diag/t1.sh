@@ -1,3 +1,2 @@
-timeout -k 10 1100 python -m pytest tests/test_gpu_parity.py tests/test_gpu_models.py -x -q -k "train or grad or backward or fused or sgd or step or reproduc" 2>&1 | tail -3
-bash tools/step_kstats.sh k7 2>&1 | grep -E "bwd_kernel<3|bwd_tail1"
-for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 2>&1 | grep -E "hipGraph"; done
+for lib in build_ab/libgwtf_dwplain.so go_with_the_flows_amd/libgwtf_hip.so; do echo "== $lib"; for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 --lib $lib 2>&1 | grep -E "hipGraph"; done; done
+bash tools/step_kstats.sh k8 --lib build_ab/libgwtf_dwplain.so 2>&1 | grep -E "bwd_kernel<3, 2, 3|bwd_tail1"
