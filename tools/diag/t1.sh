@@ -1,2 +1,3 @@
-for lib in build_ab/libgwtf_dwplain.so go_with_the_flows_amd/libgwtf_hip.so; do echo "== $lib"; for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 --lib $lib 2>&1 | grep -E "hipGraph"; done; done
-bash tools/step_kstats.sh k8 --lib build_ab/libgwtf_dwplain.so 2>&1 | grep -E "bwd_kernel<3, 2, 3|bwd_tail1"
+mkdir -p gpurun_out/t1
+timeout -k 10 1100 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee gpurun_out/t1/pytest.txt
+timeout -k 10 600 python bench.py > gpurun_out/t1/bench.json 2> gpurun_out/t1/bench.err; tail -c 200 gpurun_out/t1/bench.json
