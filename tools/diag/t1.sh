@@ -1,3 +1,3 @@
-mkdir -p gpurun_out/t1
-timeout -k 10 1100 python -m pytest tests -m gpu -q 2>&1 | tail -3 | tee gpurun_out/t1/pytest.txt
-timeout -k 10 600 python bench.py > gpurun_out/t1/bench.json 2> gpurun_out/t1/bench.err; tail -c 200 gpurun_out/t1/bench.json
+timeout -k 10 1100 python -m pytest tests/test_gpu_parity.py tests/test_gpu_models.py -x -q -k "train or grad or backward or fused or sgd or step or reproduc" 2>&1 | tail -3
+bash tools/step_kstats.sh k9 2>&1 | grep -E "bwd_kernel<3"
+for i in 1 2; do timeout -k 10 200 python tools/bench_train.py --graph --steps 30 2>&1 | grep -E "hipGraph"; done
