@@ -476,7 +476,8 @@ def main():
             also[name] = {'value': round(a['value'], 3), 'unit': 'Mpoints/s',
                           'ms_per_step': round(a['elapsed'] / args.steps * 1e3, 4), 'steps': args.steps, 'warmup': args.warmup,
                           'workload': a['cfg']['name'],
-                          'roofline': roofline_record(name, a, live=(name == 'm1' and world == 1 and not args.no_live_traffic and not under_profiler()))}
+                          # every shape's HBM traffic is measured by this run (two rocprofv3 --pmc child passes each, a few seconds)
+                          'roofline': roofline_record(name, a, live=(world == 1 and not args.no_live_traffic and not under_profiler()))}
 
         if not args.no_train_step and 'train_step' in selected:
             ts = train_step_record(world, rank, local_rank, dist, dev, args.backend, args.share_device, args.train_step_steps)      # N > 1: every rank takes part (one child per GPU)
@@ -490,8 +491,12 @@ def main():
             'metric': 'point-flow fwd+logdet Mpoints/sec (B x 2048 pts)', 'value': round(m['value'], 3), 'unit': 'Mpoints/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(m['elapsed'] / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': cfg['name'], 'per_gpu_batch': B, 'points_per_shape': N, 'components': K,
+            # I/O, accumulators and every elementwise step are fp32; the f x f contraction is three f16 MFMA products of hi / lo split
+            # fp32 operands (fp32-grade: DESIGN.md section 5); GWTF_TUNE_EXACT_FP32 runs it on the fp32 MFMA instead (also.exact_fp32)
+            'vs_baseline': None, 'dtype': 'f32 (split-f16 x3 MFMA, fp32 accumulate)', 'data': 'synthetic',
+            'config': {'workload': cfg['name'] + (' -- leads the line because it is the largest single-GPU config of BASELINE.json '
+                                                  '(configs[1]); the north-star shape B=32 x 2048, f=64 is also.m1' if args.workload == 'airplane' else ''),
+                       'per_gpu_batch': B, 'points_per_shape': N, 'components': K,
                        'couplings_per_component': 3 * L, 'f': f, 'G': G, 'direction': mode,
                        'point_definition': 'one 3-D point through one component stack (coords + sum logvars)',
                        'sharding': f'batch of shapes over {world} rank(s), no data-path collective',

@@ -100,20 +100,11 @@ def fold(engine, g, eps):
     s1 = 1.0 / torch.sqrt(rv1 + BN_EPS)
     W1p = P['W1'] * s1.unsqueeze(-1)
     c1 = -rm1 * s1
-    if g.is_cuda:
-        # the FiLM heads (Linear -> BatchNorm with running statistics -> Swish -> Linear -> exp) in HIP, forward and backward
-        # (csrc/gwtf_film_train.hip), parameters read in place from the arena
-        film_raw, _, _ = FilmHeadsFn.apply(P['raw'], g, engine.C, engine.f, engine.G, 0, g.shape[0], eps, False)
-        a, bsh = film_raw[:, :, :, 0, :engine.f], film_raw[:, :, :, 1, :engine.f]
-    else:
-        hg, hb, hrm, hrv = P['hbn']
-        S = hg / torch.sqrt(hrv + BN_EPS)
-        T = hb - hrm * S
-        hraw = torch.einsum('bg,cxhfg->bcxhf', g, P['L0'])
-        hbn = hraw * S + T
-        hn = hbn * torch.sigmoid(hbn)
-        o = torch.einsum('bcxhi,cxhji->bcxhj', hn, P['L1']) + P['b1']
-        a, bsh = eps + torch.exp(o[:, :, :, 0]), o[:, :, :, 1]
+    # the FiLM heads (Linear -> BatchNorm with running statistics -> Swish -> Linear -> exp) in HIP, forward and backward
+    # (csrc/gwtf_film_train.hip), parameters read in place from the arena; CPU / non-fp32 tensors raise (there is no torch
+    # restatement in the package: tests/test_gpu_film_heads.py holds the one the kernels are checked against)
+    film_raw, _, _ = FilmHeadsFn.apply(P['raw'], g, engine.C, engine.f, engine.G, 0, g.shape[0], eps, False)
+    a, bsh = film_raw[:, :, :, 0, :engine.f], film_raw[:, :, :, 1, :engine.f]
     cvec = c1 + bsh / a
     u = P['W2'].unsqueeze(0) * a.unsqueeze(3)
     # Range scaling of the split-f16 contraction's operands, as the eval packer applies it (csrc/gwtf_layout.h, RANGE SCALING):
@@ -398,8 +389,13 @@ class _BNSwishRows(torch.autograd.Function):
         return gx, gp[0].view(hraw.shape[1:]), gp[1].view(hraw.shape[1:])
 
 
+PATHS = {'film_heads_hip': 0, 'film_heads_torch': 0}     # which FiLM-head implementation ran (tools/bench_train.py reports it)
+
+
 def _film_train(P, g, eps):
-    """FiLM heads with batch statistics over the B latent rows -> a, bsh (B,C,2,f) and batch {mean, unbiased var}."""
+    """FiLM heads with batch statistics over the B latent rows -> a, bsh (B,C,2,f) and batch {mean, unbiased var}.
+    torch ops: only the per-coupling cross-check chain (force_autograd_chain) comes through here."""
+    PATHS['film_heads_torch'] += 1
     hg, hb, _, _ = P['hbn']
     hraw = torch.einsum('bg,cxhfg->bcxhf', g, P['L0'])
     Bn = hraw.shape[0]
@@ -422,10 +418,15 @@ class FilmHeadsFn(torch.autograd.Function):
     def forward(ctx, raw, g_all, KC, f, G, row0, B, eps, training):
         L = _lib.lib()
         raw, g_all = raw.contiguous(), g_all.contiguous().float()
+        _lib._ptr(raw, 'the raw parameter arena')          # fp32, on a HIP device: a .double()'d or CPU module raises here
+        _lib._ptr(g_all, 'g')
+        if raw.device != g_all.device:
+            raise _lib.GwtfError(f'FilmHeadsFn: parameters on {raw.device}, latents on {g_all.device}')
         dev = raw.device
         Ball, H, FP = g_all.shape[0], 4 * KC, L.gwtf_padded_width(f)
         if raw.numel() != KC * L.gwtf_raw_coupling_floats(f, G):
             raise _lib.GwtfError(f'FilmHeadsFn: arena of {raw.numel()} floats for {KC} couplings')
+        PATHS['film_heads_hip'] += 1
         poison = branch_poison(raw, KC).contiguous()
         hraw = torch.empty(Ball, H, f, device=dev, dtype=torch.float32)
         hn = torch.empty_like(hraw)

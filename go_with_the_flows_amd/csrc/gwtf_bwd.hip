@@ -28,6 +28,10 @@
 #ifndef GWTF_K2_MASK
 #define GWTF_K2_MASK 15     // A/B knob: which compile-time-pattern variants the launcher uses (1 / 2: light pass, one warped / one kept; 4 / 8: merged pass)
 #endif
+#ifndef GWTF_BWD_ABLATE
+#define GWTF_BWD_ABLATE 0   // TIMING PROBES of the merged pass (wrong results): 1 no sd0 LDS atomics | 2 no dW1 partial stores | 4 per-wave
+                            // scale (no amax barrier) | 8 no dW1 product | 16 no sd0 sums at all | 32 no transposed-dacc stores
+#endif
 namespace {
 
 using namespace gwtf_dev;
@@ -112,6 +116,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   __shared__ float2 s_pts[PTS];
   __shared__ float s_amax[2][4];
   __shared__ __align__(16) unsigned char s_xt_own[XALIAS ? 16 : XBYTES];
+#ifdef GWTF_BWD_LDS_PAD      // A/B knob: KiB of dead LDS in the merged pass (forces fewer workgroups per compute unit; docs/LOG.md round 5)
+  __shared__ float s_pad[MERGED ? GWTF_BWD_LDS_PAD * 256 : 1];
+  if (B < 0) { s_pad[threadIdx.x] = eps; g_in[0] = s_pad[N & 255]; }
+#endif
   for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
     (&s_film[0][0][0])[t] = 0.f;
     (&s_sd0[0][0][0])[t] = 0.f;
@@ -361,10 +369,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           sdc += da;
           acc[br][m][nb][r] = da;
         }
-        sdc = row_sum16(sdc);
-        sdu0 = row_sum16(sdu0);
-        if (!ONE_W) sdu1 = row_sum16(sdu1);
-        if (i16 == 0) {
+        sdc = row_sum_part(sdc);
+        sdu0 = row_sum_part(sdu0);
+        if (!ONE_W) sdu1 = row_sum_part(sdu1);
+        if (row_sum_owner(i16)) {
           atomicAdd(&s_film[br][0][ft], sdc);
           atomicAdd(&s_film[br][1][ft], sdu0);
           if (!ONE_W) atomicAdd(&s_film[br][2][ft], sdu1);        // (zero on entry: the absent column's sum stays zero)
@@ -386,8 +394,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
     amax = wave_max(amax);
     if (lane == 0) s_amax[br][wave] = amax;
     if (br == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of branch 1's W1T have landed
+    if (!((GWTF_BWD_ABLATE & 4) && MERGED)) {
     __syncthreads();   // also: every wave is past its forward recompute (branch 0) / past reading the previous X image (branch 1)
     amax = fmaxf(fmaxf(s_amax[br][0], s_amax[br][1]), fmaxf(s_amax[br][2], s_amax[br][3]));
+    }
     const int ebits = (__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, amax)) >> 23) & 0xff;
     const bool rescale = ebits >= 16 && ebits <= 240;
     const float up = rescale ? __builtin_bit_cast(float, (262 - ebits) << 23) : 1.0f;     // 2^(8 - (ebits - 127))
@@ -449,10 +459,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           if (!ONE_K) g1 = fmaf(dp, xb[nb], g1);
           g2 += dp;
         }
-        g0 = row_sum16(g0);
-        if (!ONE_K) g1 = row_sum16(g1);
-        g2 = row_sum16(g2);
-        if (i16 == 0) {
+        if ((GWTF_BWD_ABLATE & 16) && MERGED) continue;
+        g0 = row_sum_part(g0);
+        if (!ONE_K) g1 = row_sum_part(g1);
+        g2 = row_sum_part(g2);
+        if ((GWTF_BWD_ABLATE & 1) && MERGED) { asm volatile("" :: "v"(g0), "v"(g1), "v"(g2)); continue; }
+        if (row_sum_owner(i16)) {
           atomicAdd(&s_sd0[br][0][fi], g0);
           if (!ONE_K) atomicAdd(&s_sd0[br][1][fi], g1);          // (zero on entry: the absent column's sum stays zero)
           atomicAdd(&s_sd0[br][2][fi], g2);
@@ -473,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int m = 2 * ks + (e >> 2);
-            if (m < MB) {
+            if (m < MB && !((GWTF_BWD_ABLATE & 32) && MERGED)) {
               unsigned char* dst = xt + (16 * m + 4 * q + (e & 3)) * XPITCH + col + 32 * nb;
               *reinterpret_cast<_Float16*>(dst) = dhi[ks][nb][e];
               *reinterpret_cast<_Float16*>(dst + FP * XPITCH) = dlo[ks][nb][e];
@@ -485,7 +497,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           __builtin_amdgcn_global_load_lds((glb_void*)(pb_c + KB::W1T + piece * 256 + lane * 4),
                                            (lds_void*)&lds[K::PW + K::FSP + piece * 256], 16, 0, 0);
       }
-      for (int ni = wave; ni < MB; ni += 4) {                // this wave's column(s) of output tiles: h features 16 ni .. (f > 64: two)
+      for (int ni = wave; ni < MB && !((GWTF_BWD_ABLATE & 8) && MERGED); ni += 4) {   // this wave's column(s) of output tiles: h features 16 ni .. (f > 64: two)
         const f32x4 sp = sd0n[16 * ni + i16];                 // the lane's h feature: {w0a, w0b, c0, -}
         f32x4 dw[MB];
 #pragma unroll
@@ -535,7 +547,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 #pragma unroll
           for (int r = 0; r < 4; ++r) {  // streaming store: the partials are read once, by another kernel -- keep them out of L2
             const int row = 16 * mi + 4 * q + r;
-            if (row < f && col < f) __builtin_nontemporal_store(dw[mi][r] * down, &out[row * f + col]);
+            if (row < f && col < f && !((GWTF_BWD_ABLATE & 2) && MERGED && N > 0)) __builtin_nontemporal_store(dw[mi][r] * down, &out[row * f + col]);
           }
       }
     }
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * mi + 4 * q + r;
-        if (row < f && col < f) __builtin_nontemporal_store(dwk[mi][r], &out[row * f + col]);
+        if (row < f && col < f && !((GWTF_BWD_ABLATE & 2) && MERGED && N > 0)) __builtin_nontemporal_store(dwk[mi][r], &out[row * f + col]);
       }
   }
 #pragma unroll

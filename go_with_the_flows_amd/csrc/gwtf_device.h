@@ -88,6 +88,29 @@ __device__ __forceinline__ float row_sum16(float v) {
   return v;
 }
 
+// Row sums that end in an LDS atomic (the per-feature sums over a workgroup's points).  GWTF_ROWSUM_MODE:
+//   0  row_sum16 + an atomic from lane 0 of each row.  The compiler sinks the LAST DPP add into the exec-masked block of the atomic and
+//      leaves `v_mov_b32 old, 0` + `v_mov_b32_dpp` outside it: 6 VALU per sum (tools/isa_lines.py census, docs/LOG.md round 5).
+//   1  the same four steps with the total pinned outside the masked block (an empty asm use): 4 fused v_add_f32_dpp per sum.
+//   2  two quad steps only; the four quad leaders of a row (i16 % 4 == 0) add their partials to the same LDS word: 2 VALU per sum,
+//      a 4-way same-address conflict per row in the LDS atomic instead of two more dependent DPP steps.
+#ifndef GWTF_ROWSUM_MODE
+#define GWTF_ROWSUM_MODE 1
+#endif
+__device__ __forceinline__ float row_sum_part(float v) {
+  if (GWTF_ROWSUM_MODE == 0) return row_sum16(v);
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  if (GWTF_ROWSUM_MODE == 1) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, false));  // row_mirror
+  }
+  asm("" : "+v"(v));      // the sum is complete in EVERY lane here: nothing of it moves into the owners' masked block
+  return v;
+}
+// lanes of a 16-lane row that hand their row_sum_part to the LDS atomic
+__device__ __forceinline__ bool row_sum_owner(int i16) { return GWTF_ROWSUM_MODE == 2 ? (i16 & 3) == 0 : i16 == 0; }
+
 // Sum the per-quarter partials o[nb] over the four 16-lane quarters so that the lane in quarter q ends
 // with the total of point block (q & (NB-1)).
 template <int NB>

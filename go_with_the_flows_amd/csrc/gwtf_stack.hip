@@ -456,9 +456,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
           s1 += v;
           s2 = fmaf(v, v, s2);
         }
-        s1 = row_sum16(s1);
-        s2 = row_sum16(s2);
-        if (i16 == 0) {
+        s1 = row_sum_part(s1);
+        s2 = row_sum_part(s2);
+        if (row_sum_owner(i16)) {
           const int ft = 16 * m + 4 * q + r;
           atomicAdd(&s_stats[(br * FP + ft) * 2 + 0], s1);   // LDS: 4 waves
           atomicAdd(&s_stats[(br * FP + ft) * 2 + 1], s2);

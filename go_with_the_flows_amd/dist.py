@@ -93,9 +93,11 @@ def syncs_statistics(bn_modules):
 # Per-shape work (the FiLM heads of the decoders, the prior flow on the latent, the Gaussian heads) is a few MFLOP on B rows:
 # every rank runs it on the rows of ALL ranks (one all-gather of the B x G latents) instead of synchronising the statistics of
 # each of its BatchNorm layers -- same numbers as SyncBatchNorm, two collectives per module instead of two per layer.  That
-# needs every rank's row count.  The reference's loader gives a rank the same batch on every step (DistributedSampler +
-# drop_last, train_ae.py:77-78,97-109), so the counts are exchanged ONCE per distinct local batch size and cached: no
-# device-to-host synchronisation in the step, which is what lets the whole step be captured in a hipGraph.
+# needs every rank's row count.  Eager steps exchange the counts at EVERY lookup (one 8-byte all-gather: every rank enters the
+# same collective whatever its own batch did, so a batch size that changes on one rank only can never pair a size exchange on
+# that rank with a row gather on another); a captured hipGraph step cannot talk to the host and replays the layout of the eager
+# warm-up step that preceded its capture -- its loader must keep the per-rank batch fixed, as the reference's do (DistributedSampler
+# + drop_last, train_ae.py:77-78,97-109).
 class RowLayout:
     __slots__ = ('sizes', 'row0', 'total', 'even')
 
@@ -109,55 +111,51 @@ class RowLayout:
 
 
 _ROW_LAYOUTS = {}
+ROW_EXCHANGES = {'n': 0}      # size exchanges done by this process (tests read it)
 
 
 def reset_row_layouts():
-    """Forget the cached per-rank batch sizes (call on every rank when the per-rank batch size changes on SOME rank only)."""
+    """Forget the cached per-rank batch sizes (they are only ever used inside hipGraph captures and under
+    GWTF_ROW_LAYOUT_TRUST_CACHE=1; kept for callers of earlier versions)."""
     _ROW_LAYOUTS.clear()
-
-
-_ROW_CHECK = {'calls': 0}
 
 
 def _exchange_sizes(rows, device, world, rank):
     on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
     sizes = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
     dist.all_gather(sizes, torch.tensor([int(rows)], dtype=torch.int64, device=on))
+    ROW_EXCHANGES['n'] += 1
     return RowLayout([int(x.item()) for x in sizes], rank)
 
 
 def row_layout(rows, device):
-    """The number of rows every rank of the default group holds, given that this rank holds `rows`.  Collective on first
-    use of a value of `rows` (every rank must call it then), cached afterwards.  The cache is keyed by THIS rank's row count,
-    so a batch size that changes on some other rank only (a loader without drop_last, an evaluation pass) would go unnoticed:
-    the model's train() / eval() transitions call reset_row_layouts(), and outside hipGraph captures every
-    GWTF_ROW_LAYOUT_CHECK_EVERY-th lookup (default 64; 0 = never) exchanges the sizes again and raises on a mismatch.  A
-    captured step cannot check: its loader must keep the per-rank batch fixed (the reference's loaders use drop_last=True)."""
+    """The number of rows every rank of the default group holds, given that this rank holds `rows`.
+    Outside hipGraph captures this is a collective on EVERY call (all ranks must call it in the same order -- they do: the calls
+    are the model's per-step module calls) and its result is remembered under this rank's row count.  Inside a capture nothing
+    can be exchanged: the remembered layout of the last eager call with the same `rows` is used (GraphedTrainStep and every
+    capture of this package run an eager warm-up step first) and a missing one raises.
+    GWTF_ROW_LAYOUT_TRUST_CACHE=1 (set on ALL ranks or on none) restores exchange-once-per-batch-size for eager loops whose
+    per-rank batch never changes: no device-to-host synchronisation after the first step, and no protection either."""
     if not (dist.is_available() and dist.is_initialized()):
         return RowLayout([rows], 0)
     world, rank = dist.get_world_size(), dist.get_rank()
+    if world == 1:
+        return RowLayout([rows], 0)
     key = (world, rank, int(rows))
-    lay = _ROW_LAYOUTS.get(key)
     capturing = device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
-    if lay is None:
-        if world == 1:
-            lay = RowLayout([rows], 0)
-        else:
-            if capturing:
-                raise RuntimeError('the per-rank batch sizes are exchanged on the first step with a given batch size: run one '
-                                   'step outside the hipGraph capture first (GraphedTrainStep does)')
-            lay = _exchange_sizes(rows, device, world, rank)
-        _ROW_LAYOUTS[key] = lay
-    elif world > 1 and not capturing and int(os.environ.get('GWTF_ROW_LAYOUT_CHECK_EVERY', '64')) > 0:
-        # (the lookup count advances identically on every rank: the lookups are the model's per-step calls)
-        _ROW_CHECK['calls'] += 1
-        if _ROW_CHECK['calls'] % int(os.environ.get('GWTF_ROW_LAYOUT_CHECK_EVERY', '64')) == 0:
-            now = _exchange_sizes(rows, device, world, rank)
-            if now.sizes != lay.sizes:
-                _ROW_LAYOUTS.clear()
-                raise RuntimeError(f'per-rank batch sizes changed from {lay.sizes} to {now.sizes} while this rank kept {rows} rows: '
-                                   'call dist.reset_row_layouts() on every rank when any rank\'s batch size changes')
-    return lay
+    lay = _ROW_LAYOUTS.get(key)
+    if capturing:
+        if lay is None:
+            raise RuntimeError('the per-rank batch sizes are exchanged by eager steps: run one step with this batch size outside '
+                               'the hipGraph capture first (GraphedTrainStep does)')
+        return lay
+    if lay is not None and os.environ.get('GWTF_ROW_LAYOUT_TRUST_CACHE') == '1':
+        return lay
+    now = _exchange_sizes(rows, device, world, rank)
+    if lay is not None and lay.sizes == now.sizes:
+        return lay                                          # unchanged: callers may compare layouts by identity
+    _ROW_LAYOUTS[key] = now
+    return now
 
 
 def _gather_padded(t, lay):

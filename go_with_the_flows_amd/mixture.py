@@ -66,11 +66,12 @@ class MixtureStack:
         pw, film, eps = self._film(g.contiguous().float())
         return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode)
 
-    def forward_all_lists(self, p, g, mode='inverse'):
+    def forward_all_lists(self, p, g, mode='inverse', defer_running_stats=False):
         """Every component on every point, train-mode BatchNorm, WITH the reference's per-coupling lists: -> (out, logdet (K,B,3,N),
         (ps, mus, logvars) each (K, C, B, 3, N) direct-ordered; ps / logvars differentiable in every slot, a gradient through mus
         raises) -- the K list-API decoder calls of flow_mixture.py:163-166 as ONE pass of the K-batched pipeline.  None when that
-        pipeline does not apply (eval-mode BatchNorm, the cross-check chain): the caller then takes the per-decoder route."""
+        pipeline does not apply (eval-mode BatchNorm, the cross-check chain): the caller then takes the per-decoder route.
+        defer_running_stats: return bn_batch (K, ...) as a fourth value instead of updating the BatchNorm buffers here."""
         e0 = self.engines[0]
         e0._check(p, g)
         if not e0.couplings[0].training or any(getattr(e, 'force_autograd_chain', False) for e in self.engines):
@@ -81,6 +82,9 @@ class MixtureStack:
             t.requires_grad for d in self.decoders for t in d.parameters()))
         with torch.set_grad_enabled(needs_grad):
             out, logdet, lists, bn_batch = train_density_forward_multi(self.engines, p, g, mode, distributed=_sharded())
+        if defer_running_stats:
+            # the sibling round of decoders._SiblingGroup: every decoder's buffers are updated when its own call arrives
+            return out, logdet, lists, bn_batch
         for k, e in enumerate(self.engines):
             e._update_running_stats(bn_batch[k])
             e._last_lists = None

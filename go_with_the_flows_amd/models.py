@@ -261,7 +261,11 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
             assert p_input.shape[0] == 1                     # evaluation feeds one shape at a time (flow_mixture.py:146)
             flows_idx = self._draw_components(logits[0], n_sampled_points)
             sizes = [int((flows_idx == t).sum()) for t in range(K)]
-        output_decoder = self._decode_training_batched(p_input, g_sample, sizes) if self.mode == 'training' else None
+        # literal_k_loop: this mirror's own shortcut off -- the K decoders are called one at a time exactly as the reference's loop
+        # does (flow_mixture.py:163-166), which is what a maintainer who only swaps the decoder import runs (tools/bench_train.py
+        # --api swap; the decoders' sibling batching, decoders._SiblingGroup, then does the batching below the API)
+        batched = self.mode == 'training' and not getattr(self, 'literal_k_loop', False)
+        output_decoder = self._decode_training_batched(p_input, g_sample, sizes) if batched else None
         if output_decoder is None:
             output_decoder = [self.one_flow_decode(p_input, g_sample, self.pc_decoder[i], sizes[i]) for i in range(K)]
         if not labeled_samples:

@@ -210,7 +210,7 @@ int gwtf_train_backward(const float* p, const float* ps, const float* g_out, con
  * Replaces T_*_0_cond_w / T_*_0_cond_b of every coupling (reference lib/networks/flows.py:33-45, 68-80, evaluated at :100-101,
  * 105-106): Linear(G -> f) -> BatchNorm1d over the latent rows -> Swish -> Linear(f -> f); a = eps + exp(scale head), b = shift head.
  * H = 4 KC heads (KC couplings in all: K stacks x C), one workgroup per head, parameters read in place from the raw arena
- * [KC][raw coupling record]; training = 1: batch statistics over the B_all rows (<= 128; all ranks' rows when data parallel),
+ * [KC][raw coupling record]; training = 1: batch statistics over the B_all rows (any number <= 65536, walked 128 at a time; all ranks' rows when data parallel),
  * 0: the arena's running statistics.
  *   g [B_all][G]; poison [KC][2] (0 or NaN, added to the scale a: diverged weights reach every output) or NULL
  *   hraw, hn [B_all][H][f] (pre-BatchNorm / post-Swish activations, kept for the backward); stats [3][H][f] = mean, biased var, rstd

@@ -106,7 +106,7 @@ def _rows_worker(rank, world, port):
     lay = gd.row_layout(b1 - b0, torch.device('cpu'))
     assert lay.sizes == [gd.shard_bounds(B, r, world)[1] - gd.shard_bounds(B, r, world)[0] for r in range(world)]
     assert (lay.row0, lay.total, lay.even) == (b0, B, B % world == 0)
-    assert gd.row_layout(b1 - b0, torch.device('cpu')) is lay                    # cached: no second exchange
+    assert gd.row_layout(b1 - b0, torch.device('cpu')) is lay                    # unchanged sizes: the same layout object
     mine = full[b0:b1].clone().requires_grad_(True)
     rows, lay2 = gd.gather_rows(mine)
     assert torch.equal(rows, full) and lay2 is lay
@@ -197,32 +197,36 @@ def test_data_parallel_wrapper_starts_every_rank_from_rank0_state(world):
 
 def _row_layout_worker(rank, world, port):
     sys.path.insert(0, ROOT)
-    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      GWTF_ROW_LAYOUT_CHECK_EVERY='4')
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from go_with_the_flows_amd import dist as gd
     gd.init_from_env('gloo')
     cpu = torch.device('cpu')
-    lay = gd.row_layout(5, cpu)                       # both ranks hold 5 rows: exchanged once, cached
+    lay = gd.row_layout(5, cpu)                       # both ranks hold 5 rows
     assert lay.sizes == [5, 5] and lay.total == 10 and lay.row0 == 5 * rank
+    n0 = gd.ROW_EXCHANGES['n']
     for _ in range(3):
-        assert gd.row_layout(5, cpu) is lay           # cached lookups (no collective)
-    assert gd.row_layout(5, cpu) is lay               # 4th cached lookup: sizes exchanged again, still equal
-    # rank 1's loader now delivers 3 rows while rank 0 keeps 5: rank 0's cache key (its own 5 rows) is unchanged -- without the
-    # periodic check it would go on slicing with the stale layout.  Rank 1 has no entry for 3 rows and exchanges at once; rank 0
-    # joins that exchange with its 4th lookup since the last check and raises.
-    if rank == 1:
-        assert gd.row_layout(3, cpu).sizes == [5, 3]
-    else:
-        for _ in range(3):
-            gd.row_layout(5, cpu)
-        with pytest.raises(RuntimeError, match='per-rank batch sizes changed'):
-            gd.row_layout(5, cpu)
+        assert gd.row_layout(5, cpu) is lay           # unchanged sizes: the same object ...
+    assert gd.ROW_EXCHANGES['n'] == n0 + 3            # ... but every eager lookup exchanged the sizes again
+    # rank 1's loader now delivers 3 rows while rank 0 keeps 5.  Rank 0's own count is unchanged -- with a cache keyed on it (rounds
+    # 3-4) rank 0 went straight to the row gather while rank 1 exchanged sizes: mismatched collectives.  Every lookup exchanges
+    # now, so both ranks learn the new layout in the SAME collective, whichever rank's batch changed.
+    now = gd.row_layout(3 if rank == 1 else 5, cpu)
+    assert now.sizes == [5, 3] and now.total == 8 and now.row0 == (0 if rank == 0 else 5)
+    rows, lay2 = gd.gather_rows(torch.full((3 if rank == 1 else 5, 2), float(rank)))
+    assert lay2.sizes == [5, 3] and torch.equal(rows, torch.cat([torch.zeros(5, 2), torch.ones(3, 2)]))
+    # back to 5 / 5: the remembered layout of this rank's 5 rows had become [5, 3] on rank 0 -- it is replaced, not trusted
+    assert gd.row_layout(5, cpu).sizes == [5, 5]
+    # opt-out for fixed-batch eager loops: exchange once per batch size, cached afterwards (no collective, no protection)
+    os.environ['GWTF_ROW_LAYOUT_TRUST_CACHE'] = '1'
+    n1 = gd.ROW_EXCHANGES['n']
+    assert gd.row_layout(5, cpu).sizes == [5, 5] and gd.ROW_EXCHANGES['n'] == n1
+    del os.environ['GWTF_ROW_LAYOUT_TRUST_CACHE']
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_row_layout_cache_notices_a_batch_size_change_on_another_rank():
-    """the per-rank row counts are cached by THIS rank's count only; a periodic re-exchange outside graph captures
-    turns a silent stale layout into an error."""
+    """the size exchange is unconditional outside graph captures, so a batch size that changes on ONE rank reaches every
+    rank in the same collective (the periodic re-check of round 4 only worked when the change landed on a rank's 64th lookup)."""
     port = 29500 + (os.getpid() + 977) % 2000
     mp.spawn(_row_layout_worker, args=(2, port), nprocs=2, join=True)

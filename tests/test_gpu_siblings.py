@@ -1,0 +1,127 @@
+"""The literal import swap: the reference keeps its K decoders in an nn.ModuleList and calls them ONE AT A
+TIME on the same (p, g) (flow_mixture.py:163-166).  decoders._SiblingGroup turns a round of such calls into one pass of the K-batched
+train pipeline once it has observed one; these tests pin that nothing observable changes.  Needs an MI355X."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+import go_with_the_flows_amd as gw
+from helpers import maxabs
+from go_with_the_flows_amd.mixture import MixtureStack
+from go_with_the_flows_amd.synth import load_synth_, synth_inputs
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+K, L, F, G, B, N = 3, 2, 37, 16, 6, 384
+
+
+class Holder(nn.Module):
+    """What the reference's model is to its decoders: an nn.ModuleList and a loop."""
+
+    def __init__(self):
+        super().__init__()
+        self.pc_decoder = nn.ModuleList([gw.LocalCondRNVPDecoder(L, F, G) for _ in range(K)])
+
+    def decode(self, p, g):
+        return [self.pc_decoder[i](p, g, mode='inverse') for i in range(K)]       # flow_mixture.py:163-166
+
+
+def build():
+    m = Holder()
+    load_synth_(m, 77)
+    return m.to(DEV).train()
+
+
+def inputs(seed):
+    p, g = synth_inputs(B, N, G, seed)
+    return torch.from_numpy(p).to(DEV), torch.from_numpy(g).to(DEV)
+
+
+def loss_of(outs):
+    """Reads what the reference's loss reads (ps[0], every logvars slot) plus an inner ps slot."""
+    tot = 0.0
+    for k, (ps, mus, lvs) in enumerate(outs):
+        tot = tot + (ps[0] ** 2).sum() * 0.5 + sum(lvs).sum() + (ps[2 + k] * 0.3).sum()
+    return tot / B
+
+
+def run_rounds(m, rounds, monkeypatch=None, off=False):
+    if off:
+        monkeypatch.setenv('GWTF_NO_SIBLING_BATCH', '1')
+    res = []
+    for r in range(rounds):
+        p, g = inputs(10 + r)
+        p.requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        outs = m.decode(p, g)
+        loss_of(outs).backward()
+        res.append(dict(lists=[[[t.detach().cpu().numpy() for t in lst] for lst in o] for o in outs],
+                        gp=p.grad.cpu().numpy(),
+                        grads={n: v.grad.cpu().numpy() for n, v in m.named_parameters() if v.grad is not None},
+                        running={n: v.cpu().numpy().copy() for n, v in m.state_dict().items() if 'running' in n or 'num_batches' in n}))
+    if off:
+        monkeypatch.delenv('GWTF_NO_SIBLING_BATCH')
+    return res
+
+
+def test_sequential_sibling_calls_become_one_batched_round_with_identical_results(monkeypatch):
+    a, b = build(), build()
+    ra = run_rounds(a, 3)
+    rb = run_rounds(b, 3, monkeypatch, off=True)                # the K separate pipelines, every round
+    st = a.pc_decoder[0].sibling_group().stats
+    assert st == {'batched_rounds': 2, 'abandoned_rounds': 0, 'single_calls': K}, st       # round 1 observed, rounds 2-3 batched
+    assert b.pc_decoder[0].sibling_group().stats['batched_rounds'] == 0
+    for xa, xb in zip(ra, rb):
+        for oa, ob in zip(xa['lists'], xb['lists']):
+            for la, lb in zip(oa, ob):
+                assert len(la) == len(lb) == 3 * L
+                for ta, tb in zip(la, lb):
+                    assert maxabs(ta, tb) <= 2e-6 * max(1.0, np.abs(tb).max())
+        assert maxabs(xa['gp'], xb['gp']) <= 2e-5 * np.abs(xb['gp']).max()
+        assert set(xa['grads']) == set(xb['grads'])
+        gmax = max(np.abs(v).max() for v in xb['grads'].values())
+        assert max(maxabs(xa['grads'][n], xb['grads'][n]) for n in xb['grads']) <= 1e-4 * gmax
+        for n in xb['running']:
+            assert maxabs(xa['running'][n], xb['running'][n]) <= 1e-6 * max(1.0, np.abs(xb['running'][n]).max()), n
+
+
+def test_batched_round_equals_forward_all_lists_of_the_same_decoders():
+    a, b = build(), build()
+    run_rounds(a, 1)                                                            # observe
+    p, g = inputs(5)
+    with torch.no_grad():
+        outs = a.decode(p, g)                                                   # batched round (no autograd: train-mode forward only)
+        z, ld, (ps, mus, lvs) = MixtureStack(b.pc_decoder).forward_all_lists(p, g, 'inverse')
+    assert a.pc_decoder[0].sibling_group().stats['batched_rounds'] == 1
+    for k in range(K):
+        for j in range(3 * L):
+            for got, want in ((outs[k][0][j], ps[k, j]), (outs[k][1][j], mus[k, j]), (outs[k][2][j], lvs[k, j])):
+                assert maxabs(got.cpu().numpy(), want.cpu().numpy()) <= 2e-6 * max(1.0, float(want.abs().max()))
+
+
+def test_an_unfinished_round_switches_the_group_back_and_updates_only_the_called_decoder():
+    a = build()
+    run_rounds(a, 1)                                                            # observe: confirmed
+    before = {n: v.clone() for n, v in a.state_dict().items() if 'running_mean' in n}
+    p, g = inputs(3)
+    with torch.no_grad():
+        a.pc_decoder[0](p, g, mode='inverse')                                   # speculated round; siblings never ask
+        p2, g2 = inputs(4)
+        a.pc_decoder[0](p2, g2, mode='inverse')                                 # a new round: the old one is abandoned
+    st = a.pc_decoder[0].sibling_group().stats
+    assert st['batched_rounds'] == 1 and st['abandoned_rounds'] == 1 and not a.pc_decoder[0].sibling_group().confirmed
+    after = a.state_dict()
+    moved = {n.split('.')[1] for n, v in before.items() if not torch.equal(v, after[n])}
+    assert moved == {'0'}, moved                                                # decoders 1, 2 kept their BatchNorm buffers
+
+
+def test_eval_mode_and_lone_decoders_take_the_plain_path():
+    a = build().eval()
+    p, g = inputs(1)
+    with torch.no_grad():
+        for _ in range(2):
+            a.decode(p, g)
+    assert a.pc_decoder[0].sibling_group().stats == {'batched_rounds': 0, 'abandoned_rounds': 0, 'single_calls': 0}
+    lone = gw.LocalCondRNVPDecoder(L, F, G)
+    assert lone.sibling_group() is None

@@ -30,9 +30,12 @@ ap.add_argument('--batch', type=int, default=64)
 ap.add_argument('--points', type=int, default=2048)
 ap.add_argument('--steps', type=int, default=5)
 ap.add_argument('--graph', action='store_true', help='capture forward + backward in one hipGraph')
-ap.add_argument('--api', default='fused', choices=['fused', 'list', 'both'],
+ap.add_argument('--api', default='fused', choices=['fused', 'list', 'both', 'swap', 'swap_loop'],
                 help="fused: forward_fused + Flow_Mixture_Loss.fused; list: the reference's own call, model(g, p) -> lists -> loss; "
-                     "both: fused, then a second graph of the list call in the same process")
+                     "both: fused, then a second graph of the list call in the same process; swap: the literal import swap of "
+                     "INTEGRATION.md section 1 -- the K decoders called ONE AT A TIME (flow_mixture.py:163-166) and the loss on their "
+                     "lists; swap_loop: the same with the loss as the reference's B x K Python loop (losses.py:109-131, restated "
+                     "below).  GWTF_NO_SIBLING_BATCH=1 turns the decoders' sibling batching off (what round 4 shipped)")
 ap.add_argument('--lib', default=None, help='A/B: load this build of libgwtf_hip.so instead of the in-tree one')
 ap.add_argument('--parts', default='epd', help='debug: which parts run (e=encoder, p=prior flow, d=decoders)')
 ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend of a data-parallel run (nccl = RCCL)')
@@ -82,12 +85,38 @@ reducer = OverlappedGradients(model) if sharded() else None
 g_fix = torch.randn(a.batch, CFG['g_latent_space_size'], device='cuda')
 
 
-API = ['list' if a.api == 'list' else 'fused']
+API = [a.api if a.api in ('list', 'swap', 'swap_loop') else 'fused']
+if a.api in ('swap', 'swap_loop'):
+    model.literal_k_loop = True
+
+
+def loop_mixture_nll(output_decoder, logits):
+    """The point NLL as the reference evaluates it (losses.py:101-137), restated: a Python loop over the B shapes and the K
+    components that re-adds every component's whole list of log-variances (`sum(list)` of 3 n_flows + 1 full (B,3,N) tensors) for
+    each of its B x K iterations.  Timing harness for `--api swap_loop`; its value equals Flow_Mixture_Loss's (asserted below)."""
+    log_w = (logits - torch.logsumexp(logits, dim=-1, keepdim=True)).unsqueeze(1)              # (B, 1, K)
+    K, B = len(output_decoder), output_decoder[0]['p_prior_mus'][0].shape[0]
+    per_shape = []
+    for i in range(B):
+        cols = []
+        for j in range(K):
+            o = output_decoder[j]
+            mu0, lv0 = o['p_prior_mus'][0][i], o['p_prior_logvars'][0][i]
+            logdet = sum(o['p_prior_logvars'])[i]
+            z = o['p_prior_samples'][0][i]
+            inner = -torch.sum(logdet + (z - mu0) ** 2 / torch.exp(lv0), dim=0, keepdim=True)
+            cols.append(0.5 * (inner - float(np.log(2.0 * np.pi)) * z.shape[0]))
+        lp = torch.cat(cols, dim=0).t() + log_w[i]
+        per_shape.append(-torch.logsumexp(lp, dim=-1).sum().unsqueeze(0))
+    return torch.cat(per_shape).mean()
 
 
 def fwd_bwd():
     opt.zero_grad(set_to_none=True)
-    if a.parts == 'epd' and API[0] == 'list':
+    if a.parts == 'epd' and API[0] == 'swap_loop':
+        output_prior, output_decoder, logits = model(g_in, p_in)
+        loss, pnll, gnll, gent = crit._combine(loop_mixture_nll(output_decoder, logits), output_prior)
+    elif a.parts == 'epd' and API[0] in ('list', 'swap'):
         output_prior, output_decoder, logits = model(g_in, p_in)             # training.py:43-47 of the reference
         loss, pnll, gnll, gent = crit(output_prior, output_decoder, logits)
     elif a.parts == 'epd':
@@ -151,8 +180,8 @@ _Gl = CFG['g_latent_space_size']
 _heads_hip = all(m._hip_layers(torch.zeros(_rows, m.features[0].weight.shape[1] if m.n_layers else 1, device='cuda')) is not None
                  for m in (model.g_posterior, model.p_prior) if m.n_layers)
 _prior_hip = model.g_prior._fused_ok(torch.zeros(a.batch, _Gl, device='cuda'), _rows)
-# (the FiLM heads under autograd have no library path left: autograd.train_density_forward_multi always runs csrc/gwtf_film_train.hip)
-say(f'per-shape modules: rows={_rows} film_heads=hip heads={"hip" if _heads_hip else "library"} prior_flow={"hip" if _prior_hip else "library"}')
+_film = '+'.join(k.split('_')[-1] for k, v in gwa.PATHS.items() if v) or 'not run'      # the implementation(s) the steps above went through
+say(f'per-shape modules: rows={_rows} film_heads={_film} heads={"hip" if _heads_hip else "library"} prior_flow={"hip" if _prior_hip else "library"}')
 say(f'eager   : {ms:8.2f} ms/step  {pts / ms / 1e3:8.2f} Mpoints/s (each point through all {CFG["n_components"]} components)')
 if a.graph:
     s = torch.cuda.Stream()
