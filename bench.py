@@ -164,6 +164,19 @@ def train_step_record(world=1, rank=0, local_rank=0, dist=None, dev=None, backen
         rec = {'ms_per_step': ms['hipGraph'], 'eager_ms_per_step': ms.get('eager'), 'steps': steps, 'per_shape_modules': ms.get('per_shape_modules'),
                'list_api_ms_per_step': ms.get('hipGraph list API'),        # the reference's own call: model(g, p) -> lists -> loss
                'workload': wl + ', B=64'}
+        # The literal drop-in: ONLY the decoder import swapped -- the K decoders called one at a time
+        # (flow_mixture.py:163-166); `with_this_loss`: the loss import swapped too (lists -> the fused NLL kernel); `reference_loss_loop`:
+        # the reference's own B x K Python loss loop on the returned lists (losses.py:109-131, restated in tools/bench_train.py).
+        # `no_sibling_batching`: the same call with decoders._SiblingGroup off (K separate K = 1 pipelines: what round 4 shipped).
+        sw = _run_bench_train(['--api', 'swap'], base_env, steps=steps)
+        sw_off = _run_bench_train(['--api', 'swap'], dict(base_env, GWTF_NO_SIBLING_BATCH='1'), steps=max(3, steps // 4))
+        sw_loop = _run_bench_train(['--api', 'swap_loop'], base_env, steps=3, timeout=300)
+        rec['import_swap_only'] = {
+            'with_this_loss': {'ms_per_step': sw.get('hipGraph'), 'eager_ms_per_step': sw.get('eager'), 'error': sw.get('error')},
+            'with_this_loss_no_sibling_batching': {'ms_per_step': sw_off.get('hipGraph'), 'eager_ms_per_step': sw_off.get('eager'), 'error': sw_off.get('error')},
+            'reference_loss_loop': {'ms_per_step': sw_loop.get('hipGraph'), 'eager_ms_per_step': sw_loop.get('eager'), 'error': sw_loop.get('error')},
+            'note': 'K sequential LocalCondRNVPDecoder.forward calls on one (p, g) land in ONE K-batched pipeline pass (first call of a '
+                    'ModuleList sibling group runs all K, later calls return their slices); the loss loop re-adds 34 full tensors B x K times'}
         sh = _run_bench_train([], dict(base_env, GWTF_FORCE_SHARDED='1'), steps=steps)
         rec['data_parallel_path_1rank'] = ({'ms_per_step': sh.get('hipGraph'), 'statistic_all_reduces_in_graph': sh.get('collectives'),
                                             'per_shape_modules': sh.get('per_shape_modules'),
@@ -346,6 +359,69 @@ def run_workload(name, args, dev, rank, world, sync_all, reduce_max):
                 achieved=flops_per_point(L, f) * pts_per_launch / (kern_ms * 1e-3) / 1e12)
 
 
+def exact_fp32_record(name, m, dev, reps=10):
+    """The same stack launch on the EXACT-fp32 contraction body (csrc/gwtf_stack_exact.hip: v_mfma_f32_16x16x4_f32, unsplit operands)
+    -- the honest comparison point for the split-f16 kernel's rate: what the unit whose dtype the result has delivers on this
+    workload -- and the cost of the re-run launch that follows every eval stack launch (its workgroups read their tile's results and
+    leave: no point of the bench grids is out of range).  HIP events around the launches alone, results in preallocated tensors."""
+    cfg = WORKLOADS[name]
+    K, L, f, G, B, N, mode = (cfg[k] for k in ('K', 'L', 'f', 'G', 'B', 'N', 'mode'))
+    decoders = []
+    for k in range(K):
+        d = gw.LocalCondRNVPDecoder(L, f, G)
+        load_synth_(d, 2 + k)
+        decoders.append(d.to(dev).eval())
+    p, g = synth_inputs(B, N, G, 0)
+    pd, gd = torch.from_numpy(p).to(dev), torch.from_numpy(g).to(dev)
+    stack = gw.MixtureStack(decoders)
+    eps = decoders[0].flows[0].nvp1._eps_value
+    outs = [torch.empty(K, B, 3, N, device=dev) for _ in range(2)]
+
+    def timed(fns, rounds):
+        """median HIP-event duration of each fn, the fns taken in turn `rounds` times (clock drift hits all of them alike)"""
+        ts = [[] for _ in fns]
+        with torch.no_grad():
+            for _ in range(rounds):
+                for i, fn in enumerate(fns):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    torch.cuda._sleep(400000)     # ~0.2 ms of device-side spin: the launches below are queued before the first event fires
+                    e0.record()
+                    fn()
+                    e1.record()
+                    ts[i].append((e0, e1))
+        torch.cuda.synchronize(dev)
+        return [float(np.median([a.elapsed_time(b) for a, b in t])) for t in ts]
+    with torch.no_grad():
+        pw, film, _ = stack._film(gd)
+        px = stack.packed_exact()
+    split = lambda x: _lib.stack_forward_multi(pd, pw, film, K, stack.C, f, 0, eps, mode, out=outs[0], logdet=outs[1], packed_x=x)
+
+    def exact():
+        with _lib.exact_fp32():
+            split(px)
+    with torch.no_grad():
+        for _ in range(100):                  # ~50 ms of load: clocks settle before anything is measured
+            split(px)
+    t_split, _, t_exact = timed([lambda: split(None), lambda: split(px), exact], reps)
+    # the re-run launch's cost where it matters: inside a hipGraph (one graph of the split launch alone, one with the re-run behind it)
+    graphs = []
+    with torch.no_grad():
+        for x in (None, px):
+            gr = torch.cuda.CUDAGraph()
+            with graph_capture(gr):
+                for _ in range(10):
+                    split(x)
+            graphs.append(gr)
+    t_g = timed([graphs[0].replay, graphs[1].replay], reps)
+    t_both = t_split + (t_g[1] - t_g[0]) / 10
+    tf = flops_per_point(L, f) * K * B * N / (t_exact * 1e-3) / 1e12
+    return {'workload': cfg['name'], 'kernel': 'stack_exact_kernel (v_mfma_f32_16x16x4_f32, unsplit fp32 operands)',
+            'kernel_ms': round(t_exact, 4), 'achieved': round(tf, 2), 'unit': 'TFLOP/s', 'peak_fp32_mfma': MFMA_F32_PEAK_TFLOPS,
+            'frac_of_fp32_mfma_peak': round(tf / MFMA_F32_PEAK_TFLOPS, 4), 'split_f16_kernel_ms': round(t_split, 4),
+            'split_over_exact': round(t_exact / t_split, 2), 'rerun_launch_us': round((t_both - t_split) * 1e3, 2),
+            'note': 'rerun_launch_us: the exact-fp32 re-run launch behind the split launch when no tile is flagged, measured inside a hipGraph (10 launches with it - 10 without) / 10; it is part of every timed step above'}
+
+
 def under_profiler():
     """True when this process already runs under rocprofv3 (its tool library is preloaded / its environment is set)."""
     return 'rocprof' in os.environ.get('LD_PRELOAD', '').lower() or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
@@ -418,7 +494,7 @@ def main():
     ap.add_argument('--no-also', action='store_true', help='skip the secondary M1 (north-star shape) measurement')
     ap.add_argument('--no-train-step', action='store_true', help='skip the secondary whole-model training-step measurement')
     ap.add_argument('--train-step-steps', type=int, default=20, help='timed steps of the secondary training-step measurement')
-    ap.add_argument('--also-select', default='m1,ae,svr,k16,k16_b1,train_step',
+    ap.add_argument('--also-select', default='m1,ae,svr,k16,k16_b1,exact_fp32,train_step',
                     help='comma list of the secondary measurements to run beside the airplane headline')
     ap.add_argument('--eager', action='store_true', help='launch through the eager module path instead of one hipGraph per step')
     ap.add_argument('--points-per-wave', type=int, default=0, help='tuning hook: 16/32/64, 0 = library default')
@@ -479,6 +555,8 @@ def main():
                           # every shape's HBM traffic is measured by this run (two rocprofv3 --pmc child passes each, a few seconds)
                           'roofline': roofline_record(name, a, live=(world == 1 and not args.no_live_traffic and not under_profiler()))}
 
+        if rank == 0 and 'exact_fp32' in selected:
+            also['exact_fp32'] = exact_fp32_record('airplane', m, dev)
         if not args.no_train_step and 'train_step' in selected:
             ts = train_step_record(world, rank, local_rank, dist, dev, args.backend, args.share_device, args.train_step_steps)      # N > 1: every rank takes part (one child per GPU)
             if rank == 0:

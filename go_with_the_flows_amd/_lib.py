@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GWTF_LIB') or os.path.join(_HERE, 'libgwtf_hip.so')      # GWTF_LIB: an A/B build (tools/ab_build.sh)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 MODE_DIRECT, MODE_INVERSE = 0, 1
 STAT_REPLICAS = 64   # GWTF_STAT_REPLICAS in csrc/gwtf_layout.h
@@ -35,6 +35,10 @@ _SIGNATURES = {
     'gwtf_stack_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_stack_forward_multi': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
                                  [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, _c_fp]),
+    'gwtf_packed_x_coupling_floats': (ctypes.c_size_t, [ctypes.c_int]),
+    'gwtf_pack_weights_exact': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
+    'gwtf_stack_forward_exact': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
+                                 [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_stack_plan': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]),
     'gwtf_train_moments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_train_fold0': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_double, ctypes.c_int, _c_fp, _c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
@@ -244,7 +248,42 @@ def film_forward(g, packed_film, C, f, eps, training, want_stats=False):
     return (out, stats) if want_stats else out
 
 
-def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists):
+# ---- the exact-fp32 contraction body (csrc/gwtf_stack_exact.hip) ---------------------------------------------------------------
+# EXACT[0]: run the stack on the fp32 matrix instruction instead of the split-f16 one (tests, bench.py's comparison point;
+# `with exact_fp32():`).  Otherwise, when the caller hands the exact record (packed_x) along, every split launch is followed by the
+# RE-RUN launch: tiles holding a point the split kernel flagged out of range (NaN) are recomputed exactly, all others exit at once.
+EXACT = [False]
+
+
+class exact_fp32:
+    def __enter__(self):
+        self._old, EXACT[0] = EXACT[0], True
+        return self
+
+    def __exit__(self, *exc):
+        EXACT[0] = self._old
+        return False
+
+
+def pack_weights_exact(raw, packed_film, C, f, G, pattern0=0, K=1):
+    """GwtfPackX records of K concatenated stacks of C couplings (the fp32 operands of the exact contraction body)."""
+    L = lib()
+    px = torch.empty(K * C * L.gwtf_packed_x_coupling_floats(f), device=raw.device, dtype=torch.float32)
+    with torch.cuda.device(raw.device):
+        check(L.gwtf_pack_weights_exact(_ptr(raw, 'raw'), _ptr(packed_film, 'packed_film'), _ptr(px, 'packed_x'), K, C, f, G,
+                                        int(pattern0), _stream(raw)))
+    return px
+
+
+def _exact_launch(p, packed_x, film, out, logdet, lp, seg, K, C, f, pattern0, eps, mode, p_stride, out_stride, only_flagged):
+    L = lib()
+    B, _, N = p.shape
+    check(L.gwtf_stack_forward_exact(_ptr(p, 'p'), _ptr(packed_x, 'packed_x'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                     _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], seg, K, B, N, C, f, pattern0, float(eps),
+                                     _MODES[mode], p_stride, out_stride, int(only_flagged), _TUNE[0] & 0xffff, _stream(p)))
+
+
+def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists, packed_x=None):
     L = lib()
     B, three, N = p.shape
     if three != 3:
@@ -256,13 +295,21 @@ def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists):
     lists = torch.empty(3, C, B, 3, N, device=p.device, dtype=torch.float32) if want_lists else None
     lp = [lists[i].data_ptr() for i in range(3)] if want_lists else [None, None, None]
     with torch.cuda.device(p.device):
+        if EXACT[0]:
+            if packed_x is None:
+                raise GwtfError('exact_fp32: this call site has no exact record (packed_x)')
+            _exact_launch(p, packed_x, film, out, logdet, lp, None, 1, C, f, pattern0, eps, mode, 0, 0, 0)
+            return out, logdet, lists
         check(L.gwtf_stack_forward(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
                                    _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], B, N, C, f, pattern0, float(eps),
                                    _MODES[mode], _TUNE[0], _stream(p)))
+        if packed_x is not None:
+            _exact_launch(p, packed_x, film, out, logdet, lp, None, 1, C, f, pattern0, eps, mode, 0, 0, 1)
     return out, logdet, lists
 
 
-def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segments=None, shared_points=True, out=None, logdet=None):
+def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segments=None, shared_points=True, out=None, logdet=None,
+                        packed_x=None):
     """K components in one launch.  shared_points=True: every component maps all of p -> outputs (K,B,3,N).
     Otherwise ``segments`` (list of K (begin,end)) partitions the N points among the components -> (B,3,N).
     out / logdet: optional preallocated result tensors (a timing probe brackets the launch alone with them)."""
@@ -296,9 +343,16 @@ def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segment
             logdet = make(B, 3, N, device=p.device, dtype=torch.float32)
         stride = 0
     with torch.cuda.device(p.device):
+        if EXACT[0]:
+            if packed_x is None:
+                raise GwtfError('exact_fp32: this call site has no exact record (packed_x)')
+            _exact_launch(p, packed_x, film, out, logdet, [None] * 3, seg, K, C, f, pattern0, eps, mode, 0, stride, 0)
+            return out, logdet
         check(L.gwtf_stack_forward_multi(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
                                          _ptr(logdet, 'logdet'), None, None, None, seg, K, B, N, C, f, pattern0,
                                          float(eps), _MODES[mode], 0, stride, _TUNE[0], _stream(p)))
+        if packed_x is not None:
+            _exact_launch(p, packed_x, film, out, logdet, [None] * 3, seg, K, C, f, pattern0, eps, mode, 0, stride, 1)
     return out, logdet
 
 

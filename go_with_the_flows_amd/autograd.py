@@ -469,15 +469,17 @@ class _AllReduceSum(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t):
         import torch.distributed as dist
+        from .dist import run
         t = t.clone()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
         return t
 
     @staticmethod
     def backward(ctx, g):
         import torch.distributed as dist
+        from .dist import run
         g = g.clone().contiguous()
-        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+        run(dist.all_reduce, g, op=dist.ReduceOp.SUM)
         return g
 
 
@@ -580,8 +582,9 @@ def _stat_sum(t):
     stat_compact_kernel): that record goes on the wire (3 KB at f = 37, K = 4, where the copies are 196 KB) and every consumer --
     the folds, the backward pass -- reads it in place of the copies: no write-back, no second launch."""
     import torch.distributed as dist
+    from .dist import run
     COLLECTIVES['n'] += 1
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
 
 
 class TrainMixtureFn(torch.autograd.Function):

@@ -104,7 +104,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
     }
   }
   __shared__ __align__(16) float lds[K::PW + K::FSP + (LIGHT ? 0 : KB::PB_LDS)];
-  __shared__ float s_film[2][3][FP], s_sd0[2][3][FP], s_bias[4];
+  // sd0 sums: one set per workgroup (atomics), or one per wave (GWTF_ROWSUM_KEEP >= 2: plain stores, summed by the flush)
+  constexpr int SD0W = (GWTF_ROWSUM_KEEP >= 2 && GWTF_ROWSUM_MODE == 1 && !LIGHT) ? 4 : 1;
+  __shared__ float s_film[2][3][FP], s_sd0[SD0W][2][3][FP], s_bias[4];
   // MERGED / STATS: the statistics' upstream g_stats [2][2][FP] staged once per workgroup (read from global memory where it is used
   // it was 48 conditional loads -- each its own exec-masked block -- per wave inside the dacc loop)
   __shared__ __align__(16) float s_gst[(STATS || MERGED) ? 4 * FP : 4];
@@ -120,10 +122,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   __shared__ float s_pad[MERGED ? GWTF_BWD_LDS_PAD * 256 : 1];
   if (B < 0) { s_pad[threadIdx.x] = eps; g_in[0] = s_pad[N & 255]; }
 #endif
-  for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
-    (&s_film[0][0][0])[t] = 0.f;
-    (&s_sd0[0][0][0])[t] = 0.f;
-  }
+  for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) (&s_film[0][0][0])[t] = 0.f;
+  for (int t = threadIdx.x; t < SD0W * 2 * 3 * FP; t += blockDim.x) (&s_sd0[0][0][0][0])[t] = 0.f;
   if (threadIdx.x < 4) s_bias[threadIdx.x] = 0.f;
   if (STATS || MERGED)
     for (int t = threadIdx.x; t < 4 * FP; t += blockDim.x) s_gst[t] = (t % FP) < f ? g_stats[t] : 0.f;
@@ -170,6 +170,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   constexpr bool ONE_W = K2 == 1;          // compile-time: one warped coordinate (everything with index 1 of a warped slot is absent)
 #endif
   constexpr bool ONE_K = K2 == 0;          // compile-time: one kept coordinate (sd0 has ONE input: its second weight column, x_b and their sums are absent)
+  // this workgroup's dW1 partial of branch br, column tile ni (gwtf_dw1.h PARTIAL RECORD: [2][f columns][RP rows]): the lane's four
+  // consecutive rows of each row tile as one 16-byte streaming store (the partials are read once, by another kernel)
+  auto store_partial = [&](float* ws, int br, int ni, const f32x4 (&dw)[MB]) {
+    const int RP = gwtf_dw1::rows_padded(f), col = 16 * ni + i16;
+    if ((GWTF_BWD_ABLATE & 2) && MERGED && N > 0) return;
+    if (col >= f) return;
+    float* out = ws + (size_t)blockIdx.x * gwtf_dw1::rec_floats(f) + ((size_t)br * f + col) * RP + 4 * q;
+#pragma unroll
+    for (int mi = 0; mi < MB; ++mi)
+      if (16 * mi + 4 * q < RP) __builtin_nontemporal_store(dw[mi], reinterpret_cast<f32x4*>(out + 16 * mi));
+  };
 
   for (int it = 0; it < tpw; ++it) {
   const int tile = tile0 + it;
@@ -426,6 +437,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
     float pxa[NB], pxb[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) pxa[nb] = pxb[nb] = 0.f;
+    constexpr bool SLOT0 = SD0W == 4;                         // per-wave slots, plain stores (gwtf_device.h GWTF_ROWSUM_KEEP)
+    const int ws0 = SLOT0 ? wave : 0;
 #pragma unroll
     for (int mi = 0; mi < MB; ++mi) {
       f32x4 dh[NB];
@@ -465,9 +478,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
         g2 = row_sum_part(g2);
         if ((GWTF_BWD_ABLATE & 1) && MERGED) { asm volatile("" :: "v"(g0), "v"(g1), "v"(g2)); continue; }
         if (row_sum_owner(i16)) {
-          atomicAdd(&s_sd0[br][0][fi], g0);
-          if (!ONE_K) atomicAdd(&s_sd0[br][1][fi], g1);          // (zero on entry: the absent column's sum stays zero)
-          atomicAdd(&s_sd0[br][2][fi], g2);
+          if (SLOT0) {
+            s_sd0[ws0][br][0][fi] = g0;
+            if (!ONE_K) s_sd0[ws0][br][1][fi] = g1;
+            s_sd0[ws0][br][2][fi] = g2;
+          } else {
+            atomicAdd(&s_sd0[0][br][0][fi], g0);
+            if (!ONE_K) atomicAdd(&s_sd0[0][br][1][fi], g1);          // (zero on entry: the absent column's sum stays zero)
+            atomicAdd(&s_sd0[0][br][2][fi], g2);
+          }
         }
       }
     }
@@ -529,9 +548,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
             dw[mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xlo, hhi, dw[mi], 0, 0, 0);
           }
         }
-        // C layout: lane (col = h feature 16 ni + i16, q) holds rows = dacc features 16 mi + 4 q + r.  The partial is stored
-        // COMPACT, [f][f] (the padded rows / columns are zero anyway): 41 % less partial traffic at f = 37 (FP = 48), written here
-        // and read back by the reduction
+        // C layout: lane (col = h feature 16 ni + i16, q) holds rows = dacc features 16 mi + 4 q + r: store_partial above
         if (DEFER_DW && br == 0) {
           // branch 0's partial stays in registers until branch 1 is through: stored here, the wave would meet its own 12 stores at the
           // `s_waitcnt vmcnt(0)` that guards branch 1's transposed weights (vmcnt counts stores too) -- an HBM write round trip
@@ -540,29 +557,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
           for (int mi = 0; mi < MB; ++mi) dwk[mi] = dw[mi] * down;
           continue;
         }
-        float* out = dw1_ws + ((size_t)blockIdx.x * 2 + br) * f * f;
-        const int col = 16 * ni + i16;
 #pragma unroll
-        for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {  // streaming store: the partials are read once, by another kernel -- keep them out of L2
-            const int row = 16 * mi + 4 * q + r;
-            if (row < f && col < f && !((GWTF_BWD_ABLATE & 2) && MERGED && N > 0)) __builtin_nontemporal_store(dw[mi][r] * down, &out[row * f + col]);
-          }
+        for (int mi = 0; mi < MB; ++mi) dw[mi] *= down;
+        store_partial(dw1_ws, br, ni, dw);
       }
     }
   }
-  if (DEFER_DW && !LIGHT && wave < MB) {
-    float* out = dw1_ws + ((size_t)blockIdx.x * 2 + 0) * f * f;
-    const int col = 16 * wave + i16;
-#pragma unroll
-    for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * mi + 4 * q + r;
-        if (row < f && col < f && !((GWTF_BWD_ABLATE & 2) && MERGED && N > 0)) __builtin_nontemporal_store(dwk[mi][r], &out[row * f + col]);
-      }
-  }
+  if (DEFER_DW && !LIGHT && wave < MB) store_partial(dw1_ws, 0, wave, dwk);
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
     if (d == k0) gin[d] += dxa_own;
@@ -580,7 +581,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NB == 4 ? 2
   float* gs = g_sd0 + (size_t)(blockIdx.x % GWTF_STAT_REPLICAS) * (2 * 3 * FP);
   for (int t = threadIdx.x; t < 2 * 3 * FP; t += blockDim.x) {
     if (!STATS && !MERGED) atomicAdd(&gf[t], (&s_film[0][0][0])[t]);
-    if (!LIGHT) atomicAdd(&gs[t], (&s_sd0[0][0][0])[t]);
+    if (!LIGHT) {
+      float v = (&s_sd0[0][0][0][0])[t];
+#pragma unroll
+      for (int w = 1; w < SD0W; ++w) v += (&s_sd0[w][0][0][0])[t];
+      atomicAdd(&gs[t], v);
+    }
   }
   if (!STATS && !MERGED && threadIdx.x < 4) atomicAdd(&g_bias[(blockIdx.x % GWTF_STAT_REPLICAS) * 4 + threadIdx.x], s_bias[threadIdx.x]);
 }
@@ -837,7 +843,7 @@ extern "C" int gwtf_stats_backward(const float* x_in, const float* g_stats, cons
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// dW1[br][j][i] = sum over the per-workgroup partials the backward kernels leave in the workspace ([partial][2][f][f] compact,
+// dW1[br][j][i] = sum over the per-workgroup partials the backward kernels leave in the workspace ([partial][2][f][RP], gwtf_dw1.h,
 // `passes` consecutive regions of gwtf_dw1_partials(B, N) partials each: coupling path [+ statistics path]); fixed
 // summation order -> deterministic.  64 outputs per workgroup x 4 slices of the partial axis, combined through LDS.
 namespace {
@@ -861,12 +867,12 @@ __global__ __launch_bounds__(256) void dw1_reduce_kernel(const float* __restrict
 extern "C" int gwtf_dw1_partials(int B, int N) { return (B > 0 && N > 0) ? bwd_grid(B, N) : 0; }
 
 extern "C" size_t gwtf_dw1_workspace_floats(int f, int B, int N) {
-  return (size_t)gwtf_dw1_partials(B, N) * 2 * f * f;      // compact [2][f][f] partials
+  return (size_t)gwtf_dw1_partials(B, N) * gwtf_dw1::rec_floats(f);      // [2][f][RP] partials (gwtf_dw1.h)
 }
 
 // `workspace`: `passes` regions written by the backward kernels, followed by kDw1Stage records of scratch for the first
 // reduction stage (gwtf_dw1_reduce_scratch_floats(f) floats after the last region).
-extern "C" size_t gwtf_dw1_reduce_scratch_floats(int f) { return (size_t)kDw1Stage * 2 * f * f; }
+extern "C" size_t gwtf_dw1_reduce_scratch_floats(int f) { return (size_t)kDw1Stage * gwtf_dw1::rec_floats(f); }
 
 // K components: component k's workspace at workspace + k * ws_sk, its gradient blocks at dW1 + k * out_sk
 int gwtf_internal_dw1_reduce_k(float* workspace, int passes, float* dW1, size_t branch_stride, int f, int B, int N, int K,
@@ -874,10 +880,10 @@ int gwtf_internal_dw1_reduce_k(float* workspace, int passes, float* dW1, size_t 
   if (!workspace || !dW1 || passes < 1 || f <= 0 || f > GWTF_MAX_FP_TRAIN || B <= 0 || N <= 0 || K <= 0 || branch_stride < (size_t)f * f)
     return GWTF_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
-  const int FP = gwtf_padded_width(f), rec = 2 * f * f, n_partials = passes * bwd_grid(B, N);
+  const int FP = gwtf_padded_width(f), rec = gwtf_dw1::rec_floats(f), n_partials = passes * bwd_grid(B, N);
   float* mid = workspace + (size_t)n_partials * rec;
   hipLaunchKernelGGL(dw1_fold_kernel, dim3((rec + 255) / 256, kDw1Stage, K), dim3(256), 0, st, workspace, n_partials, mid, rec, ws_sk);
-  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((2 * f * f + 63) / 64, K), dim3(256), 0, st, mid, dW1, FP, f, branch_stride, ws_sk, out_sk);
+  hipLaunchKernelGGL(dw1_reduce_kernel, dim3((gwtf_dw1::rec_floats(f) + 63) / 64, K), dim3(256), 0, st, mid, dW1, FP, f, branch_stride, ws_sk, out_sk);
   return (int)hipGetLastError();
 }
 

@@ -111,6 +111,17 @@ __device__ __forceinline__ float row_sum_part(float v) {
 // lanes of a 16-lane row that hand their row_sum_part to the LDS atomic
 __device__ __forceinline__ bool row_sum_owner(int i16) { return GWTF_ROWSUM_MODE == 2 ? (i16 & 3) == 0 : i16 == 0; }
 
+// What a row total does after row_sum_part.  GWTF_ROWSUM_KEEP:
+//   0  lane 0 of the row adds it to the workgroup's LDS word (36 exec-masked 4-lane LDS atomics per branch and wave in the merged pass)
+//   2  kernels whose workgroup owns ONE tile: lane 0 of the row STORES it into the wave's own slot (plain ds_write: every slot is written
+//      once) and the flush adds the four waves' slots -- merged pass 111.0 / 103.9 -> 106.9 / 101.0 us, statistics pass 22.2 -> 21.5.
+// Measured and rejected (docs/experiments/r5_rowsum_keeper.patch): PARKING the totals (total idx in lane idx % 16 of register idx / 16,
+// one v_cndmask each) and leaving in ceil(NV / 16) full-wave operations -- as LDS atomics 113.3 -> 121.1 us (an LDS float atomic costs
+// per ACTIVE LANE: 3 x 64 lanes are the atomic work of 36 x 4, and the 72 selects come on top), as plain stores 107.3 / 100.1 (= mode 2).
+#ifndef GWTF_ROWSUM_KEEP
+#define GWTF_ROWSUM_KEEP 2
+#endif
+
 // Sum the per-quarter partials o[nb] over the four 16-lane quarters so that the lane in quarter q ends
 // with the total of point block (q & (NB-1)).
 template <int NB>

@@ -8,8 +8,15 @@ namespace gwtf_dw1 {
 
 constexpr int kStage = 64;    // stage 1 folds the partials into this many sums (fixed partition -> deterministic)
 
+// PARTIAL RECORD  [2 branches][f columns (h feature i)][RP rows (dacc feature j)], RP = f rounded up to 4: the backward kernel's lane
+// holds four CONSECUTIVE rows of one column of a 16 x 16 output tile (MFMA C layout), so a partial leaves the kernel as ONE 16-byte
+// store per tile and lane (3 per branch at f = 37) where the row-major compact [f][f] record took a dword store per element (12, each
+// with its own bound check): 8 % more bytes at f = 37 (RP = 40), a quarter of the store instructions.
+__host__ __device__ inline int rows_padded(int f) { return (f + 3) / 4 * 4; }
+__host__ __device__ inline int rec_floats(int f) { return 2 * f * rows_padded(f); }
+
 // stage 1, block (bx = element tile of 256, by = chunk < kStage, component already applied to ws / mid):
-// mid[by][e] = sum over the chunk's partials of ws[p][e], e over the whole compact [2][f][f] record (coalesced)
+// mid[by][e] = sum over the chunk's partials of ws[p][e], e over the whole partial record (coalesced)
 __device__ __forceinline__ void fold_block(const float* __restrict__ ws, int n_partials, float* __restrict__ mid, int rec, int bx,
                                            int by, int tid) {
   const int e = bx * 256 + tid;
@@ -32,18 +39,20 @@ __device__ __forceinline__ void fold_block(const float* __restrict__ ws, int n_p
   mid[(size_t)by * rec + e] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
-// stage 2, block bx = 64 outputs x 4 slices of the kStage sums, combined through LDS (`part`: 4 x 64 floats of the caller's
-// LDS; all 256 threads of the block must call)
+// stage 2, block bx = 64 consecutive elements of the RECORD (coalesced reads of the kStage sums; the padded rows are skipped) x 4 slices
+// of the kStage sums, combined through LDS (`part`: 4 x 64 floats of the caller's LDS; all 256 threads of the block must call);
+// grid: (rec_floats(f) + 63) / 64 blocks per component
 __device__ __forceinline__ void reduce_block(const float* __restrict__ mid, float* __restrict__ out, int f, size_t branch_stride,
                                              int bx, int tid, float (*part)[64]) {
   const int e = tid & 63, sl = tid >> 6;
-  const int t = bx * 64 + e;
-  const bool on = t < 2 * f * f;
-  const int br = on ? t / (f * f) : 0, j = on ? (t / f) % f : 0, i = on ? t % f : 0;
+  const int t = bx * 64 + e, RP = rows_padded(f);
+  const bool in = t < rec_floats(f);
+  const int br = in ? t / (f * RP) : 0, i = in ? (t / RP) % f : 0, j = in ? t % RP : 0;      // element (branch, column i, row j)
+  const bool on = in && j < f;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   if (on) {
-    const float* src = mid + (size_t)br * f * f + (size_t)j * f + i;      // compact [2][f][f] records
-    const size_t stride = (size_t)2 * f * f;
+    const float* src = mid + t;
+    const size_t stride = (size_t)rec_floats(f);
 #pragma unroll
     for (int c = sl * (kStage / 4); c < (sl + 1) * (kStage / 4); c += 4)
 #pragma unroll

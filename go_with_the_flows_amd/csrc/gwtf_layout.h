@@ -105,6 +105,25 @@ struct GwtfPackW {
   GWTF_HD size_t coupling_size() const { return (used_size() + 255) / 256 * 256; }
 };
 
+// EXACT-FP32 STACK RECORD (gwtf_pack_weights_exact -> csrc/gwtf_stack_exact.hip; the sd1 contraction on v_mfma_f32_16x16x4_f32 with
+// UNSPLIT fp32 operands: the reference's own arithmetic, reference flows.py:25-31), per coupling:
+//   A32[branch][t][m][lane] f32 : W1'[16 m + (lane & 15)][4 t + (lane >> 4)], t < FP / 4 -- the A operand of MFMA (t, m): row = output
+//       feature, k = input feature 4 t + q; W1' = sd1.weight with sd1_bn's 1/sqrt(var + eps) folded in and the SAME power-of-two range
+//       scaling as the split images (2^(CS[j] - RS[i]): exact in fp32), so the FiLM record (which carries RS) is shared
+//   SD0X[branch][FP][4] f32     : {w0a, w0b, c0, 0} 2^-CS of the folded sd0 in natural feature order
+// padded to whole 1-KiB LDS-DMA pieces.
+struct GwtfPackX {
+  int FP;
+  GWTF_HD GwtfPackX(int FP_) : FP(FP_) {}
+  GWTF_HD int MB() const { return FP / 16; }
+  GWTF_HD int KK() const { return FP / 4; }
+  GWTF_HD size_t a32_size() const { return (size_t)FP * FP; }                 // floats, one branch (KK * MB * 64)
+  GWTF_HD size_t a32(int branch) const { return branch * a32_size(); }
+  GWTF_HD size_t sd0x(int branch) const { return 2 * a32_size() + (size_t)branch * FP * 4; }
+  GWTF_HD size_t used_size() const { return 2 * a32_size() + 2 * (size_t)FP * 4; }
+  GWTF_HD size_t coupling_size() const { return (used_size() + 255) / 256 * 256; }
+};
+
 // BACKWARD RECORD (read by the backward kernels through LDS), per coupling:
 //   W1T[branch][mi][ks][part][lane][8] f16 : hi / lo of W1[j][i], the TRANSPOSED sd1 weight as the A operand of
 //       dh = W1^T dacc on v_mfma_f32_16x16x32_f16: row i = 16*mi + (lane&15) (input feature of sd1), k-slot (ks, q = lane>>4, e)

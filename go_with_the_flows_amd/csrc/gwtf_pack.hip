@@ -207,7 +207,58 @@ __global__ void pack_film_kernel(const float* __restrict__ raw, float* __restric
   }
 }
 
+// exact-fp32 stack record (GwtfPackX): the fp32 operands of the f x f contraction, same folding and range scaling as pack_w_kernel
+__global__ void pack_x_kernel(const float* __restrict__ raw, const float* __restrict__ pf, float* __restrict__ out, int C, int f,
+                              int G, int FP, int pattern0, int Cper) {
+  const GwtfRaw R(f, G);
+  const GwtfPackX P(FP);
+  const GwtfPackF PF(FP, G);
+  const size_t per = P.coupling_size(), total = per * (size_t)C;
+  const int MB = P.MB();
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(idx / per);
+    size_t o = idx - (size_t)c * per;
+    float v = 0.f;
+    if (o < 2 * P.a32_size()) {
+      const int br = (int)(o / P.a32_size());
+      o -= (size_t)br * P.a32_size();
+      const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
+      const float* ex = pf + ((size_t)c * 2 + br) * PF.branch_size();
+      const int lane = (int)(o % 64), m = (int)((o / 64) % MB), t = (int)(o / ((size_t)64 * MB));
+      const int jo = 16 * m + (lane & 15), ji = 4 * t + (lane >> 4);
+      if (jo < f && ji < f)
+        v = ldexpf(rb[R.sd1_w() + (size_t)jo * f + ji] * inv_std(rb[R.bn1() + f + jo]), (int)ex[PF.cs() + ji] - (int)ex[PF.rs() + jo]);
+    } else if ((o -= 2 * P.a32_size()) < 2 * (size_t)FP * 4) {
+      const int br = (int)(o / ((size_t)FP * 4)), ft = (int)((o / 4) % FP), e = (int)(o % 4);
+      const float* rb = raw + (size_t)c * R.coupling_size() + (size_t)br * R.branch_size();
+      if (ft < f && e < 3) {
+        const float* bn = rb + R.bn0();
+        const float s = bn[ft] * inv_std(bn[3 * f + ft]);
+        const int k = gwtf_pattern_kept((pattern0 + c % Cper) % 6);
+        v = e < 2 ? (e < k ? rb[R.sd0_w(ft, e, k)] * s : 0.f) : bn[f + ft] - bn[2 * f + ft] * s;
+        v = ldexpf(v, -(int)pf[((size_t)c * 2 + br) * PF.branch_size() + PF.cs() + ft]);
+      }
+    }
+    out[idx] = v;
+  }
+}
+
 }  // namespace
+
+extern "C" size_t gwtf_packed_x_coupling_floats(int f) { return GwtfPackX(gwtf_padded_width(f)).coupling_size(); }
+
+// packed_film: the eval packing of the SAME raw arena (gwtf_pack_weights_k, training = 0) -- its range-scaling exponents are read
+extern "C" int gwtf_pack_weights_exact(const float* raw, const float* packed_film, float* packed_x, int K, int Cper, int f, int G,
+                                       int pattern0, void* stream) {
+  const int C = K * Cper;
+  if (K <= 0 || Cper <= 0 || f <= 0 || G <= 0 || f > GWTF_MAX_FP || !raw || !packed_film || !packed_x || pattern0 < 0 || pattern0 > 5)
+    return GWTF_E_BADARG;
+  const int FP = gwtf_padded_width(f);
+  const size_t total = GwtfPackX(FP).coupling_size() * (size_t)C;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(pack_x_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, raw, packed_film, packed_x, C, f, G, FP, pattern0, Cper);
+  return (int)hipGetLastError();
+}
 
 // K stacks of Cper couplings each, concatenated (raw [K][Cper][record]): every stack starts again at warp pattern `pattern0`
 // (the records store sd0.weight with 1 or 2 kept columns depending on the coupling's pattern)

@@ -410,8 +410,9 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
   pw_c += blockIdx.y * pw_sk;
   ystats += blockIdx.y * ys_sk;
   __shared__ __align__(16) float lds[K::PW];
-  __shared__ float s_stats[2 * FP * 2];
-  for (int t = threadIdx.x; t < 2 * FP * 2; t += blockDim.x) s_stats[t] = 0.f;
+  constexpr int SW = (GWTF_ROWSUM_KEEP >= 2 && GWTF_ROWSUM_MODE == 1) ? 4 : 1;      // per-wave slots (plain stores) or one set (atomics)
+  __shared__ float s_stats[SW][2 * FP * 2];
+  for (int t = threadIdx.x; t < SW * 2 * FP * 2; t += blockDim.x) (&s_stats[0][0])[t] = 0.f;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = lane >> 4, i16 = lane & 15;
   const int tiles_per_shape = (N + 64 * NB - 1) / (64 * NB);
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
     for (int m = 0; m < MB; ++m) cinit[m] = zero4;
     if (pat < 3) sd1_contract<MB, NB, true, MG>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
     else sd1_contract<MB, NB, false, MG>(lds, br, kk_steps, lane, q, xa, xb, cinit, acc);
+    float* sw = s_stats[SW == 4 ? wave : 0];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
@@ -460,8 +462,12 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
         s2 = row_sum_part(s2);
         if (row_sum_owner(i16)) {
           const int ft = 16 * m + 4 * q + r;
-          atomicAdd(&s_stats[(br * FP + ft) * 2 + 0], s1);   // LDS: 4 waves
-          atomicAdd(&s_stats[(br * FP + ft) * 2 + 1], s2);
+          if (SW == 4) {
+            *reinterpret_cast<float2*>(&sw[(br * FP + ft) * 2]) = make_float2(s1, s2);
+          } else {
+            atomicAdd(&sw[(br * FP + ft) * 2 + 0], s1);   // LDS: 4 waves
+            atomicAdd(&sw[(br * FP + ft) * 2 + 1], s2);
+          }
         }
       }
   }
@@ -469,7 +475,12 @@ __global__ __launch_bounds__(256) void stats_kernel(const float* __restrict__ p,
   // one global atomic per value and workgroup, spread over GWTF_STAT_REPLICAS copies: thousands of adds to one
   // address serialise (measured 580 us for this kernel with per-wave atomics on a single copy)
   float* rep = ystats + (size_t)(blockIdx.x % GWTF_STAT_REPLICAS) * (2 * FP * 2);
-  for (int t = threadIdx.x; t < 2 * FP * 2; t += blockDim.x) atomicAdd(&rep[t], s_stats[t]);
+  for (int t = threadIdx.x; t < 2 * FP * 2; t += blockDim.x) {
+    float v = s_stats[0][t];
+#pragma unroll
+    for (int w = 1; w < SW; ++w) v += s_stats[w][t];
+    atomicAdd(&rep[t], v);
+  }
 }
 
 // Optional per-launch extras (all zero for the plain eval forward): a sub-range of couplings, a log-det to

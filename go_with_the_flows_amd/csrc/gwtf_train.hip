@@ -540,7 +540,7 @@ __global__ __launch_bounds__(256) void bwd_tail1_kernel(const float* __restrict_
     gwtf_dw1::fold_block(ws + bz * ks.dw1, n_partials, mid + bz * ks.dw1, rec, bx, by, threadIdx.x);
     return;
   }
-  const int b = blockIdx.x - n_role0 - n_role1, g2 = (2 * f * f + 63) / 64;
+  const int b = blockIdx.x - n_role0 - n_role1, g2 = (gwtf_dw1::rec_floats(f) + 63) / 64;
   gwtf_dw1::reduce_block(mid_prev + (b / g2) * ks.dw1, dW1_prev + (b / g2) * ks.raw, f, branch_stride, b % g2, threadIdx.x, red);
 }
 
@@ -557,7 +557,7 @@ __global__ __launch_bounds__(256) void bwd_tail2_kernel(const float* __restrict_
     combine_block(x, ga, nullptr, gm, g_in, B, N, ks, b % n_bx, (b / n_bx) % B, b / (n_bx * B), n_bx);
     return;
   }
-  const int b = blockIdx.x - n_role0, gx = (2 * f * f + 63) / 64;
+  const int b = blockIdx.x - n_role0, gx = (gwtf_dw1::rec_floats(f) + 63) / 64;
   const int bx = b % gx, bz = b / gx;
   gwtf_dw1::reduce_block(mid + bz * ks.dw1, dW1 + bz * ks.raw, f, branch_stride, bx, threadIdx.x, red);
 }
@@ -771,7 +771,7 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   const float* g_ps_c = t->g_ps ? t->g_ps + (size_t)c * d.XS : nullptr;
   const float* g_lvs_c = t->g_lvs ? t->g_lvs + (size_t)c * d.XS : nullptr;
   const GwtfRaw R(f, G);
-  const int rec = 2 * f * f, n_partials = gwtf_dw1_partials(B, N);
+  const int rec = gwtf_dw1::rec_floats(f), n_partials = gwtf_dw1_partials(B, N);
   const size_t scratch = gwtf_dw1_reduce_scratch_floats(f);
   float* mid = t->dw1_ws + (size_t)n_partials * rec + (size_t)(c & 1) * scratch;
   // the previous step's gradient combine, applied on the fly by this step's passes: its input was this coupling's output
@@ -796,7 +796,7 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
     const float* mid_prev = step > 0 ? t->dw1_ws + (size_t)n_partials * rec + (size_t)(c_prev & 1) * scratch : nullptr;
     float* dW1_prev = step > 0 ? t->g_raw + (size_t)c_prev * d.RC + R.sd1_w() : nullptr;
     const unsigned blocks = 2u * (FP / 16) * K + (unsigned)((rec + 255) / 256) * gwtf_dw1::kStage * K +
-                            (step > 0 ? (unsigned)((rec + 63) / 64) * K : 0u);
+                            (step > 0 ? (unsigned)((gwtf_dw1::rec_floats(f) + 63) / 64) * K : 0u);      // stage 2 walks the record's elements
     hipLaunchKernelGGL(bwd_tail1_kernel, dim3(blocks), dim3(256), 0, st, t->raw + (size_t)c * d.RC, mom.p, t->n_total, pat, g_sd0,
                        g_raw_c, g_mom, f, G, FP, ks, K, mom.nr, t->dw1_ws, n_partials, mid, rec, mid_prev, dW1_prev, R.branch_size());
     return (int)hipGetLastError();
@@ -804,7 +804,7 @@ extern "C" int gwtf_mtrain_phase(const GwtfTrainCtx* t, int phase, int step) {
   // GWTF_PHASE_BWD_C: only after the last level -- its gradient combine (dL/dp, in place) + stage 2 of its dW1 reduction
   if (step + 1 < C) return 0;
   const int bxn = (N + 255) / 256, n_bx = bxn < 64 ? bxn : 64;
-  const unsigned blocks = (unsigned)n_bx * B * K + (unsigned)((rec + 63) / 64) * K;
+  const unsigned blocks = (unsigned)n_bx * B * K + (unsigned)((gwtf_dw1::rec_floats(f) + 63) / 64) * K;
   hipLaunchKernelGGL(bwd_tail2_kernel, dim3(blocks), dim3(256), 0, st, x_in, nxt, g_mom, nxt, B, N, ks, K, n_bx, mid,
                      g_raw_c + R.sd1_w(), f, R.branch_size());
   return (int)hipGetLastError();

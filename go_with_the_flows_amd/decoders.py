@@ -95,9 +95,35 @@ class _SiblingGroup:
         e._last_lists = None
         ps, mus, lvs = rnd['lists']
         res = list(ps[k].unbind(0)), list(mus[k].unbind(0)), list(lvs[k].unbind(0))
+        # the pipeline's own log-det of this component rides along on the logvars slots: a consumer that is about to add the C slots
+        # up again (models.FlowMixtureNLL on the reference's lists) recognises the complete list and takes the sum that exists
+        tag = _SlotSum(rnd['logdet'][k], len(res[2]))
+        for j, t in enumerate(res[2]):
+            t._gwtf_slot = (tag, j, t._version)
         if not rnd['pending']:
             self.round = None                               # nothing left to hand out: release the references
         return res
+
+
+class _SlotSum:
+    """sum of the C logvars slots of one decoder call, as the pipeline computed it (same values, one tensor instead of C - 1 adds and
+    a gradient into every slot)"""
+    __slots__ = ('total', 'C')
+
+    def __init__(self, total, C):
+        self.total, self.C = total, C
+
+
+def slot_sum(tensors):
+    """The stack's own sum of `tensors` when they are exactly the C logvars slots of one batched decoder call, in order; else None."""
+    tag = getattr(tensors[0], '_gwtf_slot', (None, 0))[0] if tensors else None
+    if tag is None or len(tensors) != tag.C:
+        return None
+    for j, t in enumerate(tensors):
+        s = getattr(t, '_gwtf_slot', None)
+        if s is None or s[0] is not tag or s[1] != j or s[2] != t._version:       # (an in-place edit of a slot voids the shortcut)
+            return None
+    return tag.total
 
 
 def _note_parent(parent, name, child):

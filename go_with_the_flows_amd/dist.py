@@ -47,19 +47,51 @@ def capture_mode():
     return 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
 
 
-def quiesce_for_capture(device=None):
+# ---- the package's own eager collectives are issued through `run` -------------------------------------------------------------
+# Eager (not captured) RCCL collectives are issued asynchronously and waited for on the current stream at once -- the same ordering
+# as the blocking form -- so that the package HOLDS their Work objects: quiesce_for_capture polls exactly those instead of sleeping
+# for a guessed number of watchdog periods.  Inside a capture, and on gloo, the blocking form is used (a Work created inside a
+# capture would sit in ProcessGroupNCCL's watchdog list with events that cannot be queried).
+_EAGER_WORKS = []
+
+
+def _capturing(t=None):
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+def run(fn, *args, **kwargs):
+    """fn = a torch.distributed collective (all_reduce, all_gather, all_gather_into_tensor, all_to_all_single, broadcast)."""
+    if dist.get_backend() != 'nccl' or _capturing():
+        return fn(*args, **kwargs)
+    w = fn(*args, async_op=True, **kwargs)
+    if w is not None:
+        w.wait()                                    # stream-ordered (the host does not block): what the blocking form does
+        if len(_EAGER_WORKS) >= 64:                 # keep the list short: finished ones go
+            _EAGER_WORKS[:] = [x for x in _EAGER_WORKS if not x.is_completed()]
+        _EAGER_WORKS.append(w)
+    return None
+
+
+def quiesce_for_capture(device=None, timeout_s=10.0):
     """Call right before a hipGraph capture in a process with an RCCL process group.  ProcessGroupNCCL's watchdog thread polls the
-    completion events of earlier (eager) collectives every ~100 ms; while its internal stream is part of a capture HIP refuses
-    such a query (hipErrorCapturedEvent / hipErrorStreamCaptureUnsupported) and the watchdog takes the process down.  This
-    torch build does not wait for the watchdog's list to drain by itself, so: finish all device work, then give the watchdog
-    three polling periods to retire what is left."""
+    completion events of earlier (eager) collectives; a capture must not begin while one of them is still in flight.  Drain: finish
+    all device work, then poll is_completed() of every Work this package issued (`run` above) until all report done -- a loop on the
+    objects themselves, not a sleep for a guessed number of watchdog periods (rounds 3-4 slept 0.35 s).  GWTF_CAPTURE_QUIESCE_S adds
+    a fixed grace period on top (default 0) for torch builds whose watchdog needs one.  The primary protection stays
+    capture_mode() = 'thread_local'."""
     if dist.is_available() and dist.is_initialized() and dist.get_backend() == 'nccl' and torch.cuda.is_available():
         import time
         torch.cuda.synchronize(device)
-        # An ASSUMPTION about ProcessGroupNCCL's watchdog (its polling period is ~100 ms in this torch build and it retires a finished
-        # work item on the next poll): GWTF_CAPTURE_QUIESCE_S overrides the wait for other builds / loaded hosts.  The primary
-        # protection stays capture_mode() = 'thread_local'; keep no asynchronous Work object alive across the capture.
-        time.sleep(float(os.environ.get('GWTF_CAPTURE_QUIESCE_S', '0.35')))
+        t0 = time.perf_counter()
+        while any(not w.is_completed() for w in _EAGER_WORKS):
+            if time.perf_counter() - t0 > timeout_s:
+                raise RuntimeError(f'{sum(not w.is_completed() for w in _EAGER_WORKS)} eager collective(s) still pending after {timeout_s} s: '
+                                   'a rank is missing from a collective; a hipGraph capture cannot start')
+            time.sleep(0.002)
+        del _EAGER_WORKS[:]
+        grace = float(os.environ.get('GWTF_CAPTURE_QUIESCE_S', '0'))
+        if grace > 0:
+            time.sleep(grace)
 
 
 def graph_capture(graph, device=None, **kwargs):
@@ -70,7 +102,7 @@ def graph_capture(graph, device=None, **kwargs):
 
 def sum_over_ranks(t):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
     return t
 
 
@@ -123,7 +155,7 @@ def reset_row_layouts():
 def _exchange_sizes(rows, device, world, rank):
     on = device if dist.get_backend() == 'nccl' else torch.device('cpu')
     sizes = [torch.zeros(1, dtype=torch.int64, device=on) for _ in range(world)]
-    dist.all_gather(sizes, torch.tensor([int(rows)], dtype=torch.int64, device=on))
+    run(dist.all_gather, sizes, torch.tensor([int(rows)], dtype=torch.int64, device=on))
     ROW_EXCHANGES['n'] += 1
     return RowLayout([int(x.item()) for x in sizes], rank)
 
@@ -166,7 +198,7 @@ def _gather_padded(t, lay):
         mine = torch.cat([mine, mine.new_zeros((bmax - mine.shape[0],) + tuple(mine.shape[1:]))])
     out = mine.new_empty((len(lay.sizes) * bmax,) + tuple(mine.shape[1:]))
     if dist.get_backend() == 'nccl':
-        dist.all_gather_into_tensor(out, mine)
+        run(dist.all_gather_into_tensor, out, mine)
     else:
         dist.all_gather(list(out.chunk(len(lay.sizes))), mine)
     if lay.even:
@@ -188,7 +220,7 @@ class GatherRows(torch.autograd.Function):
     def backward(ctx, g_all):
         lay = ctx.lay
         g_all = g_all.contiguous().clone()
-        dist.all_reduce(g_all, op=dist.ReduceOp.SUM)
+        run(dist.all_reduce, g_all, op=dist.ReduceOp.SUM)
         return g_all[lay.row0:lay.row0 + lay.sizes[dist.get_rank()]], None
 
 
@@ -201,47 +233,46 @@ def gather_rows(t):
 
 
 def all_reduce_direct(flat, group=None):
-    """Sum `flat` over the ranks with the DIRECT algorithm: reduce-scatter + all-gather done as point-to-point
-    messages between every pair of ranks, not around a ring.  On an MI355X node every GPU has its own xGMI link to each of the
-    other seven (7 x ~153 GB/s, no switch), so a rank can send its W - 1 chunks to their owners at the same time over W - 1
-    different links and the whole exchange is two steps of n / W elements per link -- a ring all-reduce moves 2 (W - 1) / W n
-    elements through EVERY link in 2 (W - 1) dependent steps.  In place; `flat` is a contiguous 1-D tensor of any length (the
-    chunk grid is padded on the fly).  Uses only batched isend / irecv, which RCCL ('nccl') and gloo both provide."""
+    """Sum `flat` over the ranks with the DIRECT algorithm: reduce-scatter + all-gather as messages between every pair of
+    ranks, not around a ring.  On an MI355X node every GPU has its own xGMI link to each of the other seven (7 x ~153 GB/s, no
+    switch), so a rank sends its W - 1 chunks to their owners at the same time over W - 1 different links and the exchange is two
+    steps of n / W elements per link -- a ring all-reduce moves 2 (W - 1) / W n elements through EVERY link in 2 (W - 1) dependent
+    steps.  Step 1 is ONE all_to_all_single (chunk r of every rank to rank r: RCCL runs it as grouped sends / receives between all
+    pairs), the owner adds the W chunks in rank order (the same sum on every run), step 2 one all_gather_into_tensor.  Both are plain
+    stream-ordered collectives: no Work object, no host wait -- CAPTURABLE in a hipGraph like the ring all-reduce (round 4's
+    batch_isend_irecv + wait() form was not).  In place; `flat`: contiguous 1-D, any length (padded to W chunks on the fly)."""
     world = dist.get_world_size(group)
     if world == 1:
         return flat
-    rank = dist.get_rank(group)
     n = flat.numel()
     chunk = (n + world - 1) // world
-    bounds = [(min(n, r * chunk), min(n, (r + 1) * chunk)) for r in range(world)]
-    lo, hi = bounds[rank]
-    peers = [r for r in range(world) if r != rank]
-    to_global = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
-    # step 1 (reduce-scatter): chunk r of every rank goes to rank r; mine arrives from everybody else
-    inbox = [torch.empty(hi - lo, dtype=flat.dtype, device=flat.device) for _ in peers]
-    ops = []
-    for r, buf in zip(peers, inbox):
-        a, b = bounds[r]
-        if b > a:
-            ops.append(dist.P2POp(dist.isend, flat[a:b], to_global(r), group))
-        if hi > lo:
-            ops.append(dist.P2POp(dist.irecv, buf, to_global(r), group))
-    for w in (dist.batch_isend_irecv(ops) if ops else []):
-        w.wait()
-    mine = flat[lo:hi]
-    for buf in inbox:                      # fixed order of additions: rank 0's, rank 1's, ... -- the same sum on every run
-        mine.add_(buf)
-    # step 2 (all-gather): the reduced chunk goes to everybody, theirs arrive in place
-    ops = []
-    for r in peers:
-        a, b = bounds[r]
-        if hi > lo:
-            ops.append(dist.P2POp(dist.isend, mine, to_global(r), group))
-        if b > a:
-            ops.append(dist.P2POp(dist.irecv, flat[a:b], to_global(r), group))
-    for w in (dist.batch_isend_irecv(ops) if ops else []):
-        w.wait()
+    if chunk * world == n:
+        send = flat
+    else:
+        send = flat.new_zeros(chunk * world)
+        send[:n].copy_(flat)
+    inbox = torch.empty_like(send)
+    kw = {'group': group} if group is not None else {}
+    run(dist.all_to_all_single, inbox, send, **kw)                       # row r of inbox: rank r's copy of MY chunk
+    mine = inbox.view(world, chunk).sum(0)                               # fixed order: rank 0's, rank 1's, ...
+    if dist.get_backend(group) == 'nccl':
+        run(dist.all_gather_into_tensor, send, mine, **kw)
+    else:
+        run(dist.all_gather, list(send.chunk(world)), mine, **kw)
+    if send is not flat:
+        flat.copy_(send[:n])
     return flat
+
+
+def _sum_over_ranks(flat, algorithm):
+    """In-place sum of a flat buffer over the default group: 'ring' = the library's all-reduce (RCCL picks its own schedule), 'direct'
+    = all_reduce_direct (sized for the xGMI mesh).  Both stream-ordered and capturable."""
+    if algorithm == 'direct':
+        all_reduce_direct(flat)
+    elif algorithm == 'ring':
+        run(dist.all_reduce, flat, op=dist.ReduceOp.SUM)
+    else:
+        raise ValueError(f'unknown gradient exchange algorithm {algorithm!r}')
 
 
 def all_reduce_gradients(module, average=True, force=False, algorithm='ring'):
@@ -260,10 +291,7 @@ def all_reduce_gradients(module, average=True, force=False, algorithm='ring'):
         return 0
     grads = [p.grad for p in params]
     flat = torch.cat([g.reshape(-1) for g in grads])
-    if algorithm == 'direct':
-        all_reduce_direct(flat)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    _sum_over_ranks(flat, algorithm)
     if average:
         flat.div_(dist.get_world_size())
     # scatter back with ONE multi-tensor copy (a per-parameter copy_ is ~650 launches for the airplane model)
@@ -290,13 +318,13 @@ def sync_module_state(module, src=0, verify_only=False):
         group = by_dtype[dtype]
         flat = torch.cat([t.detach().reshape(-1) for t in group])
         wire = flat.cpu() if (on_cpu and flat.is_cuda) else flat.clone()
-        dist.broadcast(wire, src=src)
+        run(dist.broadcast, wire, src=src)
         wire = wire.to(flat.device)
         total += flat.numel()
         if verify_only:
             same = torch.equal(wire, flat) or bool(((wire == flat) | (torch.isnan(wire.float()) & torch.isnan(flat.float()))).all())
             ok = torch.tensor([1 if same else 0], dtype=torch.int64, device=wire.device if not on_cpu else 'cpu')
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            run(dist.all_reduce, ok, op=dist.ReduceOp.MIN)
             if int(ok) == 0:
                 raise RuntimeError(f"rank {dist.get_rank()}: the model's {dtype} state differs between the ranks "
                                    f'(parameters / buffers not synchronised: call dist.sync_module_state(model) first)')
@@ -332,8 +360,14 @@ class OverlappedGradients:
     hold a .grad are then reduced with the remainder, as accumulated totals (tests/dist_gpu_worker.py).
     """
 
-    def __init__(self, module, average=True, sync_state=True):
+    def __init__(self, module, average=True, sync_state=True, algorithm=None):
+        """algorithm: 'ring' (the library all-reduce) or 'direct' (all_reduce_direct: one all-to-all + one all-gather over the xGMI
+        mesh) for EVERY exchange of this reducer -- the per-decoder ones launched from inside the backward pass and the remainder --
+        so that an 8-GPU run can A/B the two inside the captured step; default: GWTF_GRAD_ALGORITHM or 'ring'."""
         self.module, self.average = module, average
+        self.algorithm = algorithm or os.environ.get('GWTF_GRAD_ALGORITHM', 'ring')
+        if self.algorithm not in ('ring', 'direct'):
+            raise ValueError(f'unknown gradient exchange algorithm {self.algorithm!r}')
         self.pending = []
         self.launched = 0          # asynchronous collectives launched from inside the backward pass (tests read it)
         # every rank starts from rank 0's parameters AND buffers, as DistributedDataParallel's constructor guarantees
@@ -364,7 +398,7 @@ class OverlappedGradients:
             return
         buf = grad.contiguous().clone()
         if not buf.is_cuda:
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+            _sum_over_ranks(buf, self.algorithm)
             self.pending.append((buf, engine, None))
         else:
             # a stream-ordered all-reduce on a SIDE stream (not async_op=True: a Work object created inside a hipGraph capture
@@ -376,7 +410,7 @@ class OverlappedGradients:
                 side = _REDUCE_STREAMS[buf.device] = torch.cuda.Stream(device=buf.device)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
-                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                _sum_over_ranks(buf, self.algorithm)
             buf.record_stream(side)
             self.pending.append((buf, engine, side))
         self.launched += 1
@@ -405,7 +439,7 @@ class OverlappedGradients:
         rest = [p for p in self.module.parameters() if p.grad is not None and id(p) not in covered]
         if rest:
             flat = torch.cat([p.grad.reshape(-1) for p in rest])
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            _sum_over_ranks(flat, self.algorithm)
             if self.average:
                 flat.div_(world)
             for p, v in zip(rest, flat.split_with_sizes([p.grad.numel() for p in rest])):

@@ -38,6 +38,7 @@ class _EncoderTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, enc, sync, *params):
         import torch.distributed as dist
+        from .dist import run as _run
         L = _lib.lib()
         x = x.contiguous()
         B, _, N = x.shape
@@ -60,7 +61,7 @@ class _EncoderTrainFn(torch.autograd.Function):
         def over_ranks(t):
             if sync:
                 t = t.clone()
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                _run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
             return t
 
         with torch.cuda.device(dev):
@@ -108,6 +109,7 @@ class _EncoderTrainFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_pooled, _g_amax):
         import torch.distributed as dist
+        from .dist import run as _run
         L = _lib.lib()
         x, pooled, *params = ctx.saved_tensors
         b = ctx.buf
@@ -121,7 +123,7 @@ class _EncoderTrainFn(torch.autograd.Function):
         def over_ranks(t):
             if sync:
                 t = t.clone()
-                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                _run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
             return t
 
         grads = [None] * 12

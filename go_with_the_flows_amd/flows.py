@@ -19,6 +19,18 @@ from .layers import SharedDot, Swish
 
 _VERSION = operator.attrgetter('_version')
 
+# Points whose coordinates leave the split-f16 contraction's operand range (|x| > 3e4, csrc/gwtf_layout.h GWTF_X_LIMIT) are flagged
+# NaN by the stack kernel; the eval-mode density / list paths follow every stack launch with the exact-fp32 re-run launch
+# (csrc/gwtf_stack_exact.hip: tiles without a flagged point leave at once, ~2 us), so such points come back with the
+# reference's finite values (reference flows.py:113-115 has no range limit).  GWTF_NO_RANGE_RERUN=1 switches it off (NaN as in
+# rounds 1-4).  The sampling partition (MixtureStack.forward_partition: base samples, |z| of a few units, latency-bound at one
+# shape per call) and the train pipeline do not re-run.
+import os as _os
+
+
+def range_rerun():
+    return _os.environ.get('GWTF_NO_RANGE_RERUN') != '1'
+
 # index -> warped coordinates; couplings of a decoder cycle through these (reference flows.py:129-148)
 WARP_PATTERNS = ((0,), (1,), (2,), (0, 1), (0, 2), (1, 2))
 
@@ -363,7 +375,16 @@ class StackEngine:
                 raw = self.raw_arena()
                 self._packed = _lib.pack_weights(raw, self.C, self.f, self.G, training, self.pattern0)
             self._cache_key = key
+            self._packed_x = None
         return self._packed
+
+    def packed_exact(self):
+        """The exact-fp32 operand record of the CURRENT eval packing (cached with it)."""
+        pw, pf = self.packed(False)
+        if getattr(self, '_packed_x', None) is None:
+            with torch.no_grad():
+                self._packed_x = _lib.pack_weights_exact(self.raw_arena(), pf, self.C, self.f, self.G, self.pattern0)
+        return self._packed_x
 
     def _check(self, p, g):
         if p.dim() != 3 or p.shape[1] != 3:
@@ -430,8 +451,9 @@ class StackEngine:
             out, logdet, lists = self._run_train(pc, gc, mode, want_lists)
         else:
             pw, pf = self.packed(False)
+            px = self.packed_exact() if (range_rerun() or _lib.EXACT[0]) else None
             film = _lib.film_forward(gc, pf, self.C, self.f, eps, False)
-            out, logdet, lists = _lib.stack_forward(pc, pw, film, self.C, self.f, self.pattern0, eps, mode, want_lists)
+            out, logdet, lists = _lib.stack_forward(pc, pw, film, self.C, self.f, self.pattern0, eps, mode, want_lists, packed_x=px)
         return out, logdet, lists                 # no-grad paths only: both differentiable cases returned above
 
     # -- train mode: batch-statistic BatchNorm ----------------------------------------------------------
@@ -549,14 +571,15 @@ class GraphedStack:
         self.engines = list(engines)
         self.p, self.g, self.mode = p, g, mode
         packs = [e.packed(False) for e in self.engines]
+        pxs = [e.packed_exact() if (range_rerun() or _lib.EXACT[0]) else None for e in self.engines]
         eps = self.engines[0].couplings[0]._eps_value
         ps = per_engine_p if per_engine_p is not None else [p] * len(self.engines)
 
         def body():
             res = []
-            for e, (pw, pf), pk in zip(self.engines, packs, ps):
+            for e, (pw, pf), px, pk in zip(self.engines, packs, pxs, ps):
                 film = _lib.film_forward(g, pf, e.C, e.f, eps, False)
-                res.append(_lib.stack_forward(pk, pw, film, e.C, e.f, e.pattern0, eps, mode, want_lists))
+                res.append(_lib.stack_forward(pk, pw, film, e.C, e.f, e.pattern0, eps, mode, want_lists, packed_x=px))
             return res
 
         side = torch.cuda.Stream(device=p.device)
@@ -567,7 +590,7 @@ class GraphedStack:
         self.graph = torch.cuda.CUDAGraph()
         with _graph_capture(self.graph), torch.no_grad():
             self.results = body()
-        self._keepalive = packs
+        self._keepalive = (packs, pxs)
 
     def replay(self):
         self.graph.replay()

@@ -35,6 +35,15 @@ class MixtureStack:
             self._cat_key, self._keep = key, packs
         return self._cat
 
+    def packed_exact(self):
+        """The K components' exact-fp32 operand records, concatenated (re-run of out-of-range tiles, flows.range_rerun)."""
+        self.packed()
+        pxs = [e.packed_exact() for e in self.engines]
+        key = tuple(id(x) for x in pxs)
+        if key != getattr(self, '_catx_key', None):
+            self._catx, self._catx_key, self._keepx = torch.cat(pxs), key, pxs
+        return self._catx
+
     def _film(self, g):
         pw, pf = self.packed()
         eps = self.engines[0].couplings[0]._eps_value
@@ -63,8 +72,10 @@ class MixtureStack:
             # eval BatchNorm with autograd (or the cross-check chain): the per-component differentiable path
             res = [e.run(p, g, mode, False) for e in self.engines]
             return torch.stack([r[0] for r in res]), torch.stack([r[1] for r in res])
+        from .flows import range_rerun
         pw, film, eps = self._film(g.contiguous().float())
-        return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode)
+        px = self.packed_exact() if (range_rerun() or _lib.EXACT[0]) else None
+        return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode, packed_x=px)
 
     def forward_all_lists(self, p, g, mode='inverse', defer_running_stats=False):
         """Every component on every point, train-mode BatchNorm, WITH the reference's per-coupling lists: -> (out, logdet (K,B,3,N),
@@ -104,8 +115,10 @@ class MixtureStack:
             segs.append((off, off + int(cnt)))
             off += int(cnt)
         pw, film, eps = self._film(g.contiguous().float())
+        # no re-run launch here (base samples of a few units; one shape per call is latency-bound) unless the exact body is forced
+        px = self.packed_exact() if _lib.EXACT[0] else None
         return _lib.stack_forward_multi(p.contiguous().float(), pw, film, self.K, self.C, self.f, e0.pattern0, eps, mode,
-                                        segments=segs, shared_points=False)
+                                        segments=segs, shared_points=False, packed_x=px)
 
 
 class _MixtureNLLFn(torch.autograd.Function):

@@ -397,8 +397,13 @@ class FlowMixtureNLL(nn.Module):
     def forward(self, output_decoder, mixture_weights_logits):
         z = torch.stack([o['p_prior_samples'][0] for o in output_decoder])
         # the batched training decode attaches the stack's own log-det (= sum of the list's flow entries, same values)
-        logdet = torch.stack([o['_sum_flow_logvars'] if '_sum_flow_logvars' in o else sum(o['p_prior_logvars'][1:])
-                              for o in output_decoder])
+        def flow_logdet(o):
+            if '_sum_flow_logvars' in o:
+                return o['_sum_flow_logvars']
+            from .decoders import slot_sum
+            own = slot_sum(o['p_prior_logvars'][1:])         # the K-loop's lists from a batched sibling round: the sum exists already
+            return own if own is not None else sum(o['p_prior_logvars'][1:])
+        logdet = torch.stack([flow_logdet(o) for o in output_decoder])
         mu0 = torch.stack([o['p_prior_mus'][0][:, :, 0] for o in output_decoder])
         lv0 = torch.stack([o['p_prior_logvars'][0][:, :, 0] for o in output_decoder])
         return flow_mixture_nll(z, logdet, mu0, lv0, mixture_weights_logits)[0]

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWTF_ABI_VERSION 4
+#define GWTF_ABI_VERSION 5
 #define GWTF_E_BADARG 10001   /* shape / mode / width outside what the kernels support */
 #define GWTF_E_UNSUPPORTED 10002   /* a layer-width list no kernel instantiation was built for */
 #define GWTF_MODE_DIRECT 0    /* sampling direction  base -> data (reference models.py:202) */
@@ -124,6 +124,22 @@ int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float*
                              float* out, float* logdet, float* ps, float* mus, float* logvars,
                              const int* segments, int K, int B, int N, int C, int f, int pattern0, float eps,
                              int mode, size_t p_stride_k, size_t out_stride_k, int tune, void* stream);
+/* The same stack with the f x f contraction on the EXACT-fp32 matrix instruction (v_mfma_f32_16x16x4_f32, unsplit operands):
+ * the arithmetic of the reference's torch.matmul in SharedDot (lib/networks/layers.py:40-45 as called by flows.py:95-117), no
+ * operand range limit (csrc/gwtf_stack_exact.hip).  packed_x: gwtf_pack_weights_exact of the same raw arena
+ * [K*C][gwtf_packed_x_coupling_floats]; film: the SAME FiLM records gwtf_film_forward wrote for the split kernel.
+ *   only_flagged = 0: every tile is computed (on-device A/B of the split-f16 contraction; the fp32-MFMA comparison point).
+ *   only_flagged = 1: RE-RUN after gwtf_stack_forward[_multi] with the same arguments -- a workgroup reads its tile's out / logdet,
+ *                     returns at once if they are all finite, and otherwise recomputes the tile (all list slots included): points the
+ *                     split kernel flagged with NaN because a coordinate left the f16-safe range (|x| > 3e4) come back with the
+ *                     reference's finite fp32 values; genuinely non-finite inputs / parameters stay NaN.
+ * ps, mus, logvars: all three or none.  tune: GWTF_TUNE_POINTS_PER_WAVE(16 | 32) only. */
+size_t gwtf_packed_x_coupling_floats(int f);
+int gwtf_pack_weights_exact(const float* raw, const float* packed_film /*eval packing of the same arena: its range exponents*/,
+                            float* packed_x, int K, int Cper, int f, int G, int pattern0, void* stream);
+int gwtf_stack_forward_exact(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps,
+                             float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f, int pattern0,
+                             float eps, int mode, size_t p_stride_k, size_t out_stride_k, int only_flagged, int tune, void* stream);
 /* Tile plan of a forward launch (what stack_dispatch decides; diagnostic + tests): out[0] = points per wavefront of the main
  * launch, out[1] = its workgroups, out[2] = points per wavefront of the tail launch (0: none), out[3] = its workgroups.
  * The choice minimises resident rounds x the cost of a round of that tile (calibrated, csrc/gwtf_stack.hip tile_cost). */

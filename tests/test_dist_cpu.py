@@ -82,6 +82,26 @@ def _direct_worker(rank, world, port):
     assert n_flat == 7 * 3 + 3
     mean = sum(r + 1.0 for r in range(world)) / world
     assert all(torch.allclose(p.grad, torch.full_like(p, mean)) for p in lin.parameters())
+    # the overlapped reducer with the exchange algorithm as a constructor argument: same averaged gradients
+    from go_with_the_flows_amd.dist import OverlappedGradients
+    for algo in ('ring', 'direct'):
+        torch.manual_seed(5)
+        net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+        red = OverlappedGradients(net, algorithm=algo)
+        assert red.algorithm == algo
+        x = torch.randn(4, 7, generator=torch.Generator().manual_seed(50 + rank))
+        with red:
+            net(x).square().sum().backward()
+        got = torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+        net.zero_grad(set_to_none=True)
+        tot = None
+        for r in range(world):                                   # every rank's local gradient, recomputed here
+            xr = torch.randn(4, 7, generator=torch.Generator().manual_seed(50 + r))
+            net(xr).square().sum().backward()
+        want = torch.cat([p.grad.reshape(-1) for p in net.parameters()]) / world
+        assert torch.allclose(got, want, rtol=1e-5, atol=1e-6), (algo, rank)
+    with pytest.raises(ValueError):
+        OverlappedGradients(lin, algorithm='tree', sync_state=False)
     dist.barrier()
     dist.destroy_process_group()
 

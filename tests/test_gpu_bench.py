@@ -33,12 +33,19 @@ def test_single_gpu_line_has_roofline_and_m1():
     assert 18.0e6 < r['traffic'] < 80.0e6, r['traffic']
     m1r = line['also']['m1']['roofline']                                          # the metric's own shape: measured live as well
     assert 'measured by this run' in m1r['traffic_source'] and 2.3e6 < m1r['traffic'] < 30.0e6, m1r
-    assert line['also']['ae']['roofline']['traffic'] is None                     # nothing carried over from an earlier profile
+    for w in ('ae', 'svr', 'k16', 'k16_b1'):                                      # every shape's traffic is measured by the run itself
+        rw = line['also'][w]['roofline']
+        assert 'measured by this run' in rw['traffic_source'] and 1.0e6 < rw['traffic'] < 60.0e6, (w, rw)
+    x = line['also']['exact_fp32']                                                # the fp32-MFMA comparison point and the re-run launch's cost
+    assert 0.2 < x['frac_of_fp32_mfma_peak'] < 1.0 and 1.2 < x['split_over_exact'] < 6.0 and -2.0 < x['rerun_launch_us'] < 15.0, x
     ts = line['also']['train_step']                      # the whole training step, timed in a child process
     assert 'error' not in ts and 5 < ts['ms_per_step'] < 60, ts
     # ... and the data-parallel code path on a 1-rank RCCL group: every collective inside the graph, at most 15 % slower
     dp = ts['data_parallel_path_1rank']
     assert 'error' not in dp and dp['statistic_all_reduces_in_graph'] == 132 and dp['ms_per_step'] < 1.15 * ts['ms_per_step'], ts
+    sw = ts['import_swap_only']                          # the literal decoder-import swap: K sequential calls -> one K-batched pass
+    assert sw['with_this_loss']['ms_per_step'] < 0.6 * sw['with_this_loss_no_sibling_batching']['ms_per_step'], sw
+    assert sw['reference_loss_loop']['ms_per_step'] > sw['with_this_loss']['ms_per_step'], sw
     ae = ts['ae_shard']                                  # configs[2]'s per-rank shard (16 shapes, G = 512) through the same path
     assert 'error' not in ae and 2 < ae['plain_ms_per_step'] <= ae['data_parallel_path_1rank_ms_per_step'] < 40, ae
 

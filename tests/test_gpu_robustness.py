@@ -129,7 +129,11 @@ def _small(f=19):
 @pytest.mark.parametrize('mode', ['direct', 'inverse'])
 @pytest.mark.parametrize('bad', [np.nan, np.inf, -np.inf, 1e5])
 @pytest.mark.parametrize('f', [19, 37])          # 37: the abs-form widths (|.| source modifiers instead of v_max)
-def test_nonfinite_or_out_of_range_points_reach_out_and_logdet(mode, bad, f):
+def test_nonfinite_or_out_of_range_points_reach_out_and_logdet(mode, bad, f, monkeypatch):
+    """The split-f16 stack kernel on its own (GWTF_NO_RANGE_RERUN=1, what rounds 1-4 shipped): NaN / Inf points and points beyond
+    the operand range are flagged NaN.  With the re-run launch (the default) the out-of-range ones come back finite:
+    tests/test_gpu_exact.py::test_out_of_range_points_come_back_finite_and_equal_to_the_fp64_oracle."""
+    monkeypatch.setenv('GWTF_NO_RANGE_RERUN', '1')
     L, f, G, B, N, m, st, p, g = _small(f)
     m = m.to(DEV).eval()
     p = p.copy()
@@ -202,3 +206,33 @@ def test_nonfinite_point_in_train_mode_reaches_the_loss(f):
     with torch.no_grad():
         out, ld = m.forward_fused(dev(p), dev(g), 'inverse')
     assert not np.isfinite(float((out ** 2).sum() + ld.sum()))
+
+
+@pytest.mark.parametrize('mode', ['direct', 'inverse'])
+@pytest.mark.parametrize('bad', [np.nan, np.inf, -np.inf])
+@pytest.mark.parametrize('f', [19, 37])
+def test_nonfinite_points_stay_nan_through_the_rerun_launch(mode, bad, f):
+    """Default path (split launch + exact-fp32 re-run of flagged tiles): a genuinely non-finite point is recomputed and is NaN again in
+    coordinates AND log-det; the other points of its tile are finite and within tolerance of a run without the bad points."""
+    L, f, G, B, N, m, st, p, g = _small(f)
+    m = m.to(DEV).eval()
+    p = p.copy()
+    hits = [(0, 0, 5), (1, 2, 77), (2, 1, 129)]
+    for b, d, n in hits:
+        p[b, d, n] = bad
+    with torch.no_grad():
+        out, ld = m.forward_fused(dev(p), dev(g), mode)
+        ps, mus, lvs = m(dev(p), dev(g), mode)
+    o, l = host(out), host(ld)
+    mask = np.zeros((B, N), bool)
+    for b, d, n in hits:
+        mask[b, n] = True
+        assert not np.isfinite(o[b, :, n]).any() and not np.isfinite(l[b, :, n]).any()
+    p_ok = np.where(np.isfinite(p), p, 0.0).astype(np.float32)
+    with torch.no_grad():
+        out_ok, ld_ok = m.forward_fused(dev(p_ok), dev(g), mode)
+    sel = np.broadcast_to(~mask[:, None, :], o.shape)
+    assert np.isfinite(o[sel]).all() and np.isfinite(l[sel]).all()
+    assert maxabs(o[sel], host(out_ok)[sel]) < TOL_COORD and maxabs(l[sel], host(ld_ok)[sel]) < TOL_LOGDET
+    fin = ps[0] if mode == 'inverse' else ps[-1]
+    assert torch.equal(torch.isnan(fin), torch.isnan(out)) and not np.isfinite(host(sum(lvs))[0, :, 5]).any()
