@@ -9,6 +9,8 @@
 
 namespace {
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));     // 16 bytes at any dword address
+
 constexpr int kMaxT = 48;
 constexpr int kChunk = 4096;
 
@@ -48,11 +50,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamTable t, float lr, 
     const float step = (mm / bc1) / (den / bc2s + eps);
     pp = pp - (pp * wd + lr * step);
   };
-  const bool vec = (((size_t)p | (size_t)g | (size_t)m | (size_t)v | (size_t)(AMS ? vm : p)) & 15) == 0;
+  // 16-byte accesses need p / m / v / vmax on 16-byte boundaries (torch allocations: always).  The GRADIENT does not: the decoders'
+  // .grad tensors are views of one flat arena gradient at odd float offsets (flows._ArenaCat, dist.OverlappedGradients.finish), and a
+  // global_load_dwordx4 only needs dword alignment -- g is read through a 4-byte-aligned vector type (with g in this test
+  // ~3.7 M of the airplane model's 4.8 M parameters took the scalar path)
+  const bool vec = (((size_t)p | (size_t)m | (size_t)v | (size_t)(AMS ? vm : p)) & 15) == 0;
   for (size_t i = base + (size_t)threadIdx.x * 4; i < base + kChunk && i < n; i += 256 * 4) {
     if (vec && i + 4 <= n) {
       float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
-      const float4 gg = *reinterpret_cast<const float4*>(g + i);
+      const f4u gg = *reinterpret_cast<const f4u*>(g + i);
       float4 vx = AMS ? *reinterpret_cast<float4*>(vm + i) : make_float4(0.f, 0.f, 0.f, 0.f);
       upd(pp.x, gg.x, mm.x, vv.x, vx.x);
       upd(pp.y, gg.y, mm.y, vv.y, vx.y);
@@ -104,11 +110,15 @@ __global__ __launch_bounds__(256) void adam_table_kernel(const unsigned long lon
     const float step = (mm / bc1) / (den / bc2s + eps);
     pp = pp - (pp * wd + lr * step);
   };
-  const bool vec = (((size_t)p | (size_t)g | (size_t)m | (size_t)v | (size_t)(AMS ? vm : p)) & 15) == 0;
+  // 16-byte accesses need p / m / v / vmax on 16-byte boundaries (torch allocations: always).  The GRADIENT does not: the decoders'
+  // .grad tensors are views of one flat arena gradient at odd float offsets (flows._ArenaCat, dist.OverlappedGradients.finish), and a
+  // global_load_dwordx4 only needs dword alignment -- g is read through a 4-byte-aligned vector type (with g in this test
+  // ~3.7 M of the airplane model's 4.8 M parameters took the scalar path)
+  const bool vec = (((size_t)p | (size_t)m | (size_t)v | (size_t)(AMS ? vm : p)) & 15) == 0;
   for (size_t i = base + (size_t)threadIdx.x * 4; i < base + kChunk && i < n; i += 256 * 4) {
     if (vec && i + 4 <= n) {
       float4 pp = *reinterpret_cast<float4*>(p + i), mm = *reinterpret_cast<float4*>(m + i), vv = *reinterpret_cast<float4*>(v + i);
-      const float4 gg = *reinterpret_cast<const float4*>(g + i);
+      const f4u gg = *reinterpret_cast<const f4u*>(g + i);
       float4 vx = AMS ? *reinterpret_cast<float4*>(vm + i) : make_float4(0.f, 0.f, 0.f, 0.f);
       upd(pp.x, gg.x, mm.x, vv.x, vx.x);
       upd(pp.y, gg.y, mm.y, vv.y, vx.y);

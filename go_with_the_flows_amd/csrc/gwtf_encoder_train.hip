@@ -431,7 +431,10 @@ __global__ void enc_pool_finalize_kernel(const unsigned long long* __restrict__ 
   if (i >= B * C) return;
   const int c = i % C;
   const float s = aff[c], t = aff[C + c];
-  const bool use_max = !(s < 0.f);
+  // The forward kernel wrote ONE of the two keys per channel, chosen by the sign of the BatchNorm WEIGHT; the other is still the zero
+  // it was initialised with.  Decide by what was written, not by the sign of s = gamma * rstd: a tiny negative gamma under a large
+  // variance flushes s to -0 / +0 and `s < 0` then picks the key that never received a point.
+  const bool use_max = kmin[i] == 0ull;
   const unsigned long long key = use_max ? kmax[i] : kmin[i];
   const unsigned ob = (unsigned)(key >> 32);
   const float y = from_ordered_bits(use_max ? ob : ~ob);

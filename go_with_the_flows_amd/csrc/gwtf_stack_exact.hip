@@ -137,7 +137,35 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
   // of tiles); in re-run mode the launch is a few fat workgroups (launch_exact: at most 512) that each LOOK at many tiles -- looking is
   // a 4-byte read per point -- and compute only the flagged ones: the re-run launch behind a clean forward pass cost 8 us as one
   // workgroup per tile (4096 workgroups with 45 KB of LDS each just to read 128 values and leave), ~3 us this way.
-  for (int bid = blockIdx.x; bid < jobs.tiles_cum[jobs.K]; bid += gridDim.x) {
+  // re-run mode, phase 1: ALL of this workgroup's tiles are looked at in one round of loads (a tile at a time would be a dependent
+  // load + barrier per tile: 8 tiles x ~1 us behind a clean airplane launch), the flagged ones leave a bit in an LDS word
+  __shared__ unsigned s_flagged;
+  unsigned flagged_mask = 0xffffffffu;
+  if (only_flagged) {
+    if (threadIdx.x == 0) s_flagged = 0u;
+    __syncthreads();
+    unsigned mine = 0u;
+    int i = 0;
+    for (int bid = blockIdx.x; bid < jobs.tiles_cum[jobs.K] && i < 32; bid += gridDim.x, ++i) {
+      int comp = 0;
+      while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
+      const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
+      const int tps = (n_end - n_begin + 64 * NB - 1) / (64 * NB);
+      const int local = bid - jobs.tiles_cum[comp];
+      const int b = local / tps, tile = local - b * tps;
+      const int n = n_begin + tile * 64 * NB + (int)threadIdx.x;          // 64 NB <= 256 points per tile: thread t looks at point t
+      // (the split kernel sets ALL of a flagged point's coordinates and log-dets to NaN, and a non-finite value in any of them flags
+      // the point: its first coordinate tells -- 4 B per point to read)
+      if ((int)threadIdx.x < 64 * NB && n < n_end && gwtf_nonfinite(out[comp * out_stride_k + (size_t)b * 3 * N + n])) mine |= 1u << i;
+    }
+    if (mine) atomicOr(&s_flagged, mine);
+    __syncthreads();
+    flagged_mask = s_flagged;
+    if (flagged_mask == 0u) return;
+  }
+  int it = 0;
+  for (int bid = blockIdx.x; bid < jobs.tiles_cum[jobs.K]; bid += gridDim.x, ++it) {
+  if (only_flagged && !((flagged_mask >> (it & 31)) & 1u)) continue;      // (launch_exact sizes the grid so that it < 32)
   int comp = 0;
   while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
   const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
@@ -153,13 +181,6 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
   const int n_own = n_wave0 + 16 * own_nb + i16;
   const bool own_inrange = n_own < n_end, own_valid = own_inrange && q < NB;
 
-  if (only_flagged) {
-    // re-run mode: this tile's results of the split-f16 launch; a tile whose points are all finite is left alone
-    // (the split kernel sets ALL of a flagged point's coordinates and log-dets to NaN, a non-finite value in any of them flags the
-    // point: its first coordinate tells -- 4 B per point to read)
-    const bool flagged = own_valid && gwtf_nonfinite(outk[(size_t)b * 3 * N + n_own]);
-    if (!__syncthreads_or(flagged ? 1 : 0)) continue;
-  }
 
   auto stage = [&](int buf, int c) {
     const float* src_w = pxk + (size_t)c * X::PX;
@@ -263,7 +284,8 @@ int launch_exact(const float* p, const float* px, const float* film, float* out,
   }
   if (jobs.tiles_cum[K] == 0) return 0;
   // re-run launches: at most 512 workgroups (two per compute unit), each walks its share of the tiles
-  const dim3 grid((unsigned)(only_flagged ? std::min(jobs.tiles_cum[K], 512) : jobs.tiles_cum[K])), block(256);
+  // (and never more than 32 tiles per workgroup: their flags are the bits of one word)
+  const dim3 grid((unsigned)(only_flagged ? std::min(jobs.tiles_cum[K], std::max(512, (jobs.tiles_cum[K] + 31) / 32)) : jobs.tiles_cum[K])), block(256);
 #define GWTF_X(MODE_, LISTS_)                                                                                                    \
   hipLaunchKernelGGL((stack_exact_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, px, film, out, logdet, ps, mus, lvs, B, \
                      N, C, pattern0, eps, kk4, jobs, p_stride_k, out_stride_k, only_flagged)

@@ -269,6 +269,7 @@ def test_train_pipeline_with_negative_batchnorm_weights_pools_the_minimum():
                 prm[::2].neg_()
                 if 'sd2' in name:
                     prm[5] = 0.0                                    # a zero weight: the channel is constant, any point is "the" maximum
+                    prm[7] = -1e-42                                 # a denormal negative weight: gamma * rstd flushes to zero
     m = m.to(DEV).train()
     x = dev(synth_inputs(B, N, 4, seed + 1)[0])
     wgt = torch.randn(B, 512, device=DEV, generator=torch.Generator(DEV).manual_seed(seed))
