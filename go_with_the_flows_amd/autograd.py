@@ -415,7 +415,13 @@ class FilmHeadsFn(torch.autograd.Function):
     train pipeline's record); batch mean / biased variance of the heads' BatchNorm (KC, 2, 2, f) (training) or its running ones."""
 
     @staticmethod
-    def forward(ctx, raw, g_all, KC, f, G, row0, B, eps, training):
+    def forward(ctx, raw, g_all, KC, f, G, row0, B, eps, training, handover=None):
+        """handover: a dict shared with the TrainMixtureFn that consumes film_raw.  Both nodes produce a gradient for the SAME raw arena
+        in disjoint slots (the pipeline: sd0 / sd1 / sd2 / BatchNorm records; this node: the FiLM records, written in place): the
+        pipeline's backward -- which always runs first, film_raw being its input -- leaves its buffer in the dict and returns no raw
+        gradient, and this node's backward writes its slots into THAT buffer and returns it: one gradient tensor instead of two 15-MB
+        ones, no zero fill, no add (airplane config)."""
+        ctx.handover, ctx.n_in = handover, (10 if handover is not None else 9)
         L = _lib.lib()
         raw, g_all = raw.contiguous(), g_all.contiguous().float()
         _lib._ptr(raw, 'the raw parameter arena')          # fp32, on a HIP device: a .double()'d or CPU module raises here
@@ -450,7 +456,9 @@ class FilmHeadsFn(torch.autograd.Function):
         dev = raw.device
         Ball = g_all.shape[0]
         g_film_raw = g_film_raw.contiguous().float()
-        g_raw = torch.zeros_like(raw)
+        g_raw = ctx.handover.pop('g_raw', None) if ctx.handover is not None else None
+        if g_raw is None or g_raw.shape != raw.shape:
+            g_raw = torch.zeros_like(raw)
         dhraw = torch.empty_like(hraw)
         dg_part = torch.empty(L.gwtf_film_heads_slices(KC, G), Ball, G, device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
@@ -458,7 +466,7 @@ class FilmHeadsFn(torch.autograd.Function):
                                                   film_raw.data_ptr(), g_film_raw.data_ptr(), g_raw.data_ptr(), dhraw.data_ptr(),
                                                   dg_part.data_ptr(), KC, f, G, Ball, row0, B, eps, 1 if training else 0,
                                                   _lib._stream(raw)))
-        return g_raw, dg_part.sum(0), None, None, None, None, None, None, None
+        return (g_raw, dg_part.sum(0)) + (None,) * (ctx.n_in - 2)
 
 
 class _AllReduceSum(torch.autograd.Function):
@@ -594,7 +602,8 @@ class TrainMixtureFn(torch.autograd.Function):
     are all-reduced between phases."""
 
     @staticmethod
-    def forward(ctx, p, raw, film_raw, K, C, f, G, pattern0, eps, mode, n_total, sharded, want_lists=True):
+    def forward(ctx, p, raw, film_raw, K, C, f, G, pattern0, eps, mode, n_total, sharded, want_lists=True, handover=None):
+        ctx.handover = handover            # see FilmHeadsFn.forward
         L = _lib.lib()
         p, raw = p.contiguous(), raw.contiguous()
         B, _, N = p.shape
@@ -708,7 +717,11 @@ class TrainMixtureFn(torch.autograd.Function):
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_BWD_C, step))
         dp = bufs['g_bufs'][L.gwtf_mtrain_final_backward_half(C, _lib._MODES[mode])]
         dp = dp[0] if K == 1 else dp.sum(0)                    # the K components read the same clouds
-        return (dp, bufs["g_raw"], bufs['g_film_raw']) + (None,) * 10
+        g_raw = bufs["g_raw"]
+        if ctx.handover is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[1]:
+            ctx.handover['g_raw'] = g_raw          # the FiLM heads' backward adds its slots and returns the one buffer
+            g_raw = None
+        return (dp, g_raw, bufs['g_film_raw']) + (None,) * 11
 
 
 def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False, want_lists=True):
@@ -735,7 +748,8 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
     # the FiLM heads of all K stacks (4 K C small MLPs, BatchNorm over the latent rows of ALL ranks): one HIP launch forward, two
     # backward, parameters read from / gradients written into the stacked arena in place (csrc/gwtf_film_train.hip)
     # (any number of latent rows: the kernels walk them 128 at a time)
-    film_raw, film_mean, film_var = FilmHeadsFn.apply(raw, g_all, K * C, f, G, row0, B, eps, True)
+    handover = {} if raw.requires_grad else None
+    film_raw, film_mean, film_var = FilmHeadsFn.apply(raw, g_all, K * C, f, G, row0, B, eps, True, handover)
     film_var = film_var * (rows_total / max(rows_total - 1.0, 1.0))  # unbiased, as BatchNorm's running_var update takes it
     if raw.requires_grad:
         # every stack's whole parameter gradient is ONE flat tensor (the gradient of its raw arena: the pipeline's part plus
@@ -748,7 +762,7 @@ def train_density_forward_multi(engines, p, g, mode='inverse', distributed=False
                     sink.on_flat_gradient(grad[k], e)
         raw.register_hook(_to_reducer)
     out, logdet, ps, mus, lvs, bn_batch = TrainMixtureFn.apply(p.float(), raw, film_raw, K, C, f, G, e0.pattern0, eps, mode,
-                                                               float(rows_total) * N, distributed, want_lists)
+                                                               float(rows_total) * N, distributed, want_lists, handover)
     lists = (ps, mus, lvs) if want_lists else None           # (K,C,B,3,N) each; ps / lvs differentiable
     bn_batch = bn_batch.clone()
     bn_batch[:, :, :, 2:4, 0] = film_mean.view(K, C, 2, 2, f)

@@ -576,6 +576,7 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
   const int c_start = ex.c_count > 0 ? ex.c_first : (MODE == GWTF_MODE_INVERSE ? C - 1 : 0);
   stage(0, c_start);
   const float s_keep = sqrtf(eps + 1.0f);  // scale applied to un-warped coordinates (reference quirk)
+  float macc[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // coordinate moments of this lane's points (ex.moments_out)
   for (int it = 0; it < tpw; ++it) {       // tpw > 1 only with n_steps == 1: nothing is staged inside the loop
   const int tile = tile0 + it;
   if (tile >= tiles_per_shape) break;
@@ -685,28 +686,28 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
     }
   }
   if (ex.moments_out) {
-    // first and second moments of the output coordinates over all points (input statistics of the next
-    // coupling's sd0_bn in train mode): wavefront shuffle reduction, 9 atomics per wave
-    float mv[9];
+    // first and second moments of the output coordinates over all points (input statistics of the next coupling's sd0_bn in train
+    // mode): every lane adds its own point's nine products up over the workgroup's tiles; ONE wavefront reduction per workgroup below
+    // (per tile it was nine 6-step reductions + a barrier: ~110 of the ~920 VALU of a one-coupling tile)
+    const float m0 = own_valid ? xo[0] : 0.f, m1 = own_valid ? xo[1] : 0.f, m2 = own_valid ? xo[2] : 0.f;
+    macc[0] += m0; macc[1] += m1; macc[2] += m2;
+    macc[3] = fmaf(m0, m0, macc[3]); macc[4] = fmaf(m0, m1, macc[4]); macc[5] = fmaf(m0, m2, macc[5]);
+    macc[6] = fmaf(m1, m1, macc[6]); macc[7] = fmaf(m1, m2, macc[7]); macc[8] = fmaf(m2, m2, macc[8]);
+  }
+  }   // tiles of this workgroup
+  if (ex.moments_out) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) mv[d] = own_valid ? xo[d] : 0.f;
-    mv[3] = mv[0] * mv[0]; mv[4] = mv[0] * mv[1]; mv[5] = mv[0] * mv[2];
-    mv[6] = mv[1] * mv[1]; mv[7] = mv[1] * mv[2]; mv[8] = mv[2] * mv[2];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      mv[i] = wave_sum(mv[i]);
-    }
+    for (int i = 0; i < 9; ++i) macc[i] = wave_sum(macc[i]);
     __shared__ float s_mom[4][9];
     if (lane == 0) {
 #pragma unroll
-      for (int i = 0; i < 9; ++i) s_mom[wave][i] = mv[i];
+      for (int i = 0; i < 9; ++i) s_mom[wave][i] = macc[i];
     }
     __syncthreads();
     if (threadIdx.x < 9)
       atomicAdd(&ex.moments_out[comp * ex.moments_stride_k + (blockIdx.x % GWTF_STAT_REPLICAS) * 16 + threadIdx.x],
                 s_mom[0][threadIdx.x] + s_mom[1][threadIdx.x] + s_mom[2][threadIdx.x] + s_mom[3][threadIdx.x]);
   }
-  }   // tiles of this workgroup (s_mom is rewritten only behind the next tile's barriers)
 }
 
 template <int MB, int NB>

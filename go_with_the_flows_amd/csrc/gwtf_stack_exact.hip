@@ -32,6 +32,8 @@ struct XCfg {
   static constexpr int LAYER = PX + FSP;
 };
 
+constexpr int kLook = 8;      // tiles a workgroup of a re-run launch looks at
+
 struct XJobs {
   int K;
   int tiles_cum[GWTF_MAX_COMPONENTS + 1];
@@ -144,20 +146,28 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
   if (only_flagged) {
     if (threadIdx.x == 0) s_flagged = 0u;
     __syncthreads();
-    unsigned mine = 0u;
-    int i = 0;
-    for (int bid = blockIdx.x; bid < jobs.tiles_cum[jobs.K] && i < 32; bid += gridDim.x, ++i) {
-      int comp = 0;
-      while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
-      const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
-      const int tps = (n_end - n_begin + 64 * NB - 1) / (64 * NB);
-      const int local = bid - jobs.tiles_cum[comp];
-      const int b = local / tps, tile = local - b * tps;
-      const int n = n_begin + tile * 64 * NB + (int)threadIdx.x;          // 64 NB <= 256 points per tile: thread t looks at point t
-      // (the split kernel sets ALL of a flagged point's coordinates and log-dets to NaN, and a non-finite value in any of them flags
-      // the point: its first coordinate tells -- 4 B per point to read)
-      if ((int)threadIdx.x < 64 * NB && n < n_end && gwtf_nonfinite(out[comp * out_stride_k + (size_t)b * 3 * N + n])) mine |= 1u << i;
+    // (all kLook loads are issued before the first is tested: tested one by one they are kLook dependent round trips -- 6.8 us for 8)
+    float first[kLook];
+#pragma unroll
+    for (int i = 0; i < kLook; ++i) {
+      const int bid = (int)blockIdx.x + i * (int)gridDim.x;
+      first[i] = 0.f;
+      if (bid < jobs.tiles_cum[jobs.K]) {
+        int comp = 0;
+        while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
+        const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
+        const int tps = (n_end - n_begin + 64 * NB - 1) / (64 * NB);
+        const int local = bid - jobs.tiles_cum[comp];
+        const int b = local / tps, tile = local - b * tps;
+        const int n = n_begin + tile * 64 * NB + (int)threadIdx.x;          // 64 NB <= 256 points per tile: thread t looks at point t
+        // (the split kernel sets ALL of a flagged point's coordinates and log-dets to NaN, and a non-finite value in any of them flags
+        // the point: its first coordinate tells -- 4 B per point to read)
+        if ((int)threadIdx.x < 64 * NB && n < n_end) first[i] = out[comp * out_stride_k + (size_t)b * 3 * N + n];
+      }
     }
+    unsigned mine = 0u;
+#pragma unroll
+    for (int i = 0; i < kLook; ++i) mine |= gwtf_nonfinite(first[i]) ? 1u << i : 0u;
     if (mine) atomicOr(&s_flagged, mine);
     __syncthreads();
     flagged_mask = s_flagged;
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
   }
   int it = 0;
   for (int bid = blockIdx.x; bid < jobs.tiles_cum[jobs.K]; bid += gridDim.x, ++it) {
-  if (only_flagged && !((flagged_mask >> (it & 31)) & 1u)) continue;      // (launch_exact sizes the grid so that it < 32)
+  if (only_flagged && !((flagged_mask >> (it & 31)) & 1u)) continue;      // (launch_exact sizes the grid so that it < kLook)
   int comp = 0;
   while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
   const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
@@ -283,9 +293,8 @@ int launch_exact(const float* p, const float* px, const float* film, float* out,
     jobs.tiles_cum[k + 1] = jobs.tiles_cum[k] + B * ((jobs.end[k] - jobs.begin[k] + 64 * NB - 1) / (64 * NB));
   }
   if (jobs.tiles_cum[K] == 0) return 0;
-  // re-run launches: at most 512 workgroups (two per compute unit), each walks its share of the tiles
-  // (and never more than 32 tiles per workgroup: their flags are the bits of one word)
-  const dim3 grid((unsigned)(only_flagged ? std::min(jobs.tiles_cum[K], std::max(512, (jobs.tiles_cum[K] + 31) / 32)) : jobs.tiles_cum[K])), block(256);
+  // re-run launches: a workgroup LOOKS at kLook tiles (their flags are bits of one LDS word)
+  const dim3 grid((unsigned)(only_flagged ? (jobs.tiles_cum[K] + kLook - 1) / kLook : jobs.tiles_cum[K])), block(256);
 #define GWTF_X(MODE_, LISTS_)                                                                                                    \
   hipLaunchKernelGGL((stack_exact_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, px, film, out, logdet, ps, mus, lvs, B, \
                      N, C, pattern0, eps, kk4, jobs, p_stride_k, out_stride_k, only_flagged)
