@@ -14,6 +14,7 @@ The image-conditioned variant (Flow_Mixture_SVR_Model, flow_mixture.py:181-239) 
 encoder is convolutional work outside the point-flow path (out of scope).
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -89,6 +90,7 @@ class Local_Cond_RNVP_MC_Global_RNVP_VAE(nn.Module):
         ``finish_encode(out)`` -- call it after the decoders have been launched (forward_fused does)."""
         B, G = g_input.shape[0], self.g_latent_space_size
         out = {'g_prior_mus': [self.g0_prior_mus.expand(B, G)], 'g_prior_logvars': [self.g0_prior_logvars.expand(B, G)]}
+        out['_g0_params'] = (self.g0_prior_mus, self.g0_prior_logvars)        # (the unexpanded base Gaussian, for the fused loss)
         if self.mode in ('training', 'autoencoding'):
             out['g_posterior_mus'], out['g_posterior_logvars'] = self.g_posterior(self._pooled_features(g_input))
             out['g_posterior_samples'] = (self.reparameterize(out['g_posterior_mus'], out['g_posterior_logvars'])
@@ -394,7 +396,8 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
 class FlowMixtureNLL(nn.Module):
     """Mixture point NLL on the reference's list outputs (losses.py:88-137), reduced by the fused HIP kernel."""
 
-    def forward(self, output_decoder, mixture_weights_logits):
+    def per_shape(self, output_decoder, mixture_weights_logits):
+        """-> (B,) NLL of every shape (its mean is the reference's scalar)."""
         z = torch.stack([o['p_prior_samples'][0] for o in output_decoder])
         # the batched training decode attaches the stack's own log-det (= sum of the list's flow entries, same values)
         def flow_logdet(o):
@@ -406,7 +409,10 @@ class FlowMixtureNLL(nn.Module):
         logdet = torch.stack([flow_logdet(o) for o in output_decoder])
         mu0 = torch.stack([o['p_prior_mus'][0][:, :, 0] for o in output_decoder])
         lv0 = torch.stack([o['p_prior_logvars'][0][:, :, 0] for o in output_decoder])
-        return flow_mixture_nll(z, logdet, mu0, lv0, mixture_weights_logits)[0]
+        return flow_mixture_nll(z, logdet, mu0, lv0, mixture_weights_logits)[1]
+
+    def forward(self, output_decoder, mixture_weights_logits):
+        return self.per_shape(output_decoder, mixture_weights_logits).mean()
 
 
 class Flow_Mixture_Loss(nn.Module):
@@ -418,16 +424,34 @@ class Flow_Mixture_Loss(nn.Module):
         self.n_components = kwargs.get('n_components')
         self.PNLL, self.GNLL, self.GENT = FlowMixtureNLL(), GaussianFlowNLL(), GaussianEntropy()
 
-    def _combine(self, pnll, output_prior):
+    def _combine(self, nll, output_prior):
+        """nll: (B,) per-shape point NLL (or its mean: the three terms are then combined with torch ops)."""
+        fused = self._combine_fused(nll, output_prior) if nll.dim() == 1 else None
+        if fused is not None:
+            return fused
+        pnll = nll.mean() if nll.dim() == 1 else nll
         gnll = self.GNLL(output_prior['g_prior_samples'], output_prior['g_prior_mus'], output_prior['g_prior_logvars'],
                          output_prior.get('_g_prior_logvars_stacked'))
         gent = self.GENT(output_prior['g_posterior_logvars'])
         return self.pnll_weight * pnll + self.gnll_weight * gnll - self.gent_weight * gent, pnll, gnll, gent
 
+    def _combine_fused(self, nll, output_prior):
+        """All four values in one launch (prior.LatentLossFn) when the prior flow handed its logvars over as one tensor."""
+        flow_lv, g0 = output_prior.get('_g_prior_logvars_stacked'), output_prior.get('_g0_params')
+        post_lv, z = output_prior.get('g_posterior_logvars'), output_prior['g_prior_samples'][0]
+        if flow_lv is None or g0 is None or post_lv is None or os.environ.get('GWTF_NO_FUSED_LATENT_LOSS') == '1':
+            return None
+        ts = (nll, z, g0[0], g0[1], flow_lv, post_lv)
+        if not all(t.is_cuda and t.dtype == torch.float32 for t in ts) or z.dim() != 2:
+            return None
+        from .prior import LatentLossFn
+        vals = LatentLossFn.apply(nll.contiguous(), z.contiguous(), g0[0].reshape(-1), g0[1].reshape(-1), flow_lv.contiguous(),
+                                  post_lv.contiguous(), float(self.pnll_weight), float(self.gnll_weight), float(self.gent_weight))
+        return vals[0], vals[1], vals[2], vals[3]
+
     def forward(self, output_prior, output_decoder, mixture_weights_logits):
-        return self._combine(self.PNLL(output_decoder, mixture_weights_logits), output_prior)
+        return self._combine(self.PNLL.per_shape(output_decoder, mixture_weights_logits), output_prior)
 
     def fused(self, output_prior, dec):
         """Same four values from ``Flow_Mixture_Model.forward_fused``'s outputs."""
-        pnll = flow_mixture_nll(dec['z'], dec['logdet'], dec['mu0'], dec['lv0'], dec['logits'])[0]
-        return self._combine(pnll, output_prior)
+        return self._combine(flow_mixture_nll(dec['z'], dec['logdet'], dec['mu0'], dec['lv0'], dec['logits'])[1], output_prior)

@@ -324,6 +324,40 @@ class _PriorFlowFn(torch.autograd.Function):
         return g_g, g_raw, None, None, None, None, None
 
 
+class LatentLossFn(torch.autograd.Function):
+    """(loss, pnll, gnll, gent) of Flow_Mixture_Loss (reference losses.py:159-170) from the per-shape point NLL and the prior's
+    tensors: one HIP launch forward, one backward (csrc/gwtf_latent.hip) in place of ~55 elementwise / reduction launches."""
+
+    @staticmethod
+    def forward(ctx, nll, z, mu0, lv0, flow_lv, post_lv, pw, gw, ew):
+        from . import _lib
+        B, G = z.shape
+        n2 = flow_lv.shape[0]
+        if nll.shape != (B,) or mu0.shape != (G,) or lv0.shape != (G,) or flow_lv.shape != (n2, B, G) or post_lv.shape != (B, G):
+            raise _lib.GwtfError(f'latent loss: shapes {tuple(nll.shape)} {tuple(z.shape)} {tuple(mu0.shape)} {tuple(lv0.shape)} '
+                                 f'{tuple(flow_lv.shape)} {tuple(post_lv.shape)} are not (B,), (B,G), (G,), (G,), (n2,B,G), (B,G)')
+        out = torch.empty(4, device=z.device, dtype=torch.float32)
+        P = _lib._ptr
+        _lib.check(_lib.lib().gwtf_latent_loss_forward(P(nll, 'nll'), P(z, 'z'), P(mu0, 'mu0'), P(lv0, 'lv0'), P(flow_lv, 'flow_lv'),
+                                                       P(post_lv, 'post_lv'), out.data_ptr(), B, G, n2, pw, gw, ew, _lib._stream(z)))
+        ctx.save_for_backward(z, mu0, lv0)
+        ctx.cfg = (B, G, n2, pw, gw, ew)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from . import _lib
+        z, mu0, lv0 = ctx.saved_tensors
+        B, G, n2, pw, gw, ew = ctx.cfg
+        g_out = g_out.contiguous()
+        buf = torch.empty(B + (n2 + 2) * B * G + 2 * G, device=z.device, dtype=torch.float32)
+        g_nll, g_z, g_post, g_flow, g_mu0, g_lv0 = buf.split([B, B * G, B * G, n2 * B * G, G, G])
+        _lib.check(_lib.lib().gwtf_latent_loss_backward(_lib._ptr(g_out, 'g_out'), z.data_ptr(), mu0.data_ptr(), lv0.data_ptr(),
+                                                        g_nll.data_ptr(), g_z.data_ptr(), g_mu0.data_ptr(), g_lv0.data_ptr(),
+                                                        g_flow.data_ptr(), g_post.data_ptr(), B, G, n2, pw, gw, ew, _lib._stream(z)))
+        return g_nll, g_z.view(B, G), g_mu0, g_lv0, g_flow.view(n2, B, G), g_post.view(B, G), None, None, None
+
+
 class GaussianFlowNLL(nn.Module):
     """reference losses.py:24-33: 0.5 * (sum(sum_j logvars_j + (z - mu0)^2 / exp(logvar0)) / B + G log 2 pi)."""
 

@@ -140,6 +140,16 @@ int gwtf_pack_weights_exact(const float* raw, const float* packed_film /*eval pa
 int gwtf_stack_forward_exact(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps,
                              float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f, int pattern0,
                              float eps, int mode, size_t p_stride_k, size_t out_stride_k, int only_flagged, int tune, void* stream);
+/* Latent-space loss terms of the training step and their combination with the point NLL (reference lib/networks/losses.py:24-33
+ * GaussianFlowNLL, :36-41 GaussianEntropy, :159-170 Flow_Mixture_Loss.forward), one launch each way (csrc/gwtf_latent.hip):
+ *   nll [B] per-shape point NLL (gwtf_mixture_nll); z [B][G] = g_prior_samples[0]; mu0, lv0 [G] = the base Gaussian of the prior flow;
+ *   flow_lv [n2][B][G] = the prior flow's stacked logvars (g_prior_logvars[1:]); post_lv [B][G] = g_posterior_logvars
+ *   out4 = {loss = pw pnll + gw gnll - ew gent, pnll, gnll, gent}.   backward: g_out4 = upstream of the four outputs. */
+int gwtf_latent_loss_forward(const float* nll, const float* z, const float* mu0, const float* lv0, const float* flow_lv,
+                             const float* post_lv, float* out4, int B, int G, int n2, float pw, float gw, float ew, void* stream);
+int gwtf_latent_loss_backward(const float* g_out4, const float* z, const float* mu0, const float* lv0, float* g_nll, float* g_z,
+                              float* g_mu0, float* g_lv0, float* g_flow_lv, float* g_post_lv, int B, int G, int n2, float pw, float gw,
+                              float ew, void* stream);
 /* Tile plan of a forward launch (what stack_dispatch decides; diagnostic + tests): out[0] = points per wavefront of the main
  * launch, out[1] = its workgroups, out[2] = points per wavefront of the tail launch (0: none), out[3] = its workgroups.
  * The choice minimises resident rounds x the cost of a round of that tile (calibrated, csrc/gwtf_stack.hip tile_cost). */
