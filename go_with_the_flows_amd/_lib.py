@@ -39,7 +39,8 @@ _SIGNATURES = {
     'gwtf_pack_weights_exact': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
     'gwtf_stack_forward_exact': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
                                  [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_latent_loss_forward': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [_c_fp]),
+    'gwtf_latent_loss_workspace_floats': (ctypes.c_int, [ctypes.c_int] * 2),
+    'gwtf_latent_loss_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [_c_fp]),
     'gwtf_latent_loss_backward': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [_c_fp]),
     'gwtf_stack_plan': (ctypes.c_int, [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 5 + [ctypes.POINTER(ctypes.c_int)]),
     'gwtf_train_moments': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),

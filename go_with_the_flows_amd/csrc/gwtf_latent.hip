@@ -1,4 +1,4 @@
-// gwtf_latent.hip -- the latent-space loss terms of the training step and their combination with the point NLL, one launch forward and
+// gwtf_latent.hip -- the latent-space loss terms of the training step and their combination with the point NLL, two small launches forward and
 // one backward (reference lib/networks/losses.py:24-33 GaussianFlowNLL, :36-41 GaussianEntropy, :159-170 Flow_Mixture_Loss.forward):
 //     gnll = 0.5 ( sum_{b,j} [ lv0_j + sum_l flow_lv[l][b][j] + (z_bj - mu0_j)^2 / exp(lv0_j) ] / B + G log 2 pi )
 //     gent = 0.5 ( G (1 + log 2 pi) + sum_{b,j} post_lv_bj / B )
@@ -10,7 +10,7 @@
 
 namespace {
 
-constexpr int kThreads = 1024;
+constexpr int kThreads = 256;
 
 __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
 #pragma unroll
@@ -23,21 +23,44 @@ __device__ __forceinline__ float block_sum(float v, float* red, int tid) {
   return s;
 }
 
-// out[4] = {loss, pnll, gnll, gent}; one workgroup (the whole input is a few thousand elements; a second stage would cost a launch)
-__global__ __launch_bounds__(kThreads) void latent_fwd_kernel(const float* __restrict__ nll, const float* __restrict__ z,
-                                                              const float* __restrict__ mu0, const float* __restrict__ lv0,
-                                                              const float* __restrict__ flow_lv, const float* __restrict__ post_lv,
-                                                              float* __restrict__ out, int B, int G, int n2, float pw, float gw, float ew) {
+// stage 1: one element per thread (the n2 flow_lv loads of a thread are independent and coalesced across the wave);
+// part[blk] = {sum of the gnll integrand, sum of post_lv} of the block's 256 elements
+__global__ __launch_bounds__(kThreads) void latent_part_kernel(const float* __restrict__ z, const float* __restrict__ mu0,
+                                                               const float* __restrict__ lv0, const float* __restrict__ flow_lv,
+                                                               const float* __restrict__ post_lv, float2* __restrict__ part, int B,
+                                                               int G, int n2) {
   __shared__ float red[kThreads / 64];
-  const int tid = threadIdx.x, n = B * G;
-  float sg = 0.f, se = 0.f, sp = 0.f;
-  for (int e = tid; e < n; e += kThreads) {
+  const int tid = threadIdx.x, n = B * G, e = blockIdx.x * kThreads + tid;
+  float sg = 0.f, se = 0.f;
+  if (e < n) {
     const int j = e % G;
     const float d = z[e] - mu0[j], l0 = lv0[j];
-    float s = l0 + d * d * __expf(-l0);
-    for (int l = 0; l < n2; ++l) s += flow_lv[(size_t)l * n + e];
-    sg += s;
-    se += post_lv[e];
+    float s0 = 0.f, s1 = 0.f;
+    int l = 0;
+    for (; l + 1 < n2; l += 2) {
+      s0 += flow_lv[(size_t)l * n + e];
+      s1 += flow_lv[(size_t)(l + 1) * n + e];
+    }
+    if (l < n2) s0 += flow_lv[(size_t)l * n + e];
+    sg = l0 + d * d * __expf(-l0) + (s0 + s1);
+    se = post_lv[e];
+  }
+  sg = block_sum(sg, red, tid);
+  se = block_sum(se, red, tid);
+  if (tid == 0) part[blockIdx.x] = make_float2(sg, se);
+}
+
+// stage 2 (one workgroup): the partials in block order + the per-shape point NLL -> out[4] = {loss, pnll, gnll, gent}
+__global__ __launch_bounds__(kThreads) void latent_finish_kernel(const float* __restrict__ nll, const float2* __restrict__ part,
+                                                                 float* __restrict__ out, int B, int G, int nb, float pw, float gw,
+                                                                 float ew) {
+  __shared__ float red[kThreads / 64];
+  const int tid = threadIdx.x;
+  float sg = 0.f, se = 0.f, sp = 0.f;
+  for (int i = tid; i < nb; i += kThreads) {
+    const float2 v = part[i];
+    sg += v.x;
+    se += v.y;
   }
   for (int b = tid; b < B; b += kThreads) sp += nll[b];
   sg = block_sum(sg, red, tid);
@@ -90,12 +113,17 @@ __global__ __launch_bounds__(256) void latent_bwd_kernel(const float* __restrict
 
 }  // namespace
 
+extern "C" int gwtf_latent_loss_workspace_floats(int B, int G) { return 2 * ((B * G + kThreads - 1) / kThreads); }
+
 extern "C" int gwtf_latent_loss_forward(const float* nll, const float* z, const float* mu0, const float* lv0, const float* flow_lv,
-                                        const float* post_lv, float* out4, int B, int G, int n2, float pw, float gw, float ew,
-                                        void* stream) {
-  if (!nll || !z || !mu0 || !lv0 || !flow_lv || !post_lv || !out4 || B <= 0 || G <= 0 || n2 <= 0) return GWTF_E_BADARG;
-  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, nll, z, mu0, lv0, flow_lv, post_lv, out4, B, G,
-                     n2, pw, gw, ew);
+                                        const float* post_lv, float* workspace, float* out4, int B, int G, int n2, float pw, float gw,
+                                        float ew, void* stream) {
+  if (!nll || !z || !mu0 || !lv0 || !flow_lv || !post_lv || !workspace || !out4 || B <= 0 || G <= 0 || n2 <= 0) return GWTF_E_BADARG;
+  const int nb = (B * G + kThreads - 1) / kThreads;
+  hipLaunchKernelGGL(latent_part_kernel, dim3(nb), dim3(kThreads), 0, (hipStream_t)stream, z, mu0, lv0, flow_lv, post_lv,
+                     (float2*)workspace, B, G, n2);
+  hipLaunchKernelGGL(latent_finish_kernel, dim3(1), dim3(kThreads), 0, (hipStream_t)stream, nll, (const float2*)workspace, out4, B, G,
+                     nb, pw, gw, ew);
   return (int)hipGetLastError();
 }
 

@@ -336,10 +336,13 @@ class LatentLossFn(torch.autograd.Function):
         if nll.shape != (B,) or mu0.shape != (G,) or lv0.shape != (G,) or flow_lv.shape != (n2, B, G) or post_lv.shape != (B, G):
             raise _lib.GwtfError(f'latent loss: shapes {tuple(nll.shape)} {tuple(z.shape)} {tuple(mu0.shape)} {tuple(lv0.shape)} '
                                  f'{tuple(flow_lv.shape)} {tuple(post_lv.shape)} are not (B,), (B,G), (G,), (G,), (n2,B,G), (B,G)')
-        out = torch.empty(4, device=z.device, dtype=torch.float32)
-        P = _lib._ptr
-        _lib.check(_lib.lib().gwtf_latent_loss_forward(P(nll, 'nll'), P(z, 'z'), P(mu0, 'mu0'), P(lv0, 'lv0'), P(flow_lv, 'flow_lv'),
-                                                       P(post_lv, 'post_lv'), out.data_ptr(), B, G, n2, pw, gw, ew, _lib._stream(z)))
+        L, P = _lib.lib(), _lib._ptr
+        ws = L.gwtf_latent_loss_workspace_floats(B, G)
+        buf = torch.empty(ws + 4, device=z.device, dtype=torch.float32)
+        out = buf[ws:]
+        _lib.check(L.gwtf_latent_loss_forward(P(nll, 'nll'), P(z, 'z'), P(mu0, 'mu0'), P(lv0, 'lv0'), P(flow_lv, 'flow_lv'),
+                                              P(post_lv, 'post_lv'), buf.data_ptr(), out.data_ptr(), B, G, n2, pw, gw, ew,
+                                              _lib._stream(z)))
         ctx.save_for_backward(z, mu0, lv0)
         ctx.cfg = (B, G, n2, pw, gw, ew)
         return out

@@ -144,9 +144,11 @@ int gwtf_stack_forward_exact(const float* p, const float* packed_x, const float*
  * GaussianFlowNLL, :36-41 GaussianEntropy, :159-170 Flow_Mixture_Loss.forward), one launch each way (csrc/gwtf_latent.hip):
  *   nll [B] per-shape point NLL (gwtf_mixture_nll); z [B][G] = g_prior_samples[0]; mu0, lv0 [G] = the base Gaussian of the prior flow;
  *   flow_lv [n2][B][G] = the prior flow's stacked logvars (g_prior_logvars[1:]); post_lv [B][G] = g_posterior_logvars
- *   out4 = {loss = pw pnll + gw gnll - ew gent, pnll, gnll, gent}.   backward: g_out4 = upstream of the four outputs. */
+ *   workspace: gwtf_latent_loss_workspace_floats(B, G) floats.  out4 = {loss = pw pnll + gw gnll - ew gent, pnll, gnll, gent}.   backward: g_out4 = upstream of the four outputs. */
+int gwtf_latent_loss_workspace_floats(int B, int G);       /* device scratch of the forward (block partials; 8-byte aligned) */
 int gwtf_latent_loss_forward(const float* nll, const float* z, const float* mu0, const float* lv0, const float* flow_lv,
-                             const float* post_lv, float* out4, int B, int G, int n2, float pw, float gw, float ew, void* stream);
+                             const float* post_lv, float* workspace, float* out4, int B, int G, int n2, float pw, float gw, float ew,
+                             void* stream);
 int gwtf_latent_loss_backward(const float* g_out4, const float* z, const float* mu0, const float* lv0, float* g_nll, float* g_z,
                               float* g_mu0, float* g_lv0, float* g_flow_lv, float* g_post_lv, int B, int G, int n2, float pw, float gw,
                               float ew, void* stream);
