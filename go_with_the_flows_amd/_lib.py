@@ -10,7 +10,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('GWTF_LIB') or os.path.join(_HERE, 'libgwtf_hip.so')      # GWTF_LIB: an A/B build (tools/ab_build.sh)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 MODE_DIRECT, MODE_INVERSE = 0, 1
 STAT_REPLICAS = 64   # GWTF_STAT_REPLICAS in csrc/gwtf_layout.h
@@ -89,7 +89,7 @@ _SIGNATURES = {
     'gwtf_enc_train_forward': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 9 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_pool': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_pack_matrix': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
-    'gwtf_enc_train_top_scatter': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_top_scatter': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_backward_top': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_top': (ctypes.c_int, [_c_fp] * 7 + [ctypes.c_int, _c_fp]),
     'gwtf_enc_train_bwd_consts': (ctypes.c_int, [_c_fp, ctypes.c_int, ctypes.c_double] + [_c_fp] * 5 + [_c_fp]),
@@ -97,6 +97,11 @@ _SIGNATURES = {
     'gwtf_enc_train_dw_partial_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'gwtf_enc_train_dw': (ctypes.c_int, [ctypes.c_int] + [_c_fp] * 7 + [ctypes.c_int, ctypes.c_int, _c_fp]),
     'gwtf_enc_train_dw3': (ctypes.c_int, [_c_fp] * 9 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_stat_compact': (ctypes.c_int, [_c_fp, _c_fp, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_mform_workspace_floats': (ctypes.c_size_t, [ctypes.c_int]),
+    'gwtf_enc_train_mform': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_dw3_finish': (ctypes.c_int, [_c_fp] * 6 + [ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_enc_train_dw0_finish': (ctypes.c_int, [_c_fp] * 5 + [ctypes.c_int, _c_fp]),
     'gwtf_prior_raw_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),
     'gwtf_prior_raw_offset': (ctypes.c_size_t, [ctypes.c_int] * 4),
     'gwtf_prior_workspace_floats': (ctypes.c_size_t, [ctypes.c_int] * 3),

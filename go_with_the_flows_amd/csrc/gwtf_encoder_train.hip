@@ -485,7 +485,8 @@ __global__ __launch_bounds__(256) void enc_top_kernel(const float* __restrict__ 
 // Channels are visited in ascending order: deterministic sums.
 // Two kernels: the row tables (this one: per shape the offsets [C + 1] and the channel list [C] of its rows), then one
 // wavefront per row for the sums (enc_top_rows_kernel).
-__global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __restrict__ coef, const int* __restrict__ amax,
+__global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __restrict__ coef, const float* __restrict__ scale,
+                                                              const int* __restrict__ amax,
                                                               int* __restrict__ slot_of, int* __restrict__ row_off,
                                                               int* __restrict__ row_list, int N, int C) {
   extern __shared__ int dyn[];                 // [N] row of a point | -1
@@ -498,7 +499,7 @@ __global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __res
   for (int c = tid; c < C; c += 256) {
     const int am = amax[(size_t)b * C + c];
     s_am[c] = min(max(am, 0), N - 1);           // defensive: the table below is indexed with it
-    s_cf[c] = coef[(size_t)b * C + c];
+    s_cf[c] = coef[(size_t)b * C + c] * (scale ? scale[c] : 1.0f);
   }
   __syncthreads();
   for (int c = tid; c < C; c += 256)
@@ -587,7 +588,8 @@ __global__ __launch_bounds__(256) void enc_top_scatter_kernel(const float* __res
 }
 
 // extra[b][r][:] = sum over the row's channels (ascending) of coef[b][c] W_3[c][:]; one wavefront per (shape, row), a lane = 4 columns
-__global__ __launch_bounds__(256) void enc_top_rows_kernel(const float* __restrict__ coef, const int* __restrict__ row_off,
+__global__ __launch_bounds__(256) void enc_top_rows_kernel(const float* __restrict__ coef, const float* __restrict__ scale,
+                                                           const int* __restrict__ row_off,
                                                            const int* __restrict__ row_list, const float* __restrict__ W3,
                                                            float* __restrict__ extra, int B, int C, int CP) {
   const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -600,7 +602,7 @@ __global__ __launch_bounds__(256) void enc_top_rows_kernel(const float* __restri
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = o; k < end; ++k) {
       const int c = row_list[(size_t)b * C + k];
-      const float g = coef[(size_t)b * C + c];
+      const float g = coef[(size_t)b * C + c] * (scale ? scale[c] : 1.0f);
       const float4 wv = *reinterpret_cast<const float4*>(&W3[(size_t)c * CP + j]);
       a.x = fmaf(g, wv.x, a.x); a.y = fmaf(g, wv.y, a.y); a.z = fmaf(g, wv.z, a.z); a.w = fmaf(g, wv.w, a.w);
     }
@@ -1282,17 +1284,19 @@ extern "C" int gwtf_enc_train_pool(const unsigned long long* kmax, const unsigne
   return (int)hipGetLastError();
 }
 
-extern "C" int gwtf_enc_train_top_scatter(const float* coef, const int* amax, const float* W3, float* extra, int* slot_of,
-                                          int* tables, int B, int N, void* stream) {
+extern "C" int gwtf_enc_train_top_scatter(const float* coef, const float* scale, const int* amax, const float* W3, float* extra,
+                                          int* slot_of, int* tables, int B, int N, void* stream) {
   if (!coef || !amax || !W3 || !extra || !slot_of || !tables || B <= 0 || N <= 0 || (size_t)N * sizeof(int) > 48 * 1024)
     return GWTF_E_BADARG;
   const int C = kC[4];
   int* row_off = tables;                          // [B][C + 2]
   int* row_list = tables + (size_t)B * (C + 2);   // [B][C]
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(enc_top_scatter_kernel, dim3(B), dim3(256), (size_t)N * sizeof(int), st, coef, amax, slot_of, row_off, row_list,
+  hipLaunchKernelGGL(enc_top_scatter_kernel, dim3(B), dim3(256), (size_t)N * sizeof(int), st, coef, scale, amax, slot_of, row_off,
+                     row_list,
                      N, C);
-  hipLaunchKernelGGL(enc_top_rows_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, coef, row_off, row_list, W3, extra, B, C, kC[3]);
+  hipLaunchKernelGGL(enc_top_rows_kernel, dim3((B * C + 3) / 4), dim3(256), 0, st, coef, scale, row_off, row_list, W3, extra, B, C,
+                     kC[3]);
   return (int)hipGetLastError();
 }
 

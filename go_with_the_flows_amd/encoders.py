@@ -64,10 +64,20 @@ class _EncoderTrainFn(torch.autograd.Function):
                 _run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
             return t
 
+        def compact(slab):
+            """sum of the R replicas of a statistic slab (R, ...) in one small launch (a torch sum over 64 rows takes 7 us)"""
+            out = torch.empty(slab.shape[1:], **f32)
+            check(L.gwtf_stat_compact(P(slab), P(out), slab.shape[0], out.numel(), st))
+            return out
+
         with torch.cuda.device(dev):
-            mom = torch.zeros(R, 12, **f32)
+            # every zero-initialised accumulator of the forward pass from ONE fill: {coordinate moments, layer sums, maxima, keys}
+            sizes = [R * 12] + [R * 2 * C[l + 1] for l in (1, 2, 3)] + [4, 2 * (2 * B * C[4])]
+            zero = torch.zeros(sum(sizes), **f32).split(sizes)
+            mom, sums_l, ymax = zero[0].view(R, 12), {l: zero[l].view(R, 2, C[l + 1]) for l in (1, 2, 3)}, zero[4]
+            keys = zero[5].view(torch.int64).view(2, B, C[4])                    # arg-max / arg-min keys of y_3 (never stored)
             check(L.gwtf_enc_train_xmoments(P(x), P(mom), B, N, st))
-            mom_local = mom.sum(0)
+            mom_local = compact(mom)
             aff = [torch.empty(4 * C[l + 1], **f32) for l in range(4)]
             table0 = torch.empty(4 * C[1], **f32)
             check(L.gwtf_enc_train_fold0(P(over_ranks(mom_local)), n_total, P(Ws[0]), P(gam[0]), P(bet[0]), P(rm[0]), P(rv[0]),
@@ -79,26 +89,25 @@ class _EncoderTrainFn(torch.autograd.Function):
                 units_b.append(torch.empty(n_units, **f32))
             check(L.gwtf_enc_train_pack_all(P(Ws[1]), P(Ws[2]), P(Ws[3]), P(units_f[1]), P(units_b[1]), P(units_f[2]), P(units_b[2]),
                                             P(units_f[3]), P(units_b[3]), st))       # one launch for the six fragment images
-            ys, ymax = [None], torch.zeros(4, **f32)
-            keys = torch.zeros(2, B, C[4], device=dev, dtype=torch.int64)        # arg-max / arg-min keys of y_3 (never stored)
+            ys = [None]
             for l in (1, 2, 3):
                 # y_1, y_2 (and the backward's dA arrays) in tiles of 32 points x all channels: include/gwtf.h gwtf_enc_train_act_floats
                 y = torch.empty(L.gwtf_enc_train_act_floats(B, C[l + 1], N), **f32) if l < 3 else None
-                sums = torch.zeros(R, 2, C[l + 1], **f32)
+                sums = sums_l[l]
                 check(L.gwtf_enc_train_forward(l, P(x if l == 1 else ys[l - 1]), P(table0 if l == 1 else aff[l - 1]),
                                                P(units_f[l]), P(y), P(sums), P(ymax[l:l + 1]),
                                                keys[0].data_ptr() if l == 3 else 0, keys[1].data_ptr() if l == 3 else 0,
                                                P(gam[3]) if l == 3 else 0, B, N, st))
-                check(L.gwtf_enc_train_fold(P(over_ranks(sums.sum(0))), l, n_total, P(gam[l]), P(bet[l]), P(rm[l]), P(rv[l]),
+                check(L.gwtf_enc_train_fold(P(over_ranks(compact(sums))), l, n_total, P(gam[l]), P(bet[l]), P(rm[l]), P(rv[l]),
                                             float(bns[l].momentum), P(aff[l]), P(aff[l - 1]), st))
                 ys.append(y)
             pooled = torch.empty(B, C[4], **f32)
             amax = torch.empty(B, C[4], device=dev, dtype=torch.int32)
             ystar = torch.empty(B, C[4], **f32)
             check(L.gwtf_enc_train_pool(keys[0].data_ptr(), keys[1].data_ptr(), P(aff[3]), P(pooled), amax.data_ptr(), P(ystar), B, N, st))
-            for bn in bns:
-                if bn.track_running_stats and bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
+            counters = [bn.num_batches_tracked for bn in bns if bn.track_running_stats and bn.num_batches_tracked is not None]
+            if counters:
+                torch._foreach_add_(counters, 1)                                 # (one launch for the four counters)
         ctx.save_for_backward(x, pooled, *params)
         ctx.buf = dict(ys=ys, aff=aff, table0=table0, units_b=units_b, ymax=ymax, amax=amax, ystar=ystar,
                        mom_local=mom_local, Ws=Ws, gam=gam)
@@ -126,52 +135,59 @@ class _EncoderTrainFn(torch.autograd.Function):
                 _run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
             return t
 
+        def compact(slab):
+            out = torch.empty(slab.shape[1:], **f32)
+            check(L.gwtf_stat_compact(P(slab), P(out), slab.shape[0], out.numel(), st))
+            return out
+
         grads = [None] * 12
         with torch.cuda.device(dev):
             g_pooled = g_pooled.contiguous().float()
             gp = torch.empty(B, C[4], **f32)
             red = torch.empty(2, C[4], **f32)
-            gmax = torch.zeros(4, **f32)
+            # every zero-initialised accumulator of the backward pass from ONE fill
+            sizes = [4, R * 3 * C[3], R * 2 * C[2], R * 5 * C[1]]
+            zero = torch.zeros(sum(sizes), **f32).split(sizes)
+            gmax, sums_l = zero[0], {3: zero[1].view(R, 3, C[3]), 2: zero[2].view(R, 2, C[2]), 1: zero[3].view(R, 5, C[1])}
             check(L.gwtf_enc_train_top(P(g_pooled), P(pooled), P(b['ystar']), P(aff[3]), P(gp), P(red), P(gmax[3:4]), B, st))
             partials = torch.empty(max(L.gwtf_enc_train_dw_partial_floats(l, B, N) for l in (1, 2, 3)), **f32)
             # ---- layer 3 in the M form (csrc/gwtf_encoder_train.hip): dy_3 = s gm_3 + Q y_3 + R with y_3 = W_3 a_2 ----
             grads[10], grads[11] = red[1], red[0]            # (views of `red`: nothing writes it again; a clone each was 8 launches per step)
             bconst = torch.empty(3 * C[4] + 4, **f32)
             check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), 3, n_total, P(gam[3]), P(aff[3]), 0, 0, P(bconst), st))
-            s3, q3, r3 = (bconst[i * C[4]:(i + 1) * C[4]] for i in range(3))
             W3 = Ws[3]
-            # M = W3^T diag(q3) W3 (256 x 256, symmetric).  As ONE product the library picks a single 256 x 256 macro tile -- one
-            # workgroup on one compute unit, 122 us for 67 MFLOP; cut along the 512-long contraction into 16 batched products it is
-            # 16 workgroups + one small sum (measured inside the train step: ~15 us).
-            W3q = (W3 * q3[:, None]).view(16, C[4] // 16, C[3])
-            M = torch.bmm(W3q.transpose(1, 2), W3.reshape(16, C[4] // 16, C[3])).sum(0)
-            k = 8.0 - torch.floor(torch.log2(M.abs().max().clamp_min(1e-37)))      # power-of-two operand scale, on the device
+            # M = W3^T diag(q3) W3 (256 x 256), its power-of-two operand scale, the fragment images of M 2^k and
+            # mconst = {W3^T r3, 2^-k}: two launches (csrc/gwtf_encoder_glue.hip; as torch operators: a batched library GEMM, a
+            # GEMV and 14 element-wise / reduction launches, ~85 us)
             units_m = torch.empty(L.gwtf_enc_train_units_floats(3) // 2, **f32)
-            check(L.gwtf_enc_train_pack_matrix(P((M * torch.exp2(k)).contiguous()), P(units_m), C[3], C[3], st))
-            mconst = torch.cat([W3.t() @ r3, torch.exp2(-k).reshape(1), torch.zeros(3, **f32)])
+            mconst = torch.empty(C[3] + 4, **f32)
+            mws = torch.empty(L.gwtf_enc_train_mform_workspace_floats(C[3]), **f32)
+            check(L.gwtf_enc_train_mform(P(W3), P(bconst), P(mws), P(units_m), P(mconst), C[3], C[4], st))
             extra = torch.empty(B, C[4], C[3], **f32)
             slot_of = torch.empty(B, N, device=dev, dtype=torch.int32)
             tables = torch.empty(B * (2 * C[4] + 2), device=dev, dtype=torch.int32)
-            check(L.gwtf_enc_train_top_scatter(P((gp * s3[None, :]).contiguous()), b['amax'].data_ptr(), P(W3), P(extra),
+            check(L.gwtf_enc_train_top_scatter(P(gp), bconst.data_ptr(), b['amax'].data_ptr(), P(W3), P(extra),      # coef = gp s_3
                                                slot_of.data_ptr(), tables.data_ptr(), B, N, st))
             up = torch.empty(L.gwtf_enc_train_act_floats(B, C[3], N), **f32)       # masked dL/da_2 (tiled like y_2)
-            sums = torch.zeros(R, 3, C[3], **f32)
+            sums = sums_l[3]
             a2rows = torch.empty(B, C[4], C[3], **f32)                             # a_2 at the arg-max points, point-major
             check(L.gwtf_enc_train_backward_top(P(ys[2]), P(aff[2]), P(units_m), P(mconst), P(extra), slot_of.data_ptr(), P(up),
                                                 P(sums), P(gmax[2:3]), P(a2rows), B, N, st))
-            red = sums.sum(0)
-            # dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2  (gwtf_enc_train_dw3)
+            red = compact(sums)
+            # dW_3 = s (.) S + Q (.) (W_3 G_2) + R (x) sum_p a_2  (gwtf_enc_train_dw3, gwtf_enc_train_dw3_finish)
             gram, S = torch.empty(C[3], C[3], **f32), torch.empty(C[4], C[3], **f32)
             check(L.gwtf_enc_train_dw3(P(gp), b['amax'].data_ptr(), slot_of.data_ptr(), P(a2rows), P(ys[2]), P(aff[2]), P(partials), P(gram),
                                        P(S), B, N, st))
-            grads[9] = (s3[:, None] * S + q3[:, None] * (W3 @ gram) + r3[:, None] * red[2][None, :]).view_as(params[9])
+            dW3 = torch.empty(C[4], C[3], **f32)
+            check(L.gwtf_enc_train_dw3_finish(P(bconst), P(S), P(W3), P(gram), red[2].data_ptr(), P(dW3), C[3], C[4], st))
+            grads[9] = dW3.view_as(params[9])
             for l in (2, 1):
                 grads[3 * l + 1], grads[3 * l + 2] = red[1], red[0]                          # bn.weight, bn.bias of layer l
                 bconst = torch.empty(3 * C[l + 1] + 4, **f32)
                 check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), l, n_total, P(gam[l]), P(aff[l]),
                                                   P(gmax[l:l + 1]), P(b['ymax'][l:l + 1]), P(bconst), st))
                 dA = torch.empty(L.gwtf_enc_train_act_floats(B, C[l], N), **f32) if l > 1 else None
-                sums = torch.zeros(R, 5 if l == 1 else 2, C[l], **f32)
+                sums = sums_l[l]
                 check(L.gwtf_enc_train_backward(l, P(ys[l]), P(up), P(bconst), P(b['units_b'][l]), P(x if l == 1 else ys[l - 1]),
                                                 P(aff[l - 1]), P(Ws[0] if l == 1 else None), P(dA), P(sums),
                                                 P(gmax[l - 1:l]) if l > 1 else 0, B, N, st))
@@ -179,17 +195,15 @@ class _EncoderTrainFn(torch.autograd.Function):
                 check(L.gwtf_enc_train_dw(l, P(ys[l]), P(up), P(bconst), P(x if l == 1 else ys[l - 1]),
                                           P(b['table0'] if l == 1 else aff[l - 1]), P(partials), P(dW), B, N, st))
                 grads[3 * l] = dW.view_as(params[3 * l])
-                red = sums.sum(0)
+                red = compact(sums)
                 up = dA
             # layer 0 (3 -> 64): every sum its gradient needs is already there
             grads[1], grads[2] = red[1], red[0]
             bconst = torch.empty(3 * C[1] + 4, **f32)
             check(L.gwtf_enc_train_bwd_consts(P(over_ranks(red[:2].contiguous())), 0, n_total, P(gam[0]), P(aff[0]), 0, 0,
                                               P(bconst), st))
-            s0, q0, r0 = bconst[:C[1]], bconst[C[1]:2 * C[1]], bconst[2 * C[1]:3 * C[1]]
-            m = b['mom_local']
-            mxx = torch.stack([m[3], m[4], m[5], m[4], m[6], m[7], m[5], m[7], m[8]]).view(3, 3)
-            dW0 = s0[:, None] * red[2:5].t() + q0[:, None] * (Ws[0] @ mxx) + r0[:, None] * m[None, :3]
+            dW0 = torch.empty(C[1], 3, **f32)
+            check(L.gwtf_enc_train_dw0_finish(P(bconst), P(red), P(Ws[0]), P(b['mom_local']), P(dW0), C[1], st))
             grads[0] = dW0.view_as(params[0])
         return (None, None, None, *grads)
 

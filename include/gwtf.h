@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define GWTF_ABI_VERSION 5
+#define GWTF_ABI_VERSION 6
 #define GWTF_E_BADARG 10001   /* shape / mode / width outside what the kernels support */
 #define GWTF_E_UNSUPPORTED 10002   /* a layer-width list no kernel instantiation was built for */
 #define GWTF_MODE_DIRECT 0    /* sampling direction  base -> data (reference models.py:202) */
@@ -471,7 +471,7 @@ int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, cons
 /* Top layer: with dy_3 = s gm_3 + Q y_3 + R and y_3 = W_3 a_2,  dL/da_2(p) = M a_2(p) + v + (rows of the arg-max points),
  * M = W_3^T diag(Q) W_3, v = W_3^T R (two small library GEMMs on the caller's side).
  *   gwtf_enc_train_pack_matrix   fragment images of M * 2^k (rows x kdim row-major, here 256 x 256)
- *   gwtf_enc_train_top_scatter   coef [B][512] = s_c gp[b][c] -> slot_of [B][N] (row of a point, or -1) and
+ *   gwtf_enc_train_top_scatter   coef [B][512] (times scale [512] when given: coef = gp, scale = s) -> slot_of [B][N] (row of a point, or -1) and
  *                                extra [B][512][256]: row r of shape b = sum of coef[b][c] W_3[c][:] over the channels whose
  *                                arg-max is that point (only the used rows are written); tables: B (2 * 512 + 2) ints of scratch
  *   gwtf_enc_train_backward_top  dA2 (256 channels, tiled) = (M a_2 + v + extra) masked by a_2 > 0; mconst = v [256] | {2^-k};
@@ -479,8 +479,8 @@ int gwtf_enc_train_bwd_consts(const float* sums, int layer, double n_total, cons
  *                                a2rows [B][512][256] (out): row slot_of[b][n] of shape b = a_2(b, :, n) of every arg-max point n,
  *                                point-major (the kernel has them in registers; other rows are not written) */
 int gwtf_enc_train_pack_matrix(const float* W, float* units, int rows, int kdim, void* stream);
-int gwtf_enc_train_top_scatter(const float* coef, const int* amax, const float* W3, float* extra, int* slot_of, int* tables,
-                               int B, int N, void* stream);
+int gwtf_enc_train_top_scatter(const float* coef, const float* scale, const int* amax, const float* W3, float* extra, int* slot_of,
+                               int* tables, int B, int N, void* stream);
 int gwtf_enc_train_backward_top(const float* y2, const float* aff2, const float* units_m, const float* mconst, const float* extra,
                                 const int* slot_of, float* dA2, float* sums, float* gmax2, float* a2rows, int B, int N, void* stream);
 /* layer = 1, 2: dA_prev (C[layer] channels, tiled) = (W_layer^T dy_layer) masked by a_{layer-1} > 0 (not stored for layer 1), dy from
@@ -501,6 +501,23 @@ int gwtf_enc_train_dw(int layer, const float* y_l, const float* up_g, const floa
  * gwtf_enc_train_backward_top accumulates). */
 int gwtf_enc_train_dw3(const float* gp, const int* amax, const int* slot_of, const float* a2rows, const float* y2, const float* aff2,
                        float* partials, float* gram, float* S, int B, int N, void* stream);
+/* The small dense algebra between those kernels (csrc/gwtf_encoder_glue.hip), a launch or two each instead of chains of library calls:
+ *   gwtf_stat_compact          out [n] = sum of the `replicas` copies of slab [replicas][n], fixed order
+ *   gwtf_enc_train_mform       bconst3 = {s, Q, R} [3][C4] of layer 3 -> units_m = fragment images of M 2^k (M = W_3^T diag(Q) W_3,
+ *                              k = 8 - floor(log2 max|M|)), mconst [C3 + 4] = {W_3^T R, 2^-k, 0, 0, 0}: what gwtf_enc_train_backward_top
+ *                              reads.  workspace: gwtf_enc_train_mform_workspace_floats(C3) floats.  C3 % 32 == 0, C4 % 64 == 0.
+ *   gwtf_enc_train_dw3_finish  dW_3 [C4][C3] = s (.) S + Q (.) (W_3 gram) + R (x) a2sum   (a2sum [C3] = sum_p a_2)
+ *   gwtf_enc_train_dw0_finish  dW_0 [C1][3] = s (.) red5[2:5]^T + Q (.) (W_0 Mxx) + R (x) m[:3]; bconst0 = {s, Q, R} [3][C1] of layer 0,
+ *                              red5 [5][C1] = the compact sums of gwtf_enc_train_backward(layer 1), mom12 = this rank's coordinate
+ *                              moments (gwtf_enc_train_xmoments, compact) */
+int gwtf_stat_compact(const float* slab, float* out, int replicas, int n, void* stream);
+size_t gwtf_enc_train_mform_workspace_floats(int C3);
+int gwtf_enc_train_mform(const float* W3, const float* bconst3, float* workspace, float* units_m, float* mconst, int C3, int C4,
+                         void* stream);
+int gwtf_enc_train_dw3_finish(const float* bconst3, const float* S, const float* W3, const float* gram, const float* a2sum, float* dW3,
+                              int C3, int C4, void* stream);
+int gwtf_enc_train_dw0_finish(const float* bconst0, const float* red5, const float* W0, const float* mom12, float* dW0, int C1,
+                              void* stream);
 
 /* Global prior flow on the shape latent: the whole GlobalRNVPDecoder (lib/networks/decoders.py:7-38; RealNVPFlowCouple /
  * RealNVPFlow, flows.py:163-243) as ONE launch per direction -- forward (the lists the reference returns) and backward
