@@ -595,6 +595,19 @@ def _stat_sum(t):
     run(dist.all_reduce, t, op=dist.ReduceOp.SUM)
 
 
+def _zero_arena(shapes, device):
+    """{name: zero tensor of shapes[name]} carved out of ONE zero-filled allocation (each region starts on a 256-byte boundary)."""
+    offs, total = {}, 0
+    for name, shape in shapes.items():
+        n = 1
+        for d in shape:
+            n *= int(d)
+        offs[name] = (total, n)
+        total += (n + 63) // 64 * 64
+    arena = torch.zeros(total, device=device, dtype=torch.float32)
+    return {name: arena[o:o + n].view(*shapes[name]) for name, (o, n) in offs.items()}
+
+
 class TrainMixtureFn(torch.autograd.Function):
     """out, logdet (K,B,3,N), lists (3,K,C,B,3,N), bn_batch (K,C,2,4,2,f) of K stacks with batch-statistic BatchNorm.
     raw (K, C*R): the stacks' raw arenas; film_raw (B, K*C, 2, 2, FP): raw FiLM {scale a, shift b} of this rank's shapes, zero
@@ -612,17 +625,19 @@ class TrainMixtureFn(torch.autograd.Function):
         FS, PB = L.gwtf_film_out_floats(f), L.gwtf_packed_b_coupling_floats(f)
         R = _lib.STAT_REPLICAS
         new = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
-        zeros = lambda *shape: torch.zeros(*shape, device=dev, dtype=torch.float32)
         film_raw = film_raw.contiguous()
         assert film_raw.shape == (B, K * C, 2, 2, FP), film_raw.shape
+        # the zero-initialised buffers (accumulators of the passes' atomics, the padded W1^T image) from ONE fill
+        shapes = dict(pb=(K * C * PB,), moments=(C + 1, K, R * 16), ystats=(C, K, R * 2 * FP * 2), bn_batch=(K, C, 2, 4, 2, f))
+        zero = _zero_arena(shapes, dev)
         with torch.cuda.device(dev):
             pw, _ = _lib.pack_weights(raw.view(-1), C, f, G, True, pattern0, K=K, stack_only=True)
-            pb = zeros(K * C * PB)
+            pb = zero['pb']
             _lib.check(L.gwtf_pack_w1t(raw.data_ptr(), pb.data_ptr(), K * C, f, G, _lib._stream(p)))
         t = _lib.TrainCtx()
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
         t.eps, t.n_total, t.tune = float(eps), float(n_total), _lib.tune_word()
-        bufs = dict(moments=zeros(C + 1, K, R * 16), ystats=zeros(C, K, R * 2 * FP * 2), bn_batch=zeros(K, C, 2, 4, 2, f),
+        bufs = dict(moments=zero['moments'], ystats=zero['ystats'], bn_batch=zero['bn_batch'],
                     # data parallel: the compact statistic records that are all-reduced and that every consumer then reads
                     mom_c=new(C + 1, K, 16) if sharded else None, ys_c=new(C, K, 2 * FP * 2) if sharded else None,
                     film_rec=new(B, K * C, FS), xbuf=new(2, K, B, 3, N), logdet=new(K, B, 3, N),
@@ -650,7 +665,7 @@ class TrainMixtureFn(torch.autograd.Function):
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_B, step))
                     if step + 1 < C:
                         _stat_sum(mom[step + 1])
-        out = bufs['xbuf'][L.gwtf_mtrain_final_forward_half(C)].clone()
+        out = bufs['xbuf'][L.gwtf_mtrain_final_forward_half(C)]       # (a view: the other half, 12 B per point and component, stays allocated with it)
         # the backward reads the forward statistics again: the compact (all-reduced) records when data parallel, the copies otherwise
         ctx.save_for_backward(p, raw, lists[0], pw, pb, bufs['film_rec'], film_raw,
                               bufs['mom_c' if sharded else 'moments'], bufs['ys_c' if sharded else 'ystats'])
@@ -683,10 +698,12 @@ class TrainMixtureFn(torch.autograd.Function):
         t.K, t.B, t.N, t.C, t.f, t.G, t.pattern0, t.mode = K, B, N, C, f, G, pattern0, _lib._MODES[mode]
         t.eps, t.n_total, t.tune = eps, n_total, _lib.tune_word()
         scratch = new(K, B, 3, N)
+        # (one fill for the accumulators; the two gradients that leave this function keep their own storage)
+        zero = _zero_arena(dict(g_film=(B, K * C, 2, 3, FP), g_sd0=(C, K, R * 2 * 3 * FP), g_bias=(C, K, R * 4), g_mom=(C, K, 16)), dev)
         bufs = dict(g_bufs=new(2, K, B, 3, N),
-                    dw1_ws=new(K * L.gwtf_mtrain_dw1_floats(f, B, N)), g_film=zeros(B, K * C, 2, 3, FP),
-                    g_sd0=zeros(C, K, R * 2 * 3 * FP), g_bias=zeros(C, K, R * 4), g_stats=new(C, K, 2 * 2 * FP),
-                    g_mom=zeros(C, K, 16), g_film_raw=torch.zeros_like(film_raw),
+                    dw1_ws=new(K * L.gwtf_mtrain_dw1_floats(f, B, N)), g_film=zero['g_film'],
+                    g_sd0=zero['g_sd0'], g_bias=zero['g_bias'], g_stats=new(C, K, 2 * 2 * FP),
+                    g_mom=zero['g_mom'], g_film_raw=torch.zeros_like(film_raw),
                     g_raw=torch.zeros_like(raw))
         t.p, t.raw, t.packed_w, t.packed_b = p.data_ptr(), raw.data_ptr(), pw.data_ptr(), pb.data_ptr()
         t.film_raw, t.film_rec = film_raw.data_ptr(), film_rec.data_ptr()
