@@ -84,8 +84,10 @@ class _SiblingGroup:
             return None
         out, logdet, lists, bn_batch = res
         self.stats['batched_rounds'] += 1
-        self.round = rnd = dict(key=key, p=p, g=g, out=out, logdet=logdet, lists=lists, bn_batch=bn_batch,
-                                pending=set(range(self.K)))
+        # (one unbind per round: its backward stacks the K gradients with one launch; a select per call would each materialise a
+        # zero-filled (K, B, 3, N) gradient and add them up)
+        self.round = rnd = dict(key=key, p=p, g=g, out=out.unbind(0), logdet=logdet.unbind(0), lists=lists, bn_batch=bn_batch,
+                                final=0 if mode == 'inverse' else lists[0].shape[1] - 1, pending=set(range(self.K)))
         return self._take(rnd, k)
 
     def _take(self, rnd, k):
@@ -95,6 +97,9 @@ class _SiblingGroup:
         e._last_lists = None
         ps, mus, lvs = rnd['lists']
         res = list(ps[k].unbind(0)), list(mus[k].unbind(0)), list(lvs[k].unbind(0))
+        # the slot of the fully transformed cloud IS the pipeline's output tensor (same kernel, same registers): handing that tensor
+        # out keeps the loss's gradient off the per-slot route, whose backward materialises a (K, C, B, 3, N) gradient per component
+        res[0][rnd['final']] = rnd['out'][k]
         # the pipeline's own log-det of this component rides along on the logvars slots: a consumer that is about to add the C slots
         # up again (models.FlowMixtureNLL on the reference's lists) recognises the complete list and takes the sum that exists
         tag = _SlotSum(rnd['logdet'][k], len(res[2]))

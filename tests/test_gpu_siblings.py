@@ -126,3 +126,16 @@ def test_eval_mode_and_lone_decoders_take_the_plain_path():
     assert a.pc_decoder[0].sibling_group().stats == {'batched_rounds': 0, 'abandoned_rounds': 0, 'single_calls': 0}
     lone = gw.LocalCondRNVPDecoder(L, F, G)
     assert lone.sibling_group() is None
+
+
+@pytest.mark.parametrize('mode', ['inverse', 'direct'])
+def test_final_slot_handed_out_is_the_pipelines_output_bit_for_bit(mode):
+    """decoders._SiblingGroup._take puts the pipeline's `out` tensor into the list slot of the fully transformed cloud (so that the
+    loss's gradient takes the dense route): it must hold exactly the values of the slot it replaces."""
+    m = build()
+    p, g = inputs(3)
+    with torch.no_grad():
+        out, logdet, (ps, mus, lvs), _ = MixtureStack(list(m.pc_decoder)).forward_all_lists(p, g, mode, defer_running_stats=True)
+    final = 0 if mode == 'inverse' else ps.shape[1] - 1
+    assert torch.equal(out, ps[:, final])
+    assert maxabs(logdet.cpu().numpy(), lvs.sum(1).cpu().numpy()) <= 2e-5 * max(1.0, float(logdet.abs().max()))
