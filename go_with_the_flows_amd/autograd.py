@@ -665,7 +665,12 @@ class TrainMixtureFn(torch.autograd.Function):
                     _lib.check(L.gwtf_mtrain_phase(ctypes.addressof(t), _lib.PHASE_FWD_B, step))
                     if step + 1 < C:
                         _stat_sum(mom[step + 1])
-        out = bufs['xbuf'][L.gwtf_mtrain_final_forward_half(C)]       # (a view: the other half, 12 B per point and component, stays allocated with it)
+        # the half of xbuf that holds the final coordinates, as a tensor of its own on the same storage (not a view: consumers that
+        # look for the (K, ...) tensor behind K per-component slices -- models._restack -- find this one); the other half, 12 B per
+        # point and component, stays allocated with it
+        xb = bufs['xbuf']
+        out = torch.empty(0, device=dev, dtype=torch.float32).set_(
+            xb.untyped_storage(), xb.storage_offset() + L.gwtf_mtrain_final_forward_half(C) * K * B * 3 * N, (K, B, 3, N))
         # the backward reads the forward statistics again: the compact (all-reduced) records when data parallel, the copies otherwise
         ctx.save_for_backward(p, raw, lists[0], pw, pb, bufs['film_rec'], film_raw,
                               bufs['mom_c' if sharded else 'moments'], bufs['ys_c' if sharded else 'ystats'])

@@ -12,19 +12,28 @@
 
 namespace {
 
+// 64 outputs x 4 replica slices per workgroup: a thread's loads are independent (all in flight at once), the four slices are added
+// in a fixed order through LDS
+template <int RU>
 __global__ __launch_bounds__(256) void stat_compact_any_kernel(const float* __restrict__ slab, float* __restrict__ out, int R, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int r = 0;
-  for (; r + 3 < R; r += 4) {
-    a0 += slab[(size_t)r * n + i];
-    a1 += slab[(size_t)(r + 1) * n + i];
-    a2 += slab[(size_t)(r + 2) * n + i];
-    a3 += slab[(size_t)(r + 3) * n + i];
+  __shared__ float part[4][64];
+  const int o = threadIdx.x & 63, sl = threadIdx.x >> 6, i = blockIdx.x * 64 + o;
+  float a0 = 0.f, a1 = 0.f;
+  if (i < n) {
+    if constexpr (RU > 0) {             // R == 4 RU: compile-time trip count
+      float v[RU];
+#pragma unroll
+      for (int r = 0; r < RU; ++r) v[r] = slab[(size_t)(sl * RU + r) * n + i];
+#pragma unroll
+      for (int r = 0; r < RU; r += 2) { a0 += v[r]; a1 += r + 1 < RU ? v[r + 1] : 0.f; }
+    } else {
+      const int per = (R + 3) / 4, r0 = sl * per, r1 = min(R, r0 + per);
+      for (int r = r0; r < r1; ++r) a0 += slab[(size_t)r * n + i];
+    }
   }
-  for (; r < R; ++r) a0 += slab[(size_t)r * n + i];
-  out[i] = (a0 + a1) + (a2 + a3);
+  part[sl][o] = a0 + a1;
+  __syncthreads();
+  if (sl == 0 && i < n) out[i] = (part[0][o] + part[1][o]) + (part[2][o] + part[3][o]);
 }
 
 constexpr int kT = 16, kKC = 64;      // output tile edge, contraction chunk
@@ -49,18 +58,24 @@ __device__ __forceinline__ float tile_dot(FA A, FB B, int K, int row0, int col0,
   return acc;
 }
 
-// blocks [0, (C3/16)^2): tiles of M = W^T diag(q) W with the tile's max |M| -> tmax[block]; the last block: mconst[0..C3) = W^T r
+// blocks [0, (C3/16)^2): tiles of M = W^T diag(q) W with the tile's max |M| -> tmax[block]; the last C3/16 blocks: mconst[0..C3) = W^T r
 __global__ __launch_bounds__(256) void enc_mform_kernel(const float* __restrict__ W, const float* __restrict__ q, const float* __restrict__ r,
                                                         float* __restrict__ M, float* __restrict__ tmax, float* __restrict__ mconst,
                                                         int C3, int C4) {
   __shared__ float As[kKC][kT + 1], Bs[kKC][kT + 1];
   __shared__ float red[4];
   const int nt = C3 / kT, tid = threadIdx.x;
-  if ((int)blockIdx.x == nt * nt) {
-    for (int i = tid; i < C3; i += 256) {
-      float a = 0.f;
-      for (int c = 0; c < C4; ++c) a = fmaf(W[(size_t)c * C3 + i], r[c], a);
-      mconst[i] = a;
+  if ((int)blockIdx.x >= nt * nt) {
+    // W^T r for 16 outputs: 16 slices of the contraction side by side, added in slice order
+    const int o = tid % kT, sl = tid / kT, i = kT * ((int)blockIdx.x - nt * nt) + o, per = C4 / 16;
+    float a = 0.f;
+    for (int c = sl * per; c < (sl + 1) * per; ++c) a = fmaf(W[(size_t)c * C3 + i], r[c], a);
+    As[sl][o] = a;
+    __syncthreads();
+    if (sl == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 16; ++k) t += As[k][o];
+      mconst[i] = t;
     }
     return;
   }
@@ -139,7 +154,9 @@ __global__ __launch_bounds__(256) void enc_dw0_finish_kernel(const float* __rest
 
 extern "C" int gwtf_stat_compact(const float* slab, float* out, int replicas, int n, void* stream) {
   if (!slab || !out || replicas <= 0 || n <= 0) return GWTF_E_BADARG;
-  hipLaunchKernelGGL(stat_compact_any_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, out, replicas, n);
+  const dim3 grid((n + 63) / 64), block(256);
+  if (replicas == 64) hipLaunchKernelGGL(stat_compact_any_kernel<16>, grid, block, 0, (hipStream_t)stream, slab, out, replicas, n);
+  else hipLaunchKernelGGL(stat_compact_any_kernel<0>, grid, block, 0, (hipStream_t)stream, slab, out, replicas, n);
   return (int)hipGetLastError();
 }
 
@@ -147,12 +164,12 @@ extern "C" size_t gwtf_enc_train_mform_workspace_floats(int C3) { return (size_t
 
 extern "C" int gwtf_enc_train_mform(const float* W3, const float* bconst3, float* workspace, float* units_m, float* mconst, int C3, int C4,
                                     void* stream) {
-  if (!W3 || !bconst3 || !workspace || !units_m || !mconst || C3 <= 0 || C4 <= 0 || C3 % 32 || C4 % kKC) return GWTF_E_BADARG;
+  if (!W3 || !bconst3 || !workspace || !units_m || !mconst || C3 <= 0 || C4 <= 0 || C3 % 32 || C4 % kKC || C4 % 16) return GWTF_E_BADARG;
   const int nt = C3 / kT;
   float* M = workspace;
   float* tmax = workspace + (size_t)C3 * C3;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(enc_mform_kernel, dim3(nt * nt + 1), dim3(256), 0, st, W3, bconst3 + C4, bconst3 + 2 * C4, M, tmax, mconst, C3, C4);
+  hipLaunchKernelGGL(enc_mform_kernel, dim3(nt * nt + nt), dim3(256), 0, st, W3, bconst3 + C4, bconst3 + 2 * C4, M, tmax, mconst, C3, C4);
   const int total = (C3 / 16) * (C3 / 32) * 2 * 64;
   hipLaunchKernelGGL(enc_mform_pack_kernel, dim3((total + 255) / 256), dim3(256), 0, st, M, tmax, nt * nt, units_m, mconst, C3);
   return (int)hipGetLastError();

@@ -393,12 +393,36 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
         return xp.gather(2, slot_t.unsqueeze(1).expand(S, 3, n))
 
 
+def _restack(tensors):
+    """torch.stack(tensors) -- or, when they are exactly the K slices `base[0], ..., base[K-1]` of one (K, ...) tensor in order (what a
+    batched decode hands out), that tensor itself: no copy forward, no unbind / stack pair backward."""
+    base = tensors[0]._base
+    if (base is not None and base.dim() == tensors[0].dim() + 1 and base.shape[0] == len(tensors) and base.is_contiguous()
+            and base.requires_grad == tensors[0].requires_grad):
+        step = base.stride(0) * base.element_size()
+        if all(t._base is base and t.shape == base.shape[1:] and t.is_contiguous() and t.data_ptr() == base.data_ptr() + k * step
+               for k, t in enumerate(tensors)):
+            return base
+    return torch.stack(tensors)
+
+
+def _first_column(t):
+    """t[:, :, 0] of a (B, P, n) base-Gaussian entry.  The reference builds that entry as `head(g).unsqueeze(2).expand(B, P, n)`
+    (models.py:169-193): when `t` is such a broadcast of a (B, P) tensor, that tensor itself is returned -- same values, and the
+    gradient reaches it directly instead of through a zero-filled (B, P, n) tensor and a sum over its n columns per component."""
+    base = t._base
+    if (base is not None and t.dim() == 3 and base.dim() == 2 and t.stride(2) == 0 and base.shape == t.shape[:2]
+            and base.stride() == t.stride()[:2] and base.data_ptr() == t.data_ptr()):
+        return base
+    return t[:, :, 0]
+
+
 class FlowMixtureNLL(nn.Module):
     """Mixture point NLL on the reference's list outputs (losses.py:88-137), reduced by the fused HIP kernel."""
 
     def per_shape(self, output_decoder, mixture_weights_logits):
         """-> (B,) NLL of every shape (its mean is the reference's scalar)."""
-        z = torch.stack([o['p_prior_samples'][0] for o in output_decoder])
+        z = _restack([o['p_prior_samples'][0] for o in output_decoder])
         # the batched training decode attaches the stack's own log-det (= sum of the list's flow entries, same values)
         def flow_logdet(o):
             if '_sum_flow_logvars' in o:
@@ -406,9 +430,9 @@ class FlowMixtureNLL(nn.Module):
             from .decoders import slot_sum
             own = slot_sum(o['p_prior_logvars'][1:])         # the K-loop's lists from a batched sibling round: the sum exists already
             return own if own is not None else sum(o['p_prior_logvars'][1:])
-        logdet = torch.stack([flow_logdet(o) for o in output_decoder])
-        mu0 = torch.stack([o['p_prior_mus'][0][:, :, 0] for o in output_decoder])
-        lv0 = torch.stack([o['p_prior_logvars'][0][:, :, 0] for o in output_decoder])
+        logdet = _restack([flow_logdet(o) for o in output_decoder])
+        mu0 = torch.stack([_first_column(o['p_prior_mus'][0]) for o in output_decoder])
+        lv0 = torch.stack([_first_column(o['p_prior_logvars'][0]) for o in output_decoder])
         return flow_mixture_nll(z, logdet, mu0, lv0, mixture_weights_logits)[1]
 
     def forward(self, output_decoder, mixture_weights_logits):

@@ -139,3 +139,23 @@ def test_final_slot_handed_out_is_the_pipelines_output_bit_for_bit(mode):
     final = 0 if mode == 'inverse' else ps.shape[1] - 1
     assert torch.equal(out, ps[:, final])
     assert maxabs(logdet.cpu().numpy(), lvs.sum(1).cpu().numpy()) <= 2e-5 * max(1.0, float(logdet.abs().max()))
+
+
+def test_loss_restacks_the_round_tensors_without_a_copy():
+    """models._restack: the K slices a batched round hands out are recognised as one (K, B, 3, N) tensor (and anything else is stacked)."""
+    from go_with_the_flows_amd.models import _first_column, _restack
+    m = build()
+    p, g = inputs(5)
+    for _ in range(2):                                  # round 1 is observed, round 2 is batched
+        outs = m.decode(p, g)
+    zs = [o[0][0] for o in outs]
+    base = _restack(zs)
+    assert base is zs[0]._base and base.shape == (K, B, 3, N) and base.requires_grad
+    assert torch.equal(base, torch.stack(zs))
+    mixed = [zs[0], zs[2], zs[1]]
+    assert torch.equal(_restack(mixed), torch.stack(mixed)) and _restack(mixed)._base is None
+    h = torch.randn(B, 3, device=DEV, requires_grad=True)
+    hb = h * 2.0
+    e = hb.unsqueeze(2).expand(B, 3, N)
+    assert _first_column(e) is hb
+    assert torch.equal(_first_column(e.contiguous()), e[:, :, 0])

@@ -36,6 +36,8 @@ ap.add_argument('--api', default='fused', choices=['fused', 'list', 'both', 'swa
                      "INTEGRATION.md section 1 -- the K decoders called ONE AT A TIME (flow_mixture.py:163-166) and the loss on their "
                      "lists; swap_loop: the same with the loss as the reference's B x K Python loop (losses.py:109-131, restated "
                      "below).  GWTF_NO_SIBLING_BATCH=1 turns the decoders' sibling batching off (what round 4 shipped)")
+ap.add_argument('--torch-profile', type=int, default=0, metavar='ROWS',
+                help='after the warm-up: torch.profiler over 3 eager steps, the ROWS operators with the most device time (with shapes), exit')
 ap.add_argument('--lib', default=None, help='A/B: load this build of libgwtf_hip.so instead of the in-tree one')
 ap.add_argument('--parts', default='epd', help='debug: which parts run (e=encoder, p=prior flow, d=decoders)')
 ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'], help='process-group backend of a data-parallel run (nccl = RCCL)')
@@ -172,6 +174,16 @@ for _ in range(2):
     l = step()
 say('loss after warm-up', float(l.detach()))
 del l                       # keep no reference to an autograd graph across iterations (hipGraph capture needs that)
+if a.torch_profile:
+    from torch.profiler import ProfilerActivity, profile
+    step()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by='self_cuda_time_total', row_limit=a.torch_profile,
+                                                             max_name_column_width=60, max_shapes_column_width=90))
+    sys.exit(0)
 ms = timed(step, a.steps)
 pts = a.batch * a.points * WORLD
 say(f'ranks: {WORLD}  per-rank batch: {a.batch}  sharded path: {sharded()}')
