@@ -10,6 +10,7 @@ library launches of the module-by-module evaluation; the per-module ``forward`` 
 (used on their own and on the CPU by the host-logic tests) stays a chain of torch ops with
 the two shipped warp patterns applied as strided slices instead of the reference's index gathers.
 """
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -205,7 +206,7 @@ class GlobalRNVPDecoder(nn.Module):
         backward (autograd runs a node's backward on the stream of its forward).  Capturable: the fork / join pair becomes a
         branch of the hipGraph.  Falls back to the synchronous evaluation when the fused path does not apply."""
         _STACKED.pop(self, None)
-        if not self._fused_ok(g, self._rows_seen(g)):
+        if not self._fused_ok(g, self._rows_seen(g)) or os.environ.get('GWTF_PRIOR_SIDE_STREAM', '1') == '0':
             return _PriorResult(self.forward(g, mode), None, None)
         cur = torch.cuda.current_stream(g.device)
         side = _SIDE_STREAMS.get(g.device)              # per device, not per module: a stream is not module state (deepcopy, pickle)
