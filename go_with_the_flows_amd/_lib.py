@@ -39,6 +39,10 @@ _SIGNATURES = {
     'gwtf_pack_weights_exact': (ctypes.c_int, [_c_fp, _c_fp, _c_fp] + [ctypes.c_int] * 5 + [_c_fp]),
     'gwtf_stack_forward_exact': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
                                  [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, _c_fp]),
+    'gwtf_stack_forward_flagging': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
+                                    [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_fp, ctypes.c_int, _c_fp]),
+    'gwtf_stack_rerun_flagged': (ctypes.c_int, [_c_fp] * 8 + [ctypes.POINTER(ctypes.c_int)] + [ctypes.c_int] * 6 +
+                                 [ctypes.c_float, ctypes.c_int, ctypes.c_size_t, ctypes.c_size_t, _c_fp, ctypes.c_int, _c_fp]),
     'gwtf_latent_loss_workspace_floats': (ctypes.c_int, [ctypes.c_int] * 2),
     'gwtf_latent_loss_forward': (ctypes.c_int, [_c_fp] * 8 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [_c_fp]),
     'gwtf_latent_loss_backward': (ctypes.c_int, [_c_fp] * 10 + [ctypes.c_int] * 3 + [ctypes.c_float] * 3 + [_c_fp]),
@@ -276,11 +280,36 @@ class exact_fp32:
 def pack_weights_exact(raw, packed_film, C, f, G, pattern0=0, K=1):
     """GwtfPackX records of K concatenated stacks of C couplings (the fp32 operands of the exact contraction body)."""
     L = lib()
-    px = torch.empty(K * C * L.gwtf_packed_x_coupling_floats(f), device=raw.device, dtype=torch.float32)
+    n = K * C * L.gwtf_packed_x_coupling_floats(f)
+    # behind the records: the work list of the flagging launch / re-run pair (include/gwtf.h), zero once -- the pair keeps it zero.
+    # It lives and dies with the record it serves; like the record it belongs to one stream at a time.
+    px = torch.empty(n + WORKLIST_INTS, device=raw.device, dtype=torch.float32)
+    px[n:].zero_()
     with torch.cuda.device(raw.device):
         check(L.gwtf_pack_weights_exact(_ptr(raw, 'raw'), _ptr(packed_film, 'packed_film'), _ptr(px, 'packed_x'), K, C, f, G,
                                         int(pattern0), _stream(raw)))
     return px
+
+
+WORKLIST_INTS = 2 + 2 * 2048          # GWTF_WORKLIST_INTS of include/gwtf.h
+
+
+def _worklist_ptr(packed_x, K, C, f):
+    """Device address of the work list behind the K * C exact records of `packed_x` (pack_weights_exact), or None."""
+    n = K * C * lib().gwtf_packed_x_coupling_floats(f)
+    if packed_x is None or packed_x.numel() != n + WORKLIST_INTS or os.environ.get('GWTF_NO_RERUN_WORKLIST') == '1':
+        return None
+    return packed_x.data_ptr() + 4 * n
+
+
+def _rerun_launch(p, packed_x, film, out, logdet, lp, seg, K, C, f, pattern0, eps, mode, p_stride, out_stride, wl):
+    """The exact-fp32 re-run of the tiles the preceding split launch flagged: from its work list, or by looking at every tile."""
+    if wl is None:
+        return _exact_launch(p, packed_x, film, out, logdet, lp, seg, K, C, f, pattern0, eps, mode, p_stride, out_stride, 1)
+    B, _, N = p.shape
+    check(lib().gwtf_stack_rerun_flagged(_ptr(p, 'p'), _ptr(packed_x, 'packed_x'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                         _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], seg, K, B, N, C, f, pattern0, float(eps),
+                                         _MODES[mode], p_stride, out_stride, wl, _TUNE[0] & 0xffff, _stream(p)))
 
 
 def _exact_launch(p, packed_x, film, out, logdet, lp, seg, K, C, f, pattern0, eps, mode, p_stride, out_stride, only_flagged):
@@ -308,11 +337,17 @@ def stack_forward(p, packed_w, film, C, f, pattern0, eps, mode, want_lists, pack
                 raise GwtfError('exact_fp32: this call site has no exact record (packed_x)')
             _exact_launch(p, packed_x, film, out, logdet, lp, None, 1, C, f, pattern0, eps, mode, 0, 0, 0)
             return out, logdet, lists
-        check(L.gwtf_stack_forward(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
-                                   _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], B, N, C, f, pattern0, float(eps),
-                                   _MODES[mode], _TUNE[0], _stream(p)))
+        wl = _worklist_ptr(packed_x, 1, C, f)
+        if wl is None:
+            check(L.gwtf_stack_forward(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                       _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], B, N, C, f, pattern0, float(eps),
+                                       _MODES[mode], _TUNE[0], _stream(p)))
+        else:
+            check(L.gwtf_stack_forward_flagging(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                                _ptr(logdet, 'logdet'), lp[0], lp[1], lp[2], None, 1, B, N, C, f, pattern0,
+                                                float(eps), _MODES[mode], 0, 0, wl, _TUNE[0], _stream(p)))
         if packed_x is not None:
-            _exact_launch(p, packed_x, film, out, logdet, lp, None, 1, C, f, pattern0, eps, mode, 0, 0, 1)
+            _rerun_launch(p, packed_x, film, out, logdet, lp, None, 1, C, f, pattern0, eps, mode, 0, 0, wl)
     return out, logdet, lists
 
 
@@ -356,11 +391,17 @@ def stack_forward_multi(p, packed_w, film, K, C, f, pattern0, eps, mode, segment
                 raise GwtfError('exact_fp32: this call site has no exact record (packed_x)')
             _exact_launch(p, packed_x, film, out, logdet, [None] * 3, seg, K, C, f, pattern0, eps, mode, 0, stride, 0)
             return out, logdet
-        check(L.gwtf_stack_forward_multi(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
-                                         _ptr(logdet, 'logdet'), None, None, None, seg, K, B, N, C, f, pattern0,
-                                         float(eps), _MODES[mode], 0, stride, _TUNE[0], _stream(p)))
+        wl = _worklist_ptr(packed_x, K, C, f)
+        if wl is None:
+            check(L.gwtf_stack_forward_multi(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                             _ptr(logdet, 'logdet'), None, None, None, seg, K, B, N, C, f, pattern0,
+                                             float(eps), _MODES[mode], 0, stride, _TUNE[0], _stream(p)))
+        else:
+            check(L.gwtf_stack_forward_flagging(_ptr(p, 'p'), _ptr(packed_w, 'packed_w'), _ptr(film, 'film'), _ptr(out, 'out'),
+                                                _ptr(logdet, 'logdet'), None, None, None, seg, K, B, N, C, f, pattern0,
+                                                float(eps), _MODES[mode], 0, stride, wl, _TUNE[0], _stream(p)))
         if packed_x is not None:
-            _exact_launch(p, packed_x, film, out, logdet, [None] * 3, seg, K, C, f, pattern0, eps, mode, 0, stride, 1)
+            _rerun_launch(p, packed_x, film, out, logdet, [None] * 3, seg, K, C, f, pattern0, eps, mode, 0, stride, wl)
     return out, logdet
 
 

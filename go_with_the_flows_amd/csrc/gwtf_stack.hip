@@ -491,6 +491,7 @@ struct Extras {
   float* moments_out;            // [GWTF_STAT_REPLICAS][16], 9 used {Sx0,Sx1,Sx2,Sx0x0,Sx0x1,Sx0x2,Sx1x1,Sx1x2,Sx2x2}, or null
   size_t moments_stride_k;       // component k accumulates into moments_out + k * moments_stride_k
   int tpw;                       // one-coupling launches: consecutive tiles of ONE shape a workgroup walks (0 / 1 = one tile)
+  int* worklist;                 // null, or the flagged-wave list a gwtf_stack_rerun_flagged launch reads (include/gwtf.h)
 };
 
 struct Jobs {
@@ -665,6 +666,14 @@ __global__ __launch_bounds__(256) void stack_kernel(const float* __restrict__ p,
       const float qnan = __builtin_bit_cast(float, 0x7fc00000u);
 #pragma unroll
       for (int d = 0; d < 3; ++d) xo[d] = ld[d] = mu_last[d] = lv_last[d] = qnan;
+    }
+    // (rare) a wave with a flagged point leaves {shape slot, first point} in the work list of the exact re-run launch that follows
+    if (ex.worklist && __builtin_amdgcn_ballot_w64(bad) != 0ull && lane == 0) {
+      const int idx = atomicAdd(&ex.worklist[0], 1);
+      if (idx < GWTF_WORKLIST_CAP) {
+        ex.worklist[2 + 2 * idx] = comp * B + b;
+        ex.worklist[3 + 2 * idx] = n_own;
+      }
     }
   }
   if (LISTS && own_valid) {
@@ -892,11 +901,21 @@ static int stack_dispatch(const float* p, const float* packed_w, const float* fi
 #undef GWTF_ARGS
 }
 
+extern "C" int gwtf_stack_forward_flagging(const float* p, const float* packed_w, const float* film, float* out,
+                                           float* logdet, float* ps, float* mus, float* logvars, const int* segments,
+                                           int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                                           size_t p_stride_k, size_t out_stride_k, int* worklist, int tune, void* stream) {
+  const Extras ex = {0, 0, nullptr, nullptr, 0, 0, worklist};
+  return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, segments, K, B, N, C, f, pattern0, eps, mode,
+                        p_stride_k, out_stride_k, ex, tune, stream);
+}
+
 extern "C" int gwtf_stack_forward_multi(const float* p, const float* packed_w, const float* film, float* out,
                                         float* logdet, float* ps, float* mus, float* logvars, const int* segments,
                                         int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
                                         size_t p_stride_k, size_t out_stride_k, int tune, void* stream) {
-  const Extras ex = {0, 0, nullptr, nullptr, 0};
+  int* worklist = nullptr;
+  const Extras ex = {0, 0, nullptr, nullptr, 0, 0, worklist};
   return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, segments, K, B, N, C, f, pattern0, eps, mode,
                         p_stride_k, out_stride_k, ex, tune, stream);
 }
@@ -908,7 +927,7 @@ extern "C" int gwtf_train_apply(const float* p, const float* packed_w, const flo
                                 const float* logdet_in, float* logdet, float* ps, float* mus, float* logvars,
                                 float* moments_out, int c, int B, int N, int C, int f, int pattern0, float eps, int mode,
                                 int tune, void* stream) {
-  const Extras ex = {c, 1, logdet_in, moments_out, 0};
+  const Extras ex = {c, 1, logdet_in, moments_out, 0, 0, nullptr};
   return stack_dispatch(p, packed_w, film, out, logdet, ps, mus, logvars, nullptr, 1, B, N, C, f, pattern0, eps, mode, 0, 0,
                         ex, tune, stream);
 }

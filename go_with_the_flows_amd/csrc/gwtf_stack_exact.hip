@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
                                                           const float* __restrict__ film, float* __restrict__ out,
                                                           float* __restrict__ logdet, float* __restrict__ ps, float* __restrict__ mus,
                                                           float* __restrict__ lvs, int B, int N, int C, int pattern0, float eps, int kk4,
-                                                          const XJobs jobs, size_t p_stride_k, size_t out_stride_k, int only_flagged) {
+                                                          const XJobs jobs, size_t p_stride_k, size_t out_stride_k, int only_flagged,
+                                                          int* __restrict__ wl) {
   using X = XCfg<MB>;
   constexpr int NBUF = 2 * X::LAYER * 4 <= 160 * 1024 - 512 ? 2 : 1;
   __shared__ __align__(16) float lds[NBUF][X::LAYER];
@@ -141,9 +142,20 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
   // workgroup per tile (4096 workgroups with 45 KB of LDS each just to read 128 values and leave), ~3 us this way.
   // re-run mode, phase 1: ALL of this workgroup's tiles are looked at in one round of loads (a tile at a time would be a dependent
   // load + barrier per tile: 8 tiles x ~1 us behind a clean airplane launch), the flagged ones leave a bit in an LDS word
+  // re-run mode WITH A WORK LIST (gwtf_stack_rerun_flagged): the split launch left {shape slot, first point} of every wave that flagged
+  // a point in wl[2..], their number in wl[0]; a small fixed grid (64 workgroups) walks that list (an empty list -- every clean pass -- is one scalar
+  // load per workgroup), checks the listed tile's flags (a tile can be listed by several of its waves: the first re-run clears them) and
+  // recomputes it.  More entries than the list holds: every tile is a candidate.  The last workgroup to finish clears the counters.
+  const bool wlmode = only_flagged && wl != nullptr;
+  int n_cand = jobs.tiles_cum[jobs.K];
+  bool listed = false;
+  if (wlmode) {
+    const int cnt = wl[0];
+    if (cnt <= GWTF_WORKLIST_CAP) { n_cand = cnt; listed = true; }
+  }
   __shared__ unsigned s_flagged;
   unsigned flagged_mask = 0xffffffffu;
-  if (only_flagged) {
+  if (only_flagged && !wlmode) {
     if (threadIdx.x == 0) s_flagged = 0u;
     __syncthreads();
     // (all kLook loads are issued before the first is tested: tested one by one they are kLook dependent round trips -- 6.8 us for 8)
@@ -174,8 +186,26 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
     if (flagged_mask == 0u) return;
   }
   int it = 0;
-  for (int bid = blockIdx.x; bid < jobs.tiles_cum[jobs.K]; bid += gridDim.x, ++it) {
-  if (only_flagged && !((flagged_mask >> (it & 31)) & 1u)) continue;      // (launch_exact sizes the grid so that it < kLook)
+  for (int cand = blockIdx.x; cand < n_cand; cand += gridDim.x, ++it) {
+  int bid = cand;
+  if (wlmode) {
+    if (listed) {
+      const int slot = wl[2 + 2 * cand], n_first = wl[3 + 2 * cand];
+      const int lc = slot / B, lb = slot - lc * B;
+      const int ltps = (jobs.end[lc] - jobs.begin[lc] + 64 * NB - 1) / (64 * NB);
+      bid = jobs.tiles_cum[lc] + lb * ltps + (n_first - jobs.begin[lc]) / (64 * NB);
+    }
+    int fc = 0;
+    while (fc + 1 < jobs.K && bid >= jobs.tiles_cum[fc + 1]) ++fc;
+    const int f_begin = jobs.begin[fc], f_end = jobs.end[fc];
+    const int ftps = (f_end - f_begin + 64 * NB - 1) / (64 * NB);
+    const int flocal = bid - jobs.tiles_cum[fc];
+    const int fb = flocal / ftps, ftile = flocal - fb * ftps;
+    const int fn = f_begin + ftile * 64 * NB + (int)threadIdx.x;
+    float first = 0.f;
+    if ((int)threadIdx.x < 64 * NB && fn < f_end) first = out[fc * out_stride_k + (size_t)fb * 3 * N + fn];
+    if (!__syncthreads_or(gwtf_nonfinite(first) ? 1 : 0)) continue;
+  } else if (only_flagged && !((flagged_mask >> (it & 31)) & 1u)) continue;      // (launch_exact sizes the grid so that it < kLook)
   int comp = 0;
   while (comp + 1 < jobs.K && bid >= jobs.tiles_cum[comp + 1]) ++comp;
   const int n_begin = jobs.begin[comp], n_end = jobs.end[comp];
@@ -278,12 +308,19 @@ __global__ __launch_bounds__(256) void stack_exact_kernel(const float* __restric
   }
   __syncthreads();      // every wave is done with the staged weights before the next flagged tile's staging overwrites them
   }   // tiles of this workgroup
+  if (wlmode && threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&wl[1], 1) == (int)gridDim.x - 1) {       // every workgroup has read the count: clear it for the next split launch
+      wl[0] = 0;
+      wl[1] = 0;
+    }
+  }
 }
 
 template <int MB, int NB>
 int launch_exact(const float* p, const float* px, const float* film, float* out, float* logdet, float* ps, float* mus, float* lvs,
                  int B, int N, int C, int pattern0, float eps, int mode, int kk4, const int* segs, int K, size_t p_stride_k,
-                 size_t out_stride_k, int only_flagged, hipStream_t st) {
+                 size_t out_stride_k, int only_flagged, int* wl, hipStream_t st) {
   XJobs jobs;
   jobs.K = K;
   jobs.tiles_cum[0] = 0;
@@ -294,10 +331,18 @@ int launch_exact(const float* p, const float* px, const float* film, float* out,
   }
   if (jobs.tiles_cum[K] == 0) return 0;
   // re-run launches: a workgroup LOOKS at kLook tiles (their flags are bits of one LDS word)
-  const dim3 grid((unsigned)(only_flagged ? (jobs.tiles_cum[K] + kLook - 1) / kLook : jobs.tiles_cum[K])), block(256);
+  static const int rerun_wgs = [] {
+    const char* e = getenv("GWTF_RERUN_WGS");
+    const int v = e ? atoi(e) : 0;
+    // a clean pass pays for the DISPATCH of these workgroups (45 KB of LDS each) and nothing else: 7.0 / 4.6 / 2.8 / 2.2 us for
+    // 256 / 128 / 64 / 32 of them (airplane launch, inside a hipGraph); 64 keeps a pass with up to 64 flagged tiles in one round
+    return v > 0 ? v : 64;
+  }();
+  const unsigned n_wl = (unsigned)(jobs.tiles_cum[K] < rerun_wgs ? jobs.tiles_cum[K] : rerun_wgs);
+  const dim3 grid(only_flagged ? (wl ? n_wl : (unsigned)((jobs.tiles_cum[K] + kLook - 1) / kLook)) : (unsigned)jobs.tiles_cum[K]), block(256);
 #define GWTF_X(MODE_, LISTS_)                                                                                                    \
   hipLaunchKernelGGL((stack_exact_kernel<MB, NB, MODE_, LISTS_>), grid, block, 0, st, p, px, film, out, logdet, ps, mus, lvs, B, \
-                     N, C, pattern0, eps, kk4, jobs, p_stride_k, out_stride_k, only_flagged)
+                     N, C, pattern0, eps, kk4, jobs, p_stride_k, out_stride_k, only_flagged, wl)
   if (mode == GWTF_MODE_DIRECT) { if (ps) GWTF_X(GWTF_MODE_DIRECT, true); else GWTF_X(GWTF_MODE_DIRECT, false); }
   else { if (ps) GWTF_X(GWTF_MODE_INVERSE, true); else GWTF_X(GWTF_MODE_INVERSE, false); }
 #undef GWTF_X
@@ -307,10 +352,10 @@ int launch_exact(const float* p, const float* px, const float* film, float* out,
 }  // namespace
 
 // see include/gwtf.h
-extern "C" int gwtf_stack_forward_exact(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps,
-                                        float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,
-                                        int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, int only_flagged,
-                                        int tune, void* stream) {
+static int exact_dispatch(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps,
+                          float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,
+                          int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, int only_flagged, int* wl,
+                          int tune, void* stream) {
   if (B <= 0 || N <= 0 || C <= 0 || f <= 0 || f > GWTF_MAX_FP || K <= 0 || K > GWTF_MAX_COMPONENTS || !p || !packed_x || !film || !out ||
       !logdet || (mode != GWTF_MODE_DIRECT && mode != GWTF_MODE_INVERSE) || pattern0 < 0 || pattern0 > 5)
     return GWTF_E_BADARG;
@@ -324,7 +369,7 @@ extern "C" int gwtf_stack_forward_exact(const float* p, const float* packed_x, c
   const int forced = (tune & 0xffff) / 16;
   // 32 points per wave (16 beyond f = 64: the accumulators of both point blocks would not fit); GWTF_TUNE_POINTS_PER_WAVE overrides
   const int nb = (forced == 1 || forced == 2) ? forced : (f > 64 ? 1 : 2);
-#define GWTF_XA p, packed_x, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk4, segments, K, p_stride_k, out_stride_k, only_flagged, st
+#define GWTF_XA p, packed_x, film, out, logdet, ps, mus, logvars, B, N, C, pattern0, eps, mode, kk4, segments, K, p_stride_k, out_stride_k, only_flagged, wl, st
 #define GWTF_XM(MB_) return nb == 1 ? launch_exact<MB_, 1>(GWTF_XA) : launch_exact<MB_, 2>(GWTF_XA);
   switch (gwtf_padded_width(f) / 16) {
     case 1: GWTF_XM(1)
@@ -339,4 +384,21 @@ extern "C" int gwtf_stack_forward_exact(const float* p, const float* packed_x, c
   }
 #undef GWTF_XM
 #undef GWTF_XA
+}
+
+extern "C" int gwtf_stack_forward_exact(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps,
+                                        float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,
+                                        int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, int only_flagged,
+                                        int tune, void* stream) {
+  return exact_dispatch(p, packed_x, film, out, logdet, ps, mus, logvars, segments, K, B, N, C, f, pattern0, eps, mode, p_stride_k,
+                        out_stride_k, only_flagged, nullptr, tune, stream);
+}
+
+extern "C" int gwtf_stack_rerun_flagged(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps,
+                                        float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f,
+                                        int pattern0, float eps, int mode, size_t p_stride_k, size_t out_stride_k, int* worklist,
+                                        int tune, void* stream) {
+  if (!worklist) return GWTF_E_BADARG;
+  return exact_dispatch(p, packed_x, film, out, logdet, ps, mus, logvars, segments, K, B, N, C, f, pattern0, eps, mode, p_stride_k,
+                        out_stride_k, 1, worklist, tune, stream);
 }

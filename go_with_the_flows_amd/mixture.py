@@ -41,7 +41,10 @@ class MixtureStack:
         pxs = [e.packed_exact() for e in self.engines]
         key = tuple(id(x) for x in pxs)
         if key != getattr(self, '_catx_key', None):
-            self._catx, self._catx_key, self._keepx = torch.cat(pxs), key, pxs
+            # (each engine's record carries its own work list behind it, _lib.pack_weights_exact: the K record parts, then ONE list)
+            n = self.C * _lib.lib().gwtf_packed_x_coupling_floats(self.f)
+            tail = torch.zeros(_lib.WORKLIST_INTS, device=pxs[0].device, dtype=torch.float32)
+            self._catx, self._catx_key, self._keepx = torch.cat([x[:n] for x in pxs] + [tail]), key, pxs
         return self._catx
 
     def _film(self, g):

@@ -140,6 +140,22 @@ int gwtf_pack_weights_exact(const float* raw, const float* packed_film /*eval pa
 int gwtf_stack_forward_exact(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps,
                              float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f, int pattern0,
                              float eps, int mode, size_t p_stride_k, size_t out_stride_k, int only_flagged, int tune, void* stream);
+/* The same pair with a WORK LIST, so that the re-run launch behind a clean pass costs the dispatch of 64 idle workgroups instead of a
+ * scan of every tile's flags (7 us -> 2.8 per forward pass of the airplane config):
+ *   gwtf_stack_forward_flagging  = gwtf_stack_forward_multi; a wave that flags a point appends {component * B + shape, first point}
+ *                                  to worklist[2 + 2 i], i = atomic increment of worklist[0]
+ *   gwtf_stack_rerun_flagged     = gwtf_stack_forward_exact(only_flagged = 1) over the listed tiles (all tiles when worklist[0] >
+ *                                  GWTF_WORKLIST_CAP); its last workgroup clears worklist[0..1]
+ * worklist: GWTF_WORKLIST_INTS ints of device memory, zero before the FIRST use, owned by one stream at a time (the pair keeps it
+ * zero between uses). */
+#define GWTF_WORKLIST_CAP 2048
+#define GWTF_WORKLIST_INTS (2 + 2 * GWTF_WORKLIST_CAP)
+int gwtf_stack_forward_flagging(const float* p, const float* packed_w, const float* film, float* out, float* logdet, float* ps,
+                                float* mus, float* logvars, const int* segments, int K, int B, int N, int C, int f, int pattern0,
+                                float eps, int mode, size_t p_stride_k, size_t out_stride_k, int* worklist, int tune, void* stream);
+int gwtf_stack_rerun_flagged(const float* p, const float* packed_x, const float* film, float* out, float* logdet, float* ps, float* mus,
+                             float* logvars, const int* segments, int K, int B, int N, int C, int f, int pattern0, float eps, int mode,
+                             size_t p_stride_k, size_t out_stride_k, int* worklist, int tune, void* stream);
 /* Latent-space loss terms of the training step and their combination with the point NLL (reference lib/networks/losses.py:24-33
  * GaussianFlowNLL, :36-41 GaussianEntropy, :159-170 Flow_Mixture_Loss.forward), one launch each way (csrc/gwtf_latent.hip):
  *   nll [B] per-shape point NLL (gwtf_mixture_nll); z [B][G] = g_prior_samples[0]; mu0, lv0 [G] = the base Gaussian of the prior flow;

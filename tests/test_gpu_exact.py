@@ -190,3 +190,49 @@ def test_exact_body_of_a_mixture_partition_and_direct_mode():
     with torch.no_grad():
         xs, _ = split(pd, gd, counts, 'direct')
     assert maxabs(host(xs), host(x)) < TOL_COORD
+
+
+def _worklist(px, K, C, f):
+    n = K * C * _lib.lib().gwtf_packed_x_coupling_floats(f)
+    assert px.numel() == n + _lib.WORKLIST_INTS
+    return px[n:].view(torch.int32)
+
+
+@pytest.mark.parametrize('hits', ['few', 'more_than_the_list_holds'])
+def test_work_list_of_the_rerun_pair(hits, monkeypatch):
+    """The flagging launch lists the waves that flagged a point, the re-run launch walks the list (every tile when the list overflows)
+    and leaves it cleared: same results as the re-run that scans every tile's flags (GWTF_NO_RERUN_WORKLIST=1), on a mixture launch
+    (K components share the clouds) and on a single decoder, call after call."""
+    K, L, f, G, B, N = 2, 1, 19, 16, 40, 2048                    # 2 x 40 x 2048 / 64 = 2560 waves > GWTF_WORKLIST_CAP
+    decs = []
+    for k in range(K):
+        d = gw.LocalCondRNVPDecoder(L, f, G)
+        load_synth_(d, 70 + k)
+        decs.append(d.to(DEV).eval())
+    p, g = synth_inputs(B, N, G, 11)
+    if hits == 'few':
+        p[0, 0, 3], p[7, 2, 1000], p[39, 1, 2047] = 1e5, -2e5, 4e4
+    else:
+        p[:, 0, :] = 1e5 * np.sign(p[:, 0, :] + 1e-9)             # every wave of every component flags
+    pd, gd = dev(p), dev(g)
+    stack = gw.MixtureStack(decs)
+    res = []
+    with torch.no_grad():
+        for rep in range(3):
+            z, ld = stack.forward_all(pd, gd, 'inverse')
+            z1, ld1 = decs[1].forward_fused(pd, gd, 'inverse')
+            assert torch.isfinite(z).all() and torch.isfinite(ld).all()
+            assert torch.equal(z[1], z1) and torch.equal(ld[1], ld1)
+            res.append((z.clone(), ld.clone()))
+            wl = _worklist(stack.packed_exact(), K, 3 * L, f)
+            assert int(wl[0]) == 0 and int(wl[1]) == 0, wl[:2]                         # cleared by the re-run launch's last workgroup
+            assert int(_worklist(decs[1].engine().packed_exact(), 1, 3 * L, f)[0]) == 0
+        assert all(torch.equal(res[0][0], r[0]) and torch.equal(res[0][1], r[1]) for r in res[1:])
+        monkeypatch.setenv('GWTF_NO_RERUN_WORKLIST', '1')
+        z_scan, ld_scan = stack.forward_all(pd, gd, 'inverse')
+        assert torch.equal(z_scan, res[0][0]) and torch.equal(ld_scan, res[0][1])
+        with _lib.exact_fp32():                                                          # and the flagged points hold the exact body's values
+            z_x, ld_x = stack.forward_all(pd, gd, 'inverse')
+    bad = torch.from_numpy(np.abs(p).max(axis=1) > 3e4).to(DEV)                          # (B, N)
+    sel = bad[None, :, None, :].expand_as(z_x)
+    assert torch.equal(res[0][0][sel], z_x[sel]) and torch.equal(res[0][1][sel], ld_x[sel])
