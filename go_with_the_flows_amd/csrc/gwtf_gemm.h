@@ -58,6 +58,25 @@ __device__ __forceinline__ float col_sum(const ColMap& m, int ncols, int B, FV v
   return tot;
 }
 
+// The same sum over values a thread already HOLDS: v[i] belongs to row rg + i RG (B <= KEEP RG).  A layer's kernels use a column's
+// values two or three times (mean, variance, output; the backward's two sums and dL/dy): fetched once, each use is one LDS round
+// instead of a dependent round trip to global memory.  Same order of additions as col_sum's loop for these sizes: the same bits.
+template <int KEEP>
+__device__ __forceinline__ float col_sum_kept(const ColMap& m, int ncols, int B, const float (&v)[KEEP], float* __restrict__ red) {
+  if (m.on) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i)
+      if (m.rg + i * m.RG < B) s += v[i];
+    red[m.rg * ncols + m.col] = s;
+  }
+  __syncthreads();
+  float tot = 0.f;
+  if (m.on)
+    for (int r = 0; r < m.RG; ++r) tot += red[r * ncols + m.col];
+  __syncthreads();
+  return tot;
+}
 
 // C (M x N) [+]= A (M x K) . B^T (N x K), M <= 128, any N, for the whole workgroup (8 wavefronts), operands read STRAIGHT from global memory /
 // L2 into the MFMA's registers (v_mfma_f32_16x16x4_f32: exact fp32 products) -- no LDS staging, no barriers: the staged version

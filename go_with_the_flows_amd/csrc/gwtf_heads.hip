@@ -23,6 +23,7 @@ namespace {
 using namespace gwtf_gemm;
 constexpr int kNJ = 1, kCols = 16 * kNJ;   // output (pass 1) / input (pass 2) columns per workgroup: narrow, so that a 512-wide layer is 32 workgroups
 constexpr int kSplitK = 128;         // contractions at least this long are cut over the eight waves (gemm_splitk)
+constexpr int kKeep = 4;             // rows of its column a thread keeps in registers (batches up to kKeep * 32 = 128 rows)
 constexpr int kGyPitch = kCols + 1;  // the dL/dy block in LDS for the weight gradient: [128 rows][17]
 constexpr int kWorkFloats = 8 * 64 * kCols;      // split-K slabs (32 KB); the dL/dy block (8.5 KB) reuses them
 static_assert(kWorkFloats >= kMaxM * kGyPitch, "the dL/dy block must fit the work area");
@@ -66,7 +67,18 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
   const bool live = cm.on && cm.col < nc;
   auto yat = [&](int b, int c) { return c < nc ? ypre[(size_t)b * Dout + c0 + c] + (bias ? bias[c0 + c] : 0.f) : 0.f; };
   float mean = 0.f, var = 1.f, rstd = 1.f, ga = 1.f, be = 0.f;
-  if (bn_mode == 1) {
+  // up to kKeep rows per thread (B <= 128): the thread's y values stay in registers for the statistics and the output
+  const bool keep = B <= kKeep * cm.RG;
+  float yv[kKeep];
+#pragma unroll
+  for (int i = 0; i < kKeep; ++i) yv[i] = (keep && cm.on && cm.rg + i * cm.RG < B) ? yat(cm.rg + i * cm.RG, cm.col) : 0.f;
+  if (bn_mode == 1 && keep) {
+    mean = col_sum_kept(cm, kCols, B, yv, red) / (float)B;
+    float dv[kKeep];
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) { const float t = yv[i] - mean; dv[i] = t * t; }
+    var = col_sum_kept(cm, kCols, B, dv, red) / (float)B;
+  } else if (bn_mode == 1) {
     mean = col_sum(cm, kCols, B, [&](int b, int c) { return yat(b, c); }, red) / (float)B;
     var = col_sum(cm, kCols, B, [&](int b, int c) { const float t = yat(b, c) - mean; return t * t; }, red) / (float)B;
   } else if (bn_mode == 2 && live) {
@@ -102,7 +114,17 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
     }
     return;
   }
-  if (live) {
+  if (live && keep) {
+#pragma unroll
+    for (int i = 0; i < kKeep; ++i) {
+      const int b = cm.rg + i * cm.RG;
+      if (b < B) {
+        float s = yv[i];
+        if (bn_mode != 0) s = bn_apply(s, mean, rstd, ga, be);
+        out[(size_t)b * Dout + col] = act == 1 ? swishf(s) : s;
+      }
+    }
+  } else if (live) {
     for (int b = cm.rg; b < B; b += cm.RG) {
       float s = yat(b, cm.col);
       if (bn_mode != 0) s = bn_apply(s, mean, rstd, ga, be);
@@ -161,7 +183,25 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
   for (int t = threadIdx.x; t < kMaxM * kGyPitch; t += kThreads) gyt[t] = 0.f;
   __syncthreads();
   float sum_ds = 0.f, sum_dsx = 0.f;
-  if (bn_mode != 0 || g_bias) {
+  // (B <= 128) the thread's rows of ds and of the normalised input stay in registers: fetched and differentiated once
+  const bool keep = B <= kKeep * cm.RG;
+  float dsv[kKeep], xhv[kKeep];
+#pragma unroll
+  for (int i = 0; i < kKeep; ++i) {
+    const int b = cm.rg + i * cm.RG;
+    const bool have = keep && cm.on && b < B && cm.col < nc;
+    dsv[i] = have ? ds_at(b, cm.col, mean, rstd, ga, be, bi) : 0.f;
+    xhv[i] = (have && bn_mode != 0) ? (ypre[(size_t)b * Dout + c0 + cm.col] + bi - mean) * rstd : 0.f;
+  }
+  if ((bn_mode != 0 || g_bias) && keep) {
+    sum_ds = col_sum_kept(cm, kCols, B, dsv, red);
+    if (bn_mode != 0) {
+      float pv[kKeep];
+#pragma unroll
+      for (int i = 0; i < kKeep; ++i) pv[i] = dsv[i] * xhv[i];
+      sum_dsx = col_sum_kept(cm, kCols, B, pv, red);
+    }
+  } else if (bn_mode != 0 || g_bias) {
     sum_ds = col_sum(cm, kCols, B, [&](int b, int c) { return ds_at(b, c, mean, rstd, ga, be, bi); }, red);
     if (bn_mode != 0)
       sum_dsx = col_sum(cm, kCols, B, [&](int b, int c) {
@@ -179,7 +219,19 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
   for (int r0 = 0; r0 < B; r0 += kMaxM) {
     const int nb = min(kMaxM, B - r0);
     if (r0) __syncthreads();                                  // the previous block's product has read the LDS block
-    if (live) {
+    if (live && keep) {           // (one row block: r0 == 0)
+#pragma unroll
+      for (int i = 0; i < kKeep; ++i) {
+        const int b = cm.rg + i * cm.RG;
+        if (b < B) {
+          float gy = dsv[i];
+          if (bn_mode == 1) gy = ga * rstd * (gy - invB * sum_ds - xhv[i] * invB * sum_dsx);
+          else if (bn_mode == 2) gy = ga * rstd * gy;
+          g_y[(size_t)b * Dout + col] = gy;
+          gyt[b * kGyPitch + cm.col] = gy;
+        }
+      }
+    } else if (live) {
       for (int b = r0 + cm.rg; b < r0 + nb; b += cm.RG) {
         const size_t o = (size_t)b * Dout + col;
         float gy = ds_at(b, cm.col, mean, rstd, ga, be, bi);
