@@ -324,11 +324,12 @@ class Flow_Mixture_Model(Local_Cond_RNVP_MC_Global_RNVP_VAE):
         # identical outputs, and K running-statistic updates with the same batch statistics.  One evaluation here; its BatchNorm
         # modules replay the other K - 1 buffer updates (same values as K passes would leave, to rounding).
         m, v = self._base_gaussian_repeated(g_sample, K)
-        mu0 = [m.expand(B, P, 1)[:, :, 0]] * K
-        lv0 = [v.expand(B, P, 1)[:, :, 0]] * K
+        # (K views of the one evaluation: no copy here, and ONE sum over K in the backward where a stack's would be K - 1 adds)
+        mu0 = m.expand(B, P, 1)[:, :, 0].unsqueeze(0).expand(K, B, P)
+        lv0 = v.expand(B, P, 1)[:, :, 0].unsqueeze(0).expand(K, B, P)
         z, logdet = self.mixture_stack().forward_all(p_input, g_sample, mode='inverse')
         self.finish_encode(output_encoder)
-        return output_encoder, {'z': z, 'logdet': logdet, 'mu0': torch.stack(mu0), 'lv0': torch.stack(lv0), 'logits': logits}
+        return output_encoder, {'z': z, 'logdet': logdet, 'mu0': mu0, 'lv0': lv0, 'logits': logits}
 
     @torch.no_grad()
     def sample_fused(self, g_sample, n_points, return_labels=False):
