@@ -52,3 +52,30 @@ def test_model_refuses_cpu_tensors():
         m(torch.zeros(2, 3, 8), torch.zeros(2, 3, 8))
     with pytest.raises(ValueError):
         models.Flow_Mixture_Model(**dict(cfg, util_mode='generating')).forward_fused(torch.zeros(2, 3, 8), torch.zeros(2, 3, 8))
+
+
+def test_loss_shortcuts_return_the_underlying_tensor_only_when_it_is_the_same_thing():
+    """models._restack / _first_column (what keeps the loss gradient on dense routes): the (K, ...) tensor behind its K in-order
+    slices, the (B, P) tensor behind its broadcast -- and a plain stack / column whenever anything differs; gradients agree."""
+    from go_with_the_flows_amd.models import _first_column, _restack
+    base = (torch.arange(24.0).view(3, 2, 4) + 0.5).requires_grad_(True) * 1.0
+    parts = list(base.unbind(0))
+    assert _restack(parts) is base
+    for other in ([parts[0], parts[2], parts[1]], parts[:2], [p.clone() for p in parts], [base[0], base[1], base[2][:, :4] * 1.0]):
+        got = _restack(other)
+        assert got is not base and torch.equal(got, torch.stack(other))
+    detached = list(base.detach().unbind(0))
+    assert _restack(detached)._base is None or _restack(detached).requires_grad is False
+    wide = torch.arange(48.0).view(2, 3, 2, 4)                       # slices of a LARGER tensor's sub-block are not "all of base"
+    assert torch.equal(_restack(list(wide[0].unbind(0))), wide[0])
+
+    h = torch.randn(5, 3, requires_grad=True)
+    hb = h * 2.0
+    e = hb.unsqueeze(2).expand(5, 3, 7)
+    assert _first_column(e) is hb
+    for other in (e.contiguous(), hb.t().contiguous().t().unsqueeze(2).expand(5, 3, 7), torch.randn(5, 3, 7), hb[:, :2].unsqueeze(2).expand(5, 2, 7)):
+        got = _first_column(other)
+        assert got is not hb and torch.equal(got, other[:, :, 0])
+    (g1,) = torch.autograd.grad((_first_column(e) ** 2).sum(), h, retain_graph=True)
+    (g2,) = torch.autograd.grad((e[:, :, 0] ** 2).sum(), h)
+    assert torch.equal(g1, g2)
