@@ -307,16 +307,28 @@ __global__ __launch_bounds__(kF1Slices * 16) void fold1_bwd_kernel(
   }
   {
     float ys = 0.f, yq = 0.f;
-    if (on)
+    constexpr int kPer = GWTF_STAT_REPLICAS / kF1Slices;
+    if (on && NR == GWTF_STAT_REPLICAS) {          // (all four replicas of this slice in flight at once)
+      float2 v[kPer];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i)
+        v[i] = *reinterpret_cast<const float2*>(&ystats[(size_t)(sl + i * kF1Slices) * (2 * FP * 2) + (br * FP + j) * 2]);
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) { ys += v[i].x; yq += v[i].y; }
+    } else if (on) {
       for (int r = sl; r < NR; r += kF1Slices) {
         ys += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2];
         yq += ystats[(size_t)r * (2 * FP * 2) + (br * FP + j) * 2 + 1];
       }
+    }
     st_part[sl][t][0] = ys;
     st_part[sl][t][1] = yq;
     if (blockIdx.y == 0 && t < 2) {
-      float bsum = 0.f;
-      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) bsum += g_bias[r * 4 + 2 * br + t];
+      float bv[kPer], bsum = 0.f;
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) bv[i] = g_bias[(sl + i * kF1Slices) * 4 + 2 * br + t];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) bsum += bv[i];
       bias_part[sl][t] = bsum;
     }
   }
@@ -395,20 +407,33 @@ __device__ __forceinline__ void fold0_bwd_block(
   __shared__ double gs_part[kF1Slices][16][3];
   __shared__ double red[16][5];   // per feature: gE0, gE1, gC00, gC01, gC11 contributions
   const bool on = j < f;
+  // (a thread's loads all issued before the first is used: ONE memory round trip where a rolled loop over its four replicas was four)
+  constexpr int kPer = GWTF_STAT_REPLICAS / kF1Slices;
   if (t < 9) {
     float sacc = 0.f;
-    for (int r = sl; r < NR; r += kF1Slices) sacc += mom_rep[r * 16 + t];
+    if (NR == GWTF_STAT_REPLICAS) {
+      float v[kPer];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) v[i] = mom_rep[(sl + i * kF1Slices) * 16 + t];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) sacc += v[i];
+    } else {
+      for (int r = sl; r < NR; r += kF1Slices) sacc += mom_rep[r * 16 + t];
+    }
     mom_part[sl][t] = sacc;
   }
   {
     double g0 = 0.0, g1 = 0.0, gc = 0.0;
-    if (on)
-      for (int r = sl; r < GWTF_STAT_REPLICAS; r += kF1Slices) {
-        const float* gs = g_sd0 + (size_t)r * (2 * 3 * FP) + (size_t)br * 3 * FP;
-        g0 += gs[j];
-        g1 += gs[FP + j];
-        gc += gs[2 * FP + j];
+    if (on) {
+      float v[kPer][3];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const float* gs = g_sd0 + (size_t)(sl + i * kF1Slices) * (2 * 3 * FP) + (size_t)br * 3 * FP;
+        v[i][0] = gs[j]; v[i][1] = gs[FP + j]; v[i][2] = gs[2 * FP + j];
       }
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) { g0 += v[i][0]; g1 += v[i][1]; gc += v[i][2]; }
+    }
     gs_part[sl][t][0] = g0; gs_part[sl][t][1] = g1; gs_part[sl][t][2] = gc;
   }
   __syncthreads();
