@@ -127,6 +127,8 @@ _SIGNATURES = {
                                 [ctypes.c_int] * 3 + [_c_fp]),
     'gwtf_head_layer_backward': (ctypes.c_int, [_c_fp] * 9 + [ctypes.c_int] * 2 + [_c_fp] * 2 + [ctypes.c_int] + [_c_fp] * 4 +
                                  [ctypes.c_int] * 3 + [_c_fp]),
+    'gwtf_head_pair_forward': (ctypes.c_int, [_c_fp] * 9 + [ctypes.c_int] * 4 + [_c_fp]),
+    'gwtf_head_pair_backward': (ctypes.c_int, [_c_fp] * 18 + [ctypes.c_int] * 4 + [_c_fp]),
 }
 
 PHASE_FWD_INIT, PHASE_FWD_A, PHASE_FWD_B, PHASE_BWD_A, PHASE_BWD_B, PHASE_BWD_C = range(6)

@@ -49,17 +49,17 @@ __device__ __forceinline__ float bn_apply(float y, float mean, float rstd, float
 // used, out [B][Dout].  bn_mode 0: no BatchNorm; 1: batch statistics (+ running update, momentum form, unbiased variance, applied
 // bn_updates times: the reference evaluates p_prior once per mixture component on the same batch, models.py:169-193 inside
 // flow_mixture.py:163-166); 2: running statistics.  act 0: none, 1: swish, 2: log-softmax over the Dout (<= 16) columns.
-__global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const float* __restrict__ x, const float* __restrict__ W,
-                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ rmean,
-                                                            float* __restrict__ rvar, long long* __restrict__ nbt, float momentum,
-                                                            float bn_eps, int bn_mode, int bn_updates, int act,
-                                                            float* __restrict__ ypre, float* __restrict__ stats,
-                                                            float* __restrict__ out) {
+__device__ __forceinline__ void head_fwd_block(int bid, HeadDims d, const float* __restrict__ x, const float* __restrict__ W,
+                                               const float* __restrict__ bias, const float* __restrict__ gamma,
+                                               const float* __restrict__ beta, float* __restrict__ rmean,
+                                               float* __restrict__ rvar, long long* __restrict__ nbt, float momentum,
+                                               float bn_eps, int bn_mode, int bn_updates, int act,
+                                               float* __restrict__ ypre, float* __restrict__ stats,
+                                               float* __restrict__ out) {
   __shared__ float red[kThreads];
   __shared__ float work[kWorkFloats];
   const int B = d.B, Din = d.Din, Dout = d.Dout;
-  const int c0 = blockIdx.x * kCols, nc = min(kCols, Dout - c0);
+  const int c0 = bid * kCols, nc = min(kCols, Dout - c0);
   head_gemm(B, nc, Din, x, Din, 1, W + (size_t)c0 * Din, Din, 1, ypre + c0, Dout, false, work);
   phase_sync();
   const ColMap cm = col_map(kCols);
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
       }
     }
   }
-  if (bn_mode == 1 && nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += bn_updates;
+  if (bn_mode == 1 && nbt && bid == 0 && threadIdx.x == 0) *nbt += bn_updates;
   if (act == 2) {
     // log-softmax over the columns of a row (all in this workgroup: Dout <= kCols): thread t < B owns row t
     for (int b = threadIdx.x; b < B; b += kThreads) {
@@ -133,19 +133,40 @@ __global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const fl
   }
 }
 
+__global__ __launch_bounds__(kThreads) void head_fwd_kernel(HeadDims d, const float* __restrict__ x, const float* __restrict__ W,
+                                                            const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ rmean,
+                                                            float* __restrict__ rvar, long long* __restrict__ nbt, float momentum,
+                                                            float bn_eps, int bn_mode, int bn_updates, int act,
+                                                            float* __restrict__ ypre, float* __restrict__ stats,
+                                                            float* __restrict__ out) {
+  head_fwd_block(blockIdx.x, d, x, W, bias, gamma, beta, rmean, rvar, nbt, momentum, bn_eps, bn_mode, bn_updates, act, ypre, stats, out);
+}
+
+// TWO plain Linear heads on the same input (the mu / logvar heads of a FeatureEncoder, reference encoders.py:55-60) in one launch:
+// blocks [0, ceil(Dout_a / 16)) are head a's column blocks, the rest head b's
+struct HeadPair { const float* W[2]; const float* bias[2]; float* ypre[2]; float* out[2]; int Dout[2]; };
+__global__ __launch_bounds__(kThreads) void head_fwd_pair_kernel(int B, int Din, const float* __restrict__ x, HeadPair hp) {
+  const int na = (hp.Dout[0] + kCols - 1) / kCols;
+  const int h = (int)blockIdx.x < na ? 0 : 1, bid = (int)blockIdx.x - (h ? na : 0);
+  const HeadDims d = {B, Din, hp.Dout[h]};
+  head_fwd_block(bid, d, x, hp.W[h], hp.bias[h], nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1e-5f, 0, 1, 0, hp.ypre[h], nullptr,
+                 hp.out[h]);
+}
+
 // ---- backward, pass 1: per block of 16 output columns ---------------------------------------------------------------------------
 // g_out [B][Dout] = dL/d out;  writes g_y [B][Dout] = dL/d(x W^T) (scratch for pass 2), g_W [Dout][Din], g_bias / g_gamma / g_beta
 // [Dout] (each may be null).
-__global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const float* __restrict__ x, const float* __restrict__ bias,
-                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                             const float* __restrict__ ypre, const float* __restrict__ stats,
-                                                             const float* __restrict__ out, const float* __restrict__ g_out,
-                                                             int bn_mode, int act, float* __restrict__ g_y, float* __restrict__ g_W,
-                                                             float* __restrict__ g_bias, float* __restrict__ g_gamma,
-                                                             float* __restrict__ g_beta) {
+__device__ __forceinline__ void head_bwd1_block(int bid, HeadDims d, const float* __restrict__ x, const float* __restrict__ bias,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                const float* __restrict__ ypre, const float* __restrict__ stats,
+                                                const float* __restrict__ out, const float* __restrict__ g_out,
+                                                int bn_mode, int act, float* __restrict__ g_y, float* __restrict__ g_W,
+                                                float* __restrict__ g_bias, float* __restrict__ g_gamma,
+                                                float* __restrict__ g_beta) {
   __shared__ float red[kThreads];
   const int B = d.B, Din = d.Din, Dout = d.Dout;
-  const int c0 = blockIdx.x * kCols, nc = min(kCols, Dout - c0);
+  const int c0 = bid * kCols, nc = min(kCols, Dout - c0);
   const ColMap cm = col_map(kCols);
   const int col = c0 + cm.col;
   const bool live = cm.on && cm.col < nc;
@@ -252,12 +273,41 @@ __global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const f
   }
 }
 
+__global__ __launch_bounds__(kThreads) void head_bwd1_kernel(HeadDims d, const float* __restrict__ x, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ ypre, const float* __restrict__ stats,
+                                                             const float* __restrict__ out, const float* __restrict__ g_out,
+                                                             int bn_mode, int act, float* __restrict__ g_y, float* __restrict__ g_W,
+                                                             float* __restrict__ g_bias, float* __restrict__ g_gamma,
+                                                             float* __restrict__ g_beta) {
+  head_bwd1_block(blockIdx.x, d, x, bias, gamma, beta, ypre, stats, out, g_out, bn_mode, act, g_y, g_W, g_bias, g_gamma, g_beta);
+}
+
+struct HeadPairBwd { const float* bias[2]; const float* ypre[2]; const float* out[2]; const float* g_out[2]; float* g_y[2]; float* g_W[2];
+                     float* g_bias[2]; const float* W[2]; int Dout[2]; };
+__global__ __launch_bounds__(kThreads) void head_bwd1_pair_kernel(int B, int Din, const float* __restrict__ x, HeadPairBwd hp) {
+  const int na = (hp.Dout[0] + kCols - 1) / kCols;
+  const int h = (int)blockIdx.x < na ? 0 : 1, bid = (int)blockIdx.x - (h ? na : 0);
+  const HeadDims d = {B, Din, hp.Dout[h]};
+  head_bwd1_block(bid, d, x, hp.bias[h], nullptr, nullptr, hp.ypre[h], nullptr, hp.out[h], hp.g_out[h], 0, 0, hp.g_y[h], hp.g_W[h],
+                  hp.g_bias[h], nullptr, nullptr);
+}
+
 // ---- backward, pass 2: per block of 16 input columns: g_x[:, block] (+)= g_y W[:, block] ------------------------------------------
 __global__ __launch_bounds__(kThreads) void head_bwd2_kernel(HeadDims d, const float* __restrict__ W, const float* __restrict__ g_y,
                                                              float* __restrict__ g_x, int accumulate) {
   const int c0 = blockIdx.x * kCols, nc = min(kCols, d.Din - c0);
   __shared__ float work[kWorkFloats];
   head_gemm(d.B, nc, d.Dout, g_y, d.Dout, 1, W + c0, 1, d.Din, g_x + c0, d.Din, accumulate != 0, work);
+}
+
+// the pair's input gradient: g_x[:, block] = g_ya Wa[:, block] + g_yb Wb[:, block] (the second product accumulates onto the first)
+__global__ __launch_bounds__(kThreads) void head_bwd2_pair_kernel(int B, int Din, HeadPairBwd hp, float* __restrict__ g_x) {
+  const int c0 = blockIdx.x * kCols, nc = min(kCols, Din - c0);
+  __shared__ float work[kWorkFloats];
+  head_gemm(B, nc, hp.Dout[0], hp.g_y[0], hp.Dout[0], 1, hp.W[0] + c0, 1, Din, g_x + c0, Din, false, work);
+  phase_sync();
+  head_gemm(B, nc, hp.Dout[1], hp.g_y[1], hp.Dout[1], 1, hp.W[1] + c0, 1, Din, g_x + c0, Din, true, work);
 }
 
 constexpr int kMaxRows = 1 << 16;   // any batch: the kernels walk it in blocks of 64 / 128 rows
@@ -297,5 +347,34 @@ extern "C" int gwtf_head_layer_backward(const float* x, const float* W, const fl
                      out, g_out, bn_mode, act, g_y, g_W, g_bias, g_gamma, g_beta);
   if (g_x)
     hipLaunchKernelGGL(head_bwd2_kernel, dim3((Din + kCols - 1) / kCols), dim3(kThreads), 0, st, d, W, g_y, g_x, accumulate_g_x);
+  return (int)hipGetLastError();
+}
+
+// see include/gwtf.h
+extern "C" int gwtf_head_pair_forward(const float* x, const float* Wa, const float* bias_a, const float* Wb, const float* bias_b,
+                                      float* ypre_a, float* out_a, float* ypre_b, float* out_b, int B, int Din, int Dout_a, int Dout_b,
+                                      void* stream) {
+  if (!x || !Wa || !Wb || !ypre_a || !out_a || !ypre_b || !out_b || !dims_ok(B, Din, Dout_a) || !dims_ok(B, Din, Dout_b))
+    return GWTF_E_BADARG;
+  HeadPair hp = {{Wa, Wb}, {bias_a, bias_b}, {ypre_a, ypre_b}, {out_a, out_b}, {Dout_a, Dout_b}};
+  const int blocks = (Dout_a + kCols - 1) / kCols + (Dout_b + kCols - 1) / kCols;
+  hipLaunchKernelGGL(head_fwd_pair_kernel, dim3(blocks), dim3(kThreads), 0, (hipStream_t)stream, B, Din, x, hp);
+  return (int)hipGetLastError();
+}
+
+extern "C" int gwtf_head_pair_backward(const float* x, const float* Wa, const float* bias_a, const float* Wb, const float* bias_b,
+                                       const float* ypre_a, const float* out_a, const float* ypre_b, const float* out_b,
+                                       const float* g_out_a, const float* g_out_b, float* g_y_a, float* g_y_b, float* g_x, float* g_Wa,
+                                       float* g_bias_a, float* g_Wb, float* g_bias_b, int B, int Din, int Dout_a, int Dout_b,
+                                       void* stream) {
+  if (!x || !Wa || !Wb || !ypre_a || !out_a || !ypre_b || !out_b || !g_out_a || !g_out_b || !g_y_a || !g_y_b ||
+      !dims_ok(B, Din, Dout_a) || !dims_ok(B, Din, Dout_b))
+    return GWTF_E_BADARG;
+  HeadPairBwd hp = {{bias_a, bias_b}, {ypre_a, ypre_b}, {out_a, out_b}, {g_out_a, g_out_b}, {g_y_a, g_y_b}, {g_Wa, g_Wb},
+                    {g_bias_a, g_bias_b}, {Wa, Wb}, {Dout_a, Dout_b}};
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (Dout_a + kCols - 1) / kCols + (Dout_b + kCols - 1) / kCols;
+  hipLaunchKernelGGL(head_bwd1_pair_kernel, dim3(blocks), dim3(kThreads), 0, st, B, Din, x, hp);
+  if (g_x) hipLaunchKernelGGL(head_bwd2_pair_kernel, dim3((Din + kCols - 1) / kCols), dim3(kThreads), 0, st, B, Din, hp, g_x);
   return (int)hipGetLastError();
 }

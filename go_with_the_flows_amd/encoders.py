@@ -13,6 +13,7 @@ without kernels, an input that itself requires a gradient.  CPU tensors raise: t
 (FeatureEncoder, WeightsEncoder) run one HIP launch per layer, forward and backward (csrc/gwtf_heads.hip, ``_HeadLayerFn``), for any
 number of rows (the gathered rows of a large data-parallel batch are walked 64 / 128 at a time inside the kernels).
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -403,6 +404,51 @@ class _HeadLayerFn(torch.autograd.Function):
         return g_x, g_W, g_b, g_ga, g_be, None, None, None, None
 
 
+class _HeadPairFn(torch.autograd.Function):
+    """The mu and logvar heads of a FeatureEncoder (two plain Linear layers on the same hidden activations) in ONE launch forward and
+    two backward (csrc/gwtf_heads.hip head_*_pair_kernel): the same arithmetic as two _HeadLayerFn calls."""
+
+    @staticmethod
+    def forward(ctx, x, Wa, ba, Wb, bb):
+        L = _lib.lib()
+        x, Wa, Wb = x.contiguous(), Wa.contiguous(), Wb.contiguous()
+        B, Din = x.shape
+        Da, Db = Wa.shape[0], Wb.shape[0]
+        new = lambda *shape: torch.empty(*shape, device=x.device, dtype=torch.float32)
+        ypre_a, out_a, ypre_b, out_b = new(B, Da), new(B, Da), new(B, Db), new(B, Db)
+        P = lambda t: None if t is None else _ptr(t.contiguous() if not t.is_contiguous() else t, 'head operand')
+        with torch.cuda.device(x.device):
+            check(L.gwtf_head_pair_forward(P(x), P(Wa), P(ba), P(Wb), P(bb), P(ypre_a), P(out_a), P(ypre_b), P(out_b), B, Din, Da, Db,
+                                           _stream(x)))
+        ctx.save_for_backward(x, Wa, ba, Wb, bb, ypre_a, out_a, ypre_b, out_b)
+        ctx.set_materialize_grads(False)       # an output the loss does not read arrives as None: its head's parameters get no gradient
+        return out_a, out_b
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        L = _lib.lib()
+        x, Wa, ba, Wb, bb, ypre_a, out_a, ypre_b, out_b = ctx.saved_tensors
+        B, Din = x.shape
+        Da, Db = Wa.shape[0], Wb.shape[0]
+        new = lambda *shape: torch.empty(*shape, device=x.device, dtype=torch.float32)
+        if g_a is None and g_b is None:
+            return None, None, None, None, None
+        used_a, used_b = g_a is not None, g_b is not None
+        g_a = torch.zeros_like(out_a) if g_a is None else g_a.contiguous().float()
+        g_b = torch.zeros_like(out_b) if g_b is None else g_b.contiguous().float()
+        need = ctx.needs_input_grad
+        g_x = new(B, Din) if need[0] else None
+        g_Wa, g_Wb = (new(Da, Din) if need[1] else None), (new(Db, Din) if need[3] else None)
+        g_ba = new(Da) if (ba is not None and need[2]) else None
+        g_bb = new(Db) if (bb is not None and need[4]) else None
+        g_ya, g_yb = new(B, Da), new(B, Db)
+        P = lambda t: None if t is None else t.data_ptr()
+        with torch.cuda.device(x.device):
+            check(L.gwtf_head_pair_backward(P(x), P(Wa), P(ba), P(Wb), P(bb), P(ypre_a), P(out_a), P(ypre_b), P(out_b), P(g_a), P(g_b),
+                                            P(g_ya), P(g_yb), P(g_x), P(g_Wa), P(g_ba), P(g_Wb), P(g_bb), B, Din, Da, Db, _stream(x)))
+        return g_x, (g_Wa if used_a else None), (g_ba if used_a else None), (g_Wb if used_b else None), (g_bb if used_b else None)
+
+
 class FeatureEncoder(nn.Module):
     """Per-shape MLP with Gaussian heads (reference encoders.py:31-85)."""
 
@@ -540,6 +586,13 @@ class FeatureEncoder(nn.Module):
         h = self._hidden(input, bn_updates)
         if self.deterministic:
             return self._head(self.mus, h, self._head_act)
+        la, lb = self.mus[-1], self.logvars[-1]
+        if (self._head_act == 0 and h.is_cuda and h.dtype == torch.float32 and len(self.mus) == 1 and len(self.logvars) == 1
+                and la.weight.dtype == torch.float32 and lb.weight.dtype == torch.float32
+                and max(*la.weight.shape, *lb.weight.shape) <= self.hip_max_width and os.environ.get('GWTF_NO_HEAD_PAIR') != '1'
+                and _lib.lib().gwtf_head_layer_supported(h.shape[0], la.weight.shape[1], la.weight.shape[0], 0)
+                and _lib.lib().gwtf_head_layer_supported(h.shape[0], lb.weight.shape[1], lb.weight.shape[0], 0)):
+            return _HeadPairFn.apply(h, la.weight, la.bias, lb.weight, lb.bias)      # both heads: one launch
         return self._head(self.mus, h, self._head_act), self._head(self.logvars, h)
 
 

@@ -576,6 +576,16 @@ int gwtf_head_layer_backward(const float* x, const float* W, const float* bias, 
                              const float* ypre, const float* stats, const float* out, const float* g_out, int bn_mode, int act,
                              float* g_y, float* g_x, int accumulate_g_x, float* g_W, float* g_bias, float* g_gamma, float* g_beta,
                              int B, int Din, int Dout, void* stream);
+/* The two plain Linear heads of a FeatureEncoder (mu and logvar: y = x W^T + bias, no BatchNorm, no activation; reference
+ * encoders.py:55-60) on the same input, one launch forward and two backward where two calls of gwtf_head_layer_* are two and four:
+ * ypre_* / out_* [B][Dout_*] as gwtf_head_layer_forward leaves them; g_y_* [B][Dout_*] scratch; g_x [B][Din] (may be NULL) = the sum of
+ * both heads' input gradients; g_W_* [Dout_*][Din], g_bias_* [Dout_*] (each may be NULL). */
+int gwtf_head_pair_forward(const float* x, const float* Wa, const float* bias_a, const float* Wb, const float* bias_b, float* ypre_a,
+                           float* out_a, float* ypre_b, float* out_b, int B, int Din, int Dout_a, int Dout_b, void* stream);
+int gwtf_head_pair_backward(const float* x, const float* Wa, const float* bias_a, const float* Wb, const float* bias_b,
+                            const float* ypre_a, const float* out_a, const float* ypre_b, const float* out_b, const float* g_out_a,
+                            const float* g_out_b, float* g_y_a, float* g_y_b, float* g_x, float* g_Wa, float* g_bias_a, float* g_Wb,
+                            float* g_bias_b, int B, int Din, int Dout_a, int Dout_b, void* stream);
 
 #ifdef __cplusplus
 }

@@ -101,3 +101,34 @@ def test_heads_refuse_what_the_kernels_do_not_cover_and_fall_back_to_the_library
     m = m.float()
     with pytest.raises(ValueError):                            # one row in train mode: BatchNorm raises (torch raises the same)
         m(torch.randn(1, 16, device=DEV))
+
+
+@pytest.mark.parametrize('B,din,dout', [(64, 512, 128), (64, 128, 3), (130, 40, 33)])
+def test_head_pair_launch_equals_the_two_single_launches_bit_for_bit(B, din, dout, monkeypatch):
+    """The mu / logvar heads in one launch (csrc/gwtf_heads.hip head_*_pair_kernel): same blocks, same products as one launch per head;
+    also with only ONE of the two outputs in the loss (the other head's upstream gradient is None)."""
+    torch.manual_seed(B + dout)
+    m = encoders.FeatureEncoder(1, din, dout, deterministic=False, easy_init=True).to(DEV).train()
+    x0 = torch.randn(B, din, device=DEV)
+    w = torch.randn(2, B, dout, device=DEV)
+    res = {}
+    for use_b in (True, False):
+        for name in ('pair', 'single'):
+            if name == 'single':
+                monkeypatch.setenv('GWTF_NO_HEAD_PAIR', '1')
+            else:
+                monkeypatch.delenv('GWTF_NO_HEAD_PAIR', raising=False)
+            m.zero_grad(set_to_none=True)
+            st = {k: v.clone() for k, v in m.state_dict().items()}
+            x = x0.clone().requires_grad_(True)
+            mu, lv = m(x)
+            ((mu * w[0]).sum() + ((lv * lv * w[1]).sum() if use_b else 0.0)).backward()
+            res[name] = [mu, lv, x.grad] + [p.grad for p in m.parameters()]
+            m.load_state_dict(st)                                  # (the trunk's running statistics moved)
+        for i, (a, b) in enumerate(zip(res['pair'], res['single'])):
+            if i == 2 and use_b:
+                # dL/dx: the pair's second product accumulates onto the first inside the kernel, two launches are summed by autograd --
+                # the same terms in another association
+                assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+            else:
+                assert (a is None and b is None) or torch.equal(a, b), i
