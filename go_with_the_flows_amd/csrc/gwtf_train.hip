@@ -892,13 +892,37 @@ __global__ void gather_table_kernel(const unsigned long long* __restrict__ table
   const float* __restrict__ src = reinterpret_cast<const float*>(row[0]);
   float* __restrict__ out = dst + row[1];
   const size_t m = row[2];
-  for (size_t i = threadIdx.x; i < m; i += blockDim.x) out[i] = src[i];
+  // eight loads in flight per thread (a rolled load -> store loop is a round trip per iteration: 37 of them for a FiLM head's first
+  // layer, which set the launch's time)
+  constexpr int U = 8;
+  const size_t step = (size_t)U * blockDim.x;
+  size_t i0 = 0;
+  for (; i0 + step <= m; i0 += step) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = src[i0 + u * blockDim.x + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < U; ++u) out[i0 + u * blockDim.x + threadIdx.x] = v[u];
+  }
+  {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * blockDim.x + threadIdx.x;
+      v[u] = i < m ? src[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const size_t i = i0 + u * blockDim.x + threadIdx.x;
+      if (i < m) out[i] = v[u];
+    }
+  }
 }
 }  // namespace
 
 extern "C" int gwtf_gather_table(const unsigned long long* table, float* dst, int n, void* stream) {
   if (!table || !dst || n <= 0) return GWTF_E_BADARG;
-  hipLaunchKernelGGL(gather_table_kernel, dim3(n), dim3(128), 0, (hipStream_t)stream, table, dst, n);
+  hipLaunchKernelGGL(gather_table_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table, dst, n);
   return (int)hipGetLastError();
 }
 
